@@ -1,0 +1,192 @@
+/* libmico_hip.so - C-ABI of the MI355X (gfx950) kernels behind the MiCo omni-modal forward/backward hot path.
+ *
+ * The reference (invictus717/MiCo) has no FFI/operator layer: its hot path is PyTorch eager op sequences
+ * (SURVEY.md section 2.2).  Each entry point below replaces one such sequence; the reference site it replaces is
+ * cited as file:line relative to the reference root.  Conventions:
+ *   - raw device pointers, caller owns all memory (incl. workspaces); plain ints/floats; no torch types;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates, never syncs;
+ *   - returns 0 on success, a negative MICO_E* code otherwise; mico_last_error_string() describes the failure;
+ *   - `dtype` selects the 16-bit MFMA element type for activations / weights (MICO_F16 | MICO_BF16); the
+ *     residual stream, LayerNorm statistics, softmax, losses, parameters' gradients are fp32.
+ *   - matrices are row-major with explicit leading dimensions given in ELEMENTS.
+ */
+#ifndef MICO_HIP_H
+#define MICO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MICO_F16 0
+#define MICO_BF16 1
+#define MICO_F32 2
+
+#define MICO_OK 0
+#define MICO_EINVAL (-22)
+#define MICO_ELAUNCH (-5)
+
+/* library identity / errors */
+int mico_version(void);
+const char* mico_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GEMM on MFMA (v_mfma_f32_16x16x32_{f16,bf16}), fp32 accumulate, fused epilogues.
+ *   C[M,N] = epilogue( sum_k opA(A)[m,k] * opB(B)[k,n] )
+ *   ta == 0: A is [M,K] (lda >= K)      ta == 1: A is stored [K,M] (lda >= M)   (reduction-major, read transposed)
+ *   tb == 0: B is [N,K] (ldb >= K)      tb == 1: B is stored [K,N] (ldb >= N)
+ * so nn.Linear forward  y = x W^T        is (ta=0,tb=0, A=x, B=W);                  eva_vit_model.py:191,197,310,363
+ *    its input gradient  dx = dy W        is (ta=0,tb=1, A=dy, B=W);
+ *    its weight gradient dW = dy^T x      is (ta=1,tb=1, A=dy, B=x) with M=out_features, N=in_features.
+ * All leading dimensions and K-contiguous extents must be multiples of 8 elements (16-byte rows).
+ *
+ * Epilogue (applied per element v = alpha * acc, in this order):
+ *   v += bias[n]                              (bias  != NULL, fp32 [N])
+ *   aux_out[m,n] = T(v)                       (aux_out != NULL: pre-activation copy, 16-bit, ld = ldaux)
+ *   act: MICO_ACT_GELU -> v = gelu_erf(v);  MICO_ACT_GELU_GRAD -> v *= gelu'(aux_in[m,n]);
+ *        MICO_ACT_SILU_MUL_GRAD etc. see enum
+ *   v *= row_scale[m / rows_per_scale]        (row_scale != NULL: DropPath per-sample factor, eva_vit_model.py:121-138)
+ *   v += resid[m,n]                           (resid != NULL, fp32, ld = ldc; may alias C)
+ *   v += pos[(m % pos_rows) , n]              (pos != NULL, fp32 [pos_rows,N]: positional table, eva_vit_model.py:619)
+ *   out row index: m' = m + (m / remap_group) * remap_skip + remap_offset   (patch rows -> token rows, :616-619)
+ *   C[m',n] = v  (fp32 if c_dtype == MICO_F32 (beta=1 accumulates: C += v, uses atomics when split_k > 1) else T)
+ * ------------------------------------------------------------------------------------------------------------- */
+#define MICO_ACT_NONE 0
+#define MICO_ACT_GELU 1      /* v = gelu(v) */
+#define MICO_ACT_GELU_GRAD 2 /* v = v * gelu'(aux_in) */
+
+typedef struct mico_gemm_epilogue {
+    const float* bias;      /* [N] or NULL */
+    void* aux_out;          /* 16-bit [M,N] pre-activation copy or NULL */
+    const void* aux_in;     /* 16-bit [M,N] (GELU_GRAD) or NULL */
+    int64_t ldaux;
+    int act;
+    const float* row_scale; /* [ceil(M / rows_per_scale)] or NULL */
+    int rows_per_scale;
+    const float* resid;     /* fp32 [M,N] (ld = ldc, indexed with the remapped row) or NULL */
+    const float* pos;       /* fp32 [pos_rows, N] or NULL */
+    int pos_rows;
+    int remap_group;        /* 0 = no row remap */
+    int remap_skip;
+    int remap_offset;
+    float alpha;
+    int accumulate;         /* fp32 output only: C += v */
+} mico_gemm_epilogue;
+
+int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
+              const void* A, int64_t lda, const void* B, int64_t ldb,
+              void* C, int64_t ldc, int c_dtype,
+              const mico_gemm_epilogue* epi, int split_k, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * LayerNorm (row statistics in fp32).  Replaces model/evaclip/transformer.py:121-127 (eps 1e-6) and
+ * torch.nn.LayerNorm in model/bert.py:92,147,288,296 / model/mico.py:49,400-403 (eps 1e-12).
+ *   x: [rows, cols] fp32 (x_dtype == MICO_F32) or 16-bit;  y16 / y32 optional outputs;  mean/rstd [rows] saved.
+ *   post_add (optional, fp32 [post_groups, cols]): y += post_add[(row / post_rows_per_group) % post_groups]
+ *   (frame + type embeddings of model/mico.py:201,209).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                       void* y16, float* y32, float* mean, float* rstd,
+                       int64_t rows, int cols, float eps,
+                       const float* post_add, int post_rows_per_group, int post_groups,
+                       int dtype, void* stream);
+/* dx = LN'(dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 and/or dx16 (dx16 = T(dx * scale16)).
+ * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced
+ * and ACCUMULATED (+=) into dgamma/dbeta (fp32 [cols]) scaled by grad_scale. */
+int mico_layernorm_bwd_nblk(int64_t rows);
+int mico_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const float* dx_add, float* dx32, void* dx16, float scale16,
+                       float* dgamma, float* dbeta, float grad_scale, float* ws,
+                       int64_t rows, int cols, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused scaled-dot-product attention (flash style: scores never materialised), forward and backward.
+ * Replaces eva_vit_model.py:340-361 and bert.py:246-277 (self and cross attention).
+ *   q: rows (b, i) at q + b*q_bs + i*q_rs + h*hd ;  k,v likewise with Sk rows ;  o: (b,i) at o + b*o_bs + i*o_rs + h*hd
+ *   (strides in elements, multiples of 8) - lets q/k/v alias one fused [M, 3*H*hd] projection buffer.
+ *   hd in {64, 88, 96, 128}(padded to a multiple of 32 in LDS); scale multiplies q.k (EVA scales q first, BERT divides
+ *   the scores - equal up to rounding).
+ *   mask_mode 0: none; 1: additive key mask fp32 [B, Sk]; 2: additive fp32 [B, Sq, Sk]   (bert.py:764-780, -10000 based)
+ *   lse: fp32 [B, H, Sq] log-sum-exp saved for backward.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct mico_attn_params {
+    int B, H, Sq, Sk, hd;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    float scale;
+    const float* mask;
+    int mask_mode;
+} mico_attn_params;
+
+int mico_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                  const mico_attn_params* p, int dtype, void* stream);
+/* dq/dk/dv use the q/k/v strides; d_o uses the o strides; delta: fp32 workspace [B,H,Sq]. */
+int mico_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                  void* dq, void* dk, void* dv, float* delta,
+                  const mico_attn_params* p, int dtype, void* stream);
+
+/* RoPE on tokens 1.. of a [B, N, H, hd] (row stride rs, batch stride bs) buffer, in place; inverse = transposed
+ * rotation for the backward.  cos/sin fp32 [N-1, hd].  rope.py:121-137, eva_vit_model.py:314-322. */
+int mico_rope(void* x, int64_t bs, int64_t rs, int B, int N, int H, int hd, const float* cos_t, const float* sin_t,
+              int inverse, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Patch embedding front-end: im2row of [B,C,H,W] fp32 pixels into 16-bit rows [B*(H/P)*(W/P), kpad]
+ * (k = c*P*P + i*P + j, zero padded to kpad); the projection itself is mico_gemm with pos/remap epilogue.
+ * eva_vit_model.py:440-448.  C may be 1 (audio spectrogram with channel-summed weights, mico.py:140).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_im2row(const float* pixels, void* rows16, int B, int C, int H, int W, int P, int kpad, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Elementwise / data-movement helpers (all HBM-bound, 16-byte vectorised).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* dst16[r, 0:cols_pad] = T(scale * src32[r, 0:cols]) zero-padded; */
+int mico_cast_f32_to_16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int cols_pad,
+                        float scale, int dtype, void* stream);
+int mico_cast_16_to_f32(const void* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int cols,
+                        float scale, int accumulate, int dtype, void* stream);
+/* dst16[m', :] = T(scale * row_scale[m'/rows_per_scale] * src32[m, :]) with the same row remap as the GEMM epilogue
+ * (gathers token rows out of the residual-gradient stream, skipping CLS rows).  rows = number of output rows. */
+int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                          int remap_group, int remap_skip, int remap_offset,
+                          const float* row_scale, int rows_per_scale, float scale, int dtype, void* stream);
+/* out[c] (+)= scale * sum_r x[r, c]   (bias gradients, positional-table gradients).  x fp32 or 16-bit. */
+int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows, int cols, float* out, float scale, int accumulate,
+                void* stream);
+/* x[b*group_rows + 0, :] = cls[:] + pos[0, :]  for every frame b (fp32).  eva_vit_model.py:616-619. */
+int mico_cls_rows(float* x, int64_t ld, int B, int group_rows, const float* cls, const float* pos0, int cols, void* stream);
+/* y[r,:] = a[r,:] + b[r,:] (fp32), optional 16-bit copy */
+int mico_add_f32(const float* a, const float* b, float* y, void* y16, int64_t n, float scale16, int dtype, void* stream);
+
+/* SwiGLU gate (eva_vit_model.py:217-220): h = silu(x1) * x2, 16-bit in/out, and its backward. */
+int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t n, int dtype, void* stream);
+int mico_swiglu_bwd(const void* x1, const void* x2, const void* dh, void* dx1, void* dx2, int64_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BERT embeddings: out = LN(word[ids] + type[0] + pos[s]) (bert.py:139-148) and the word-gradient scatter-add.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                        float* sum32, int64_t rows, int S, int cols, int vocab, void* stream);
+int mico_embed_scatter_add(const int64_t* ids, const float* dsum, float* dword, float* dpos, float* dtype0,
+                           int64_t rows, int S, int cols, int vocab, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Losses.
+ *  mico_ce_fwd_bwd: row-wise cross-entropy with label smoothing over fp32 or 16-bit logits [rows, cols] (ld):
+ *     loss_sum += sum_r CE(logits[r], target[r]),  n_valid += #(target != ignore_index)
+ *     dlogits (16-bit or fp32, may be NULL) = dscale * (softmax - smoothed_onehot)   (0 for ignored rows)
+ *  Replaces F.cross_entropy in vast.py:411-414,455 and bert.py:1088-1090 (logits_scale = 1/temp for ITC).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t rows, int cols,
+                    const int64_t* target, int ignore_index, float label_smoothing, float logits_scale,
+                    float* row_loss, float* row_lse,
+                    void* dlogits, int dlogits_dtype, int64_t ld_d, const float* dscale_ptr, float dscale,
+                    int dtype, void* stream);
+/* L2 normalise rows (F.normalize, eps 1e-12) forward / backward, fp32. */
+int mico_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int cols, void* stream);
+int mico_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

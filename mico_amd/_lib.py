@@ -1,0 +1,94 @@
+"""ctypes binding of libmico_hip.so (the C-ABI in include/mico_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  `lib()` raises if the shared object has not been
+built (python __graft_entry__.py / make -C mico_amd/csrc) so a missing extension can never be mistaken for a pass.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmico_hip.so")
+
+F16, BF16, F32 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+
+c_i64, c_int, c_f, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [
+        ("bias", c_vp), ("aux_out", c_vp), ("aux_in", c_vp), ("ldaux", c_i64), ("act", c_int),
+        ("row_scale", c_vp), ("rows_per_scale", c_int), ("resid", c_vp), ("pos", c_vp), ("pos_rows", c_int),
+        ("remap_group", c_int), ("remap_skip", c_int), ("remap_offset", c_int), ("alpha", c_f), ("accumulate", c_int),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int), ("hd", c_int),
+        ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64), ("v_bs", c_i64), ("v_rs", c_i64),
+        ("o_bs", c_i64), ("o_rs", c_i64), ("scale", c_f), ("mask", c_vp), ("mask_mode", c_int),
+    ]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mico_hip.h one to one
+PROTOTYPES = {
+    "mico_version": [],
+    "mico_last_error_string": [],
+    "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
+                  C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
+    "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
+                           c_int, c_vp],
+    "mico_layernorm_bwd_nblk": [c_i64],
+    "mico_layernorm_bwd": [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
+                           c_i64, c_int, c_int, c_vp],
+    "mico_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
+    "mico_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
+    "mico_rope": [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "mico_im2row": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "mico_cast_f32_to_16": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_f, c_int, c_vp],
+    "mico_cast_16_to_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f, c_int, c_int, c_vp],
+    "mico_gather_rows_cast": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_int, c_f, c_int, c_vp],
+    "mico_colsum": [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_f, c_int, c_vp],
+    "mico_cls_rows": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp],
+    "mico_add_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_int, c_vp],
+    "mico_swiglu_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_swiglu_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_bert_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp],
+    "mico_embed_scatter_add": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_f, c_vp],
+    "mico_ce_fwd_bwd": [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_int, c_i64,
+                        c_vp, c_f, c_int, c_vp],
+    "mico_l2norm_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_l2norm_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+}
+_RESTYPES = {"mico_last_error_string": C.c_char_p}
+
+_lib = None
+
+
+class MicoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libmico_hip.so once; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MicoHipError(
+            f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mico_amd/csrc`).  mico_amd has no CPU/PyTorch fallback path.")
+    l = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(l, name)   # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mico_last_error_string()
+        raise MicoHipError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

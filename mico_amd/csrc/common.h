@@ -1,0 +1,112 @@
+// Shared device helpers for the MiCo gfx950 kernels (CDNA4 only: wave64, MFMA 16x16x32, LDS-DMA, tr-reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mico_hip.h"
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_AS __attribute__((address_space(3)))
+
+extern thread_local char g_mico_err[256];
+int mico_set_err(int code, const char* fmt, ...);
+
+#define MICO_CHECK(cond, ...)                         \
+    do {                                              \
+        if (!(cond)) return mico_set_err(MICO_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define MICO_LAUNCH_CHECK()                                                        \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) return mico_set_err(MICO_ELAUNCH, "%s: %s", __func__, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- 16-bit element traits -------------------------------------------------------------------------------------
+template <typename T> struct T16;
+template <> struct T16<f16> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct T16<bf16> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x4 mfma(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+template <typename T> __device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
+    typename T16<T>::v4 v;
+    v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
+    return __builtin_bit_cast(s16x4, v);
+}
+template <typename T> __device__ __forceinline__ f32x4 unpack4(s16x4 s) {
+    typename T16<T>::v4 v = __builtin_bit_cast(typename T16<T>::v4, s);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void unpack8(s16x8 s, float* o) {
+    typename T16<T>::v8 v = __builtin_bit_cast(typename T16<T>::v8, s);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ s16x8 pack8(const float* o) {
+    typename T16<T>::v8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)o[i];
+    return __builtin_bit_cast(s16x8, v);
+}
+
+// exact (erf) GELU and its derivative - matches nn.GELU / mico.py:22-28
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Transposed LDS read (ds_read_b64_tr_b16): within each 16-lane group, lane p supplies the address of 4
+// contiguous 16-bit elements [row p>>2][cols (p&3)*4..+3] of a 4x16 block; lane i receives column i (4 rows).
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(uintptr_t)p);
+}
+
+template <typename F> __global__ void generic_kernel(F f) { f(); }
+
+static inline int dtype_ok(int dt) { return dt == MICO_F16 || dt == MICO_BF16; }
+
+#define DISPATCH_T16(dt, ...)                 \
+    do {                                      \
+        if ((dt) == MICO_F16) { typedef f16 T; __VA_ARGS__; } \
+        else { typedef bf16 T; __VA_ARGS__; } \
+    } while (0)

@@ -1,0 +1,426 @@
+// HBM-bound helpers: casts, row gathers, column sums, im2row, RoPE, SwiGLU gate, BERT embedding gather/scatter,
+// L2-normalise.  All of them move 16 bytes per lane where the layout allows and are grid-stride over at most
+// 2048 workgroups (cdna_hip_programming.md Guideline 11/13).  See include/mico_hip.h for the contracts.
+#include "common.h"
+
+namespace {
+
+constexpr int EB = 256;
+inline int egrid(int64_t work_items) {
+    int64_t nb = (work_items + EB - 1) / EB;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// ---- casts --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_f32_to_16_kernel(const float* __restrict__ src, int64_t ld_src, T* __restrict__ dst, int64_t ld_dst,
+                                      int64_t rows, int cols, int cols_pad, float scale) {
+    const int vpr = cols_pad >> 2;   // 4-element groups per output row
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * 4;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (c + k < cols) ? src[r * ld_src + c + k] * scale : 0.f;
+        *(s16x4*)(dst + r * ld_dst + c) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <typename T>
+__global__ void cast_16_to_f32_kernel(const T* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int64_t ld_dst,
+                                      int64_t rows, int cols, float scale, int accumulate) {
+    const int vpr = cols >> 2;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * 4;
+        f32x4 v = unpack4<T>(*(const s16x4*)(src + r * ld_src + c)) * scale;
+        f32x4* d = (f32x4*)(dst + r * ld_dst + c);
+        if (accumulate) *d += v;
+        else *d = v;
+    }
+}
+
+template <typename T>
+__global__ void gather_rows_cast_kernel(const float* __restrict__ src, int64_t ld_src, T* __restrict__ dst, int64_t ld_dst,
+                                        int64_t rows, int cols, int remap_group, int remap_skip, int remap_offset,
+                                        const float* __restrict__ row_scale, int rows_per_scale, float scale) {
+    const int vpr = cols >> 2;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * 4;
+        int64_t rs = r;
+        if (remap_group) rs = r + (r / remap_group) * remap_skip + remap_offset;
+        float sc = scale;
+        if (row_scale) sc *= row_scale[rs / rows_per_scale];
+        f32x4 v = *(const f32x4*)(src + rs * ld_src + c) * sc;
+        *(s16x4*)(dst + r * ld_dst + c) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- column sums: out[c] (+)= scale * sum_r x[r,c] ----------------------------------------------------------------
+// grid (col slabs of 256, row chunks); each thread owns one column for a chunk of rows, partial sums via atomics.
+template <typename XT>
+__global__ void colsum_kernel(const XT* __restrict__ x, int64_t ld, int64_t rows, int cols, float* __restrict__ out,
+                              float scale, int64_t rows_per_chunk) {
+    const int c = blockIdx.x * EB + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rows_per_chunk);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += (float)x[r * ld + c];
+        s1 += (float)x[(r + 1) * ld + c];
+        s2 += (float)x[(r + 2) * ld + c];
+        s3 += (float)x[(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) s0 += (float)x[r * ld + c];
+    unsafeAtomicAdd(out + c, ((s0 + s1) + (s2 + s3)) * scale);
+}
+
+__global__ void zero_kernel(float* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) p[i] = 0.f;
+}
+
+__global__ void cls_rows_kernel(float* __restrict__ x, int64_t ld, int B, int group_rows, const float* __restrict__ cls,
+                                const float* __restrict__ pos0, int cols) {
+    const int64_t total = (int64_t)B * cols;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t b = i / cols;
+        const int c = (int)(i - b * cols);
+        x[b * group_rows * ld + c] = cls[c] + pos0[c];
+    }
+}
+
+template <typename T>
+__global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                               T* __restrict__ y16, int64_t n4, float scale16) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+        f32x4 v = ((const f32x4*)a)[i];
+        if (b) v += ((const f32x4*)b)[i];
+        if (y) ((f32x4*)y)[i] = v;
+        if (y16) {
+            v *= scale16;
+            ((s16x4*)y16)[i] = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ---- SwiGLU gate ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ void swiglu_fwd_kernel(const T* __restrict__ x1, const T* __restrict__ x2, T* __restrict__ h, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * EB) {
+        float a[8], b[8], o[8];
+        unpack8<T>(((const s16x8*)x1)[i], a);
+        unpack8<T>(((const s16x8*)x2)[i], b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = a[k] * sigmoid_f(a[k]) * b[k];
+        ((s16x8*)h)[i] = pack8<T>(o);
+    }
+}
+
+template <typename T>
+__global__ void swiglu_bwd_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const T* __restrict__ dh,
+                                  T* __restrict__ dx1, T* __restrict__ dx2, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * EB) {
+        float a[8], b[8], d[8], o1[8], o2[8];
+        unpack8<T>(((const s16x8*)x1)[i], a);
+        unpack8<T>(((const s16x8*)x2)[i], b);
+        unpack8<T>(((const s16x8*)dh)[i], d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float s = sigmoid_f(a[k]);
+            const float silu = a[k] * s;
+            o1[k] = d[k] * b[k] * (s + silu * (1.f - s));
+            o2[k] = d[k] * silu;
+        }
+        ((s16x8*)dx1)[i] = pack8<T>(o1);
+        ((s16x8*)dx2)[i] = pack8<T>(o2);
+    }
+}
+
+// ---- im2row ---------------------------------------------------------------------------------------------------------
+// One wave writes one output row (a patch) at a time: kpad 16-bit elements.  Reads are P-element runs of a pixel row.
+template <typename T>
+__global__ void im2row_kernel(const float* __restrict__ px, T* __restrict__ rows16, int B, int C, int H, int W, int P,
+                              int kpad) {
+    const int gw = W / P, gh = H / P;
+    const int64_t npatch = (int64_t)B * gh * gw;
+    const int k_real = C * P * P;
+    const int vpr = kpad >> 2;
+    const int64_t total = npatch * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t p = i / vpr;
+        const int k0 = (int)(i - p * vpr) * 4;
+        const int b = (int)(p / (gh * gw));
+        const int pr = (int)(p - (int64_t)b * gh * gw);
+        const int py = pr / gw, pxx = pr - py * gw;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            if (k < k_real) {
+                const int c = k / (P * P);
+                const int rem = k - c * P * P;
+                const int ii = rem / P, jj = rem - ii * P;
+                v[j] = px[(((int64_t)b * C + c) * H + py * P + ii) * W + pxx * P + jj];
+            } else {
+                v[j] = 0.f;
+            }
+        }
+        *(s16x4*)(rows16 + p * kpad + k0) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- RoPE (pairs (2k, 2k+1) rotated; tokens 1.. only) ---------------------------------------------------------------
+template <typename T>
+__global__ void rope_kernel(T* __restrict__ x, int64_t bs, int64_t rs, int B, int N, int H, int hd,
+                            const float* __restrict__ cos_t, const float* __restrict__ sin_t, int inverse) {
+    const int hv = hd >> 2;   // 4 elements (2 pairs) per work item
+    const int64_t total = (int64_t)B * (N - 1) * H * hv;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        int64_t t = i;
+        const int d0 = (int)(t % hv) * 4; t /= hv;
+        const int h = (int)(t % H); t /= H;
+        const int n = (int)(t % (N - 1)); t /= (N - 1);
+        const int64_t b = t;
+        T* p = x + b * bs + (int64_t)(n + 1) * rs + h * hd + d0;
+        f32x4 v = unpack4<T>(*(const s16x4*)p);
+        const f32x4 c = *(const f32x4*)(cos_t + (int64_t)n * hd + d0);
+        f32x4 s = *(const f32x4*)(sin_t + (int64_t)n * hd + d0);
+        f32x4 o;
+        if (!inverse) {   // y = x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)
+            o[0] = v[0] * c[0] - v[1] * s[0];
+            o[1] = v[1] * c[1] + v[0] * s[1];
+            o[2] = v[2] * c[2] - v[3] * s[2];
+            o[3] = v[3] * c[3] + v[2] * s[3];
+        } else {          // transpose of the above (gradient)
+            o[0] = v[0] * c[0] + v[1] * s[1];
+            o[1] = v[1] * c[1] - v[0] * s[0];
+            o[2] = v[2] * c[2] + v[3] * s[3];
+            o[3] = v[3] * c[3] - v[2] * s[2];
+        }
+        *(s16x4*)p = pack4<T>(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- BERT embeddings ------------------------------------------------------------------------------------------------
+__global__ void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                  const float* __restrict__ pos, const float* __restrict__ type0, float* __restrict__ out,
+                                  int64_t rows, int S, int cols, int vocab) {
+    const int vpr = cols >> 2;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * 4;
+        int64_t id = ids[r];
+        if (id < 0) id = 0;
+        if (id >= vocab) id = vocab - 1;
+        const int s = (int)(r % S);
+        f32x4 v = *(const f32x4*)(word + id * cols + c) + *(const f32x4*)(type0 + c) + *(const f32x4*)(pos + (int64_t)s * cols + c);
+        *(f32x4*)(out + r * cols + c) = v;
+    }
+}
+
+__global__ void embed_scatter_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dsum, float* __restrict__ dword,
+                                     float* __restrict__ dpos, float* __restrict__ dtype0, int64_t rows, int S, int cols,
+                                     int vocab, float scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float g = dsum[i] * scale;
+        int64_t id = ids[r];
+        if (id < 0) id = 0;
+        if (id >= vocab) id = vocab - 1;
+        if (dword) unsafeAtomicAdd(dword + id * cols + c, g);
+        if (dpos) unsafeAtomicAdd(dpos + (int64_t)(r % S) * cols + c, g);
+        if (dtype0) unsafeAtomicAdd(dtype0 + c, g);
+    }
+}
+
+// ---- L2 normalise (F.normalize, eps = 1e-12): one wave per row ------------------------------------------------------
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm,
+                                  int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = x[row * cols + c];
+        s += v * v;
+    }
+    const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < cols; c += 64) y[row * cols + c] = x[row * cols + c] * inv;
+    if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ inv_norm,
+                                  float* __restrict__ dx, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += dy[row * cols + c] * y[row * cols + c];
+    s = wave_sum(s);
+    const float inv = inv_norm[row];
+    for (int c = lane; c < cols; c += 64) dx[row * cols + c] = (dy[row * cols + c] - y[row * cols + c] * s) * inv;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int mico_cast_f32_to_16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                                   int cols_pad, float scale, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && src && dst, "mico_cast_f32_to_16: bad args");
+    MICO_CHECK(cols_pad % 4 == 0 && cols_pad >= cols && ld_dst % 4 == 0 && ld_dst >= cols_pad, "mico_cast_f32_to_16: cols_pad/ld_dst must be multiples of 4");
+    if (rows <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(cast_f32_to_16_kernel<T>, dim3(egrid(rows * (cols_pad / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, cols_pad, scale));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_cast_16_to_f32(const void* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int cols,
+                                   float scale, int accumulate, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && src && dst, "mico_cast_16_to_f32: bad args");
+    MICO_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "mico_cast_16_to_f32: cols/ld must be multiples of 4");
+    if (rows <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(cast_16_to_f32_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, (const T*)src, ld_src, dst, ld_dst, rows, cols, scale, accumulate));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
+                                     int remap_group, int remap_skip, int remap_offset, const float* row_scale,
+                                     int rows_per_scale, float scale, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && src && dst, "mico_gather_rows_cast: bad args");
+    MICO_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "mico_gather_rows_cast: cols/ld must be multiples of 4");
+    if (row_scale) MICO_CHECK(rows_per_scale > 0, "mico_gather_rows_cast: rows_per_scale");
+    if (rows <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(gather_rows_cast_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, remap_group, remap_skip, remap_offset, row_scale, rows_per_scale, scale));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows, int cols, float* out, float scale,
+                           int accumulate, void* stream) {
+    MICO_CHECK(x && out && cols > 0, "mico_colsum: bad args");
+    MICO_CHECK(x_dtype == MICO_F32 || x_dtype == MICO_F16 || x_dtype == MICO_BF16, "mico_colsum: bad dtype");
+    if (!accumulate) {
+        hipLaunchKernelGGL(zero_kernel, dim3(egrid(cols)), dim3(EB), 0, ST, out, (int64_t)cols);
+        MICO_LAUNCH_CHECK();
+    }
+    if (rows <= 0) return MICO_OK;
+    const int ncb = (cols + EB - 1) / EB;
+    int64_t chunks = 2048 / ncb;
+    if (chunks < 1) chunks = 1;
+    int64_t rpc = (rows + chunks - 1) / chunks;
+    if (rpc < 16) rpc = 16;
+    chunks = (rows + rpc - 1) / rpc;
+    const dim3 grid(ncb, (unsigned)chunks);
+    if (x_dtype == MICO_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(EB), 0, ST, (const float*)x, ld, rows, cols, out, scale, rpc);
+    else if (x_dtype == MICO_F16) hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(EB), 0, ST, (const f16*)x, ld, rows, cols, out, scale, rpc);
+    else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(EB), 0, ST, (const bf16*)x, ld, rows, cols, out, scale, rpc);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_cls_rows(float* x, int64_t ld, int B, int group_rows, const float* cls, const float* pos0, int cols,
+                             void* stream) {
+    MICO_CHECK(x && cls && pos0 && B > 0 && cols > 0, "mico_cls_rows: bad args");
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(egrid((int64_t)B * cols)), dim3(EB), 0, ST, x, ld, B, group_rows, cls, pos0, cols);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_add_f32(const float* a, const float* b, float* y, void* y16, int64_t n, float scale16, int dtype,
+                            void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && a && (y || y16) && n % 4 == 0, "mico_add_f32: bad args (n must be a multiple of 4)");
+    if (n <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(add_f32_kernel<T>, dim3(egrid(n / 4)), dim3(EB), 0, ST, a, b, y, (T*)y16, n / 4, scale16));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t n, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && x1 && x2 && h && n % 8 == 0, "mico_swiglu_fwd: bad args (n must be a multiple of 8)");
+    if (n <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(swiglu_fwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (T*)h, n / 8));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_swiglu_bwd(const void* x1, const void* x2, const void* dh, void* dx1, void* dx2, int64_t n, int dtype,
+                               void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && x1 && x2 && dh && dx1 && dx2 && n % 8 == 0, "mico_swiglu_bwd: bad args");
+    if (n <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(swiglu_bwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (const T*)dh, (T*)dx1, (T*)dx2, n / 8));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_im2row(const float* pixels, void* rows16, int B, int C, int H, int W, int P, int kpad, int dtype,
+                           void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && pixels && rows16, "mico_im2row: bad args");
+    MICO_CHECK(P > 0 && H % P == 0 && W % P == 0, "mico_im2row: image %dx%d is not a multiple of the patch size %d", H, W, P);
+    MICO_CHECK(kpad % 8 == 0 && kpad >= C * P * P, "mico_im2row: kpad must be a multiple of 8 and >= C*P*P");
+    if (B <= 0) return MICO_OK;
+    const int64_t total = (int64_t)B * (H / P) * (W / P) * (kpad / 4);
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(im2row_kernel<T>, dim3(egrid(total)), dim3(EB), 0, ST, pixels, (T*)rows16, B, C, H, W, P, kpad));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_rope(void* x, int64_t bs, int64_t rs, int B, int N, int H, int hd, const float* cos_t,
+                         const float* sin_t, int inverse, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && x && cos_t && sin_t, "mico_rope: bad args");
+    MICO_CHECK(hd % 4 == 0 && rs % 4 == 0 && bs % 4 == 0, "mico_rope: hd and strides must be multiples of 4");
+    if (B <= 0 || N <= 1) return MICO_OK;
+    const int64_t total = (int64_t)B * (N - 1) * H * (hd / 4);
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(rope_kernel<T>, dim3(egrid(total)), dim3(EB), 0, ST, (T*)x, bs, rs, B, N, H, hd, cos_t, sin_t, inverse));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                                   float* sum32, int64_t rows, int S, int cols, int vocab, void* stream) {
+    MICO_CHECK(ids && word && pos && type0 && sum32 && cols % 4 == 0 && S > 0, "mico_bert_embed_fwd: bad args");
+    if (rows <= 0) return MICO_OK;
+    hipLaunchKernelGGL(bert_embed_kernel, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, ids, word, pos, type0, sum32, rows, S, cols, vocab);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_embed_scatter_add(const int64_t* ids, const float* dsum, float* dword, float* dpos, float* dtype0,
+                                      int64_t rows, int S, int cols, int vocab, float scale, void* stream) {
+    MICO_CHECK(ids && dsum && S > 0, "mico_embed_scatter_add: bad args");
+    if (rows <= 0) return MICO_OK;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(egrid(rows * cols)), dim3(EB), 0, ST, ids, dsum, dword, dpos, dtype0, rows, S, cols, vocab, scale);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int cols, void* stream) {
+    MICO_CHECK(x && y, "mico_l2norm_fwd: bad args");
+    if (rows <= 0) return MICO_OK;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, x, y, inv_norm, rows, cols);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int cols,
+                               void* stream) {
+    MICO_CHECK(dy && y && inv_norm && dx, "mico_l2norm_bwd: bad args");
+    if (rows <= 0) return MICO_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, dy, y, inv_norm, dx, rows, cols);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}

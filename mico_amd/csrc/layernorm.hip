@@ -1,0 +1,244 @@
+// LayerNorm forward / backward for gfx950 (HBM-bound row kernels; see include/mico_hip.h).
+// One wave64 owns one row at a time and keeps it in registers (cols <= 4096): a single HBM read per element,
+// 16-byte loads/stores, fp32 statistics via two in-register passes (mean, then centred variance - the same
+// arithmetic order as torch.nn.functional.layer_norm).  The backward accumulates dgamma/dbeta per lane across the
+// rows a wave walks, reduces the 4 waves of a block through LDS and leaves one partial row per block; a second tiny
+// kernel folds the partials into the fp32 parameter gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 16;   // float4 per lane -> cols <= 4096 (forward); backward supports cols <= 2048
+constexpr int LN_BLOCK = 256;
+
+template <typename XT> struct RowIO;
+template <> struct RowIO<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+};
+template <> struct RowIO<f16> {
+    static __device__ __forceinline__ f32x4 load(const f16* p) { return unpack4<f16>(*(const s16x4*)p); }
+};
+template <> struct RowIO<bf16> {
+    static __device__ __forceinline__ f32x4 load(const bf16* p) { return unpack4<bf16>(*(const s16x4*)p); }
+};
+
+template <typename T, typename XT, int NV>
+__global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y16,
+                                                           float* __restrict__ y32, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int64_t rows, int cols, float eps,
+                                                           const float* __restrict__ post_add, int post_rpg,
+                                                           int post_groups) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nv = cols >> 2;
+    const float inv = 1.0f / (float)cols;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const XT* xr = x + row * cols;
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                v[i] = RowIO<XT>::load(xr + c * 4);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4 d = v[i] - mean;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+        if (lane == 0) {
+            if (mean_o) mean_o[row] = mean;
+            if (rstd_o) rstd_o[row] = rstd;
+        }
+        const float* pa = post_add ? post_add + (int64_t)((row / post_rpg) % post_groups) * cols : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+                f32x4 o = (v[i] - mean) * rstd * g + b;
+                if (pa) o += *(const f32x4*)(pa + c * 4);
+                if (y32) *(f32x4*)(y32 + row * cols + c * 4) = o;
+                if (y16) *(s16x4*)(y16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+template <typename T, typename DT, typename XT, int NV>
+__global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ dx_add,
+                                                           float* __restrict__ dx32, T* __restrict__ dx16, float scale16,
+                                                           float* __restrict__ ws, int64_t rows, int cols) {
+    __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nv = cols >> 2;
+    const float inv = 1.0f / (float)cols;
+    f32x4 dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4 d = RowIO<DT>::load(dy + row * cols + c * 4);
+                xh[i] = (RowIO<XT>::load(x + row * cols + c * 4) - mu) * rs;
+                g[i] = d * *(const f32x4*)(gamma + c * 4);
+                dg[i] += d * xh[i];
+                db[i] += d;
+                s1 += (g[i][0] + g[i][1]) + (g[i][2] + g[i][3]);
+                f32x4 t = g[i] * xh[i];
+                s2 += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+        }
+        const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
+                if (dx_add) o += *(const f32x4*)(dx_add + row * cols + c * 4);
+                if (dx32) *(f32x4*)(dx32 + row * cols + c * 4) = o;
+                if (dx16) {
+                    o *= scale16;
+                    *(s16x4*)(dx16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+    if (!ws) return;
+    // block reduce of dgamma/dbeta partials -> ws[0][blk][cols], ws[1][blk][cols]
+    float* wg = ws + (int64_t)blockIdx.x * cols;
+    float* wb = ws + ((int64_t)gridDim.x + blockIdx.x) * cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i * 64 >= nv) break;
+        __syncthreads();
+        red[0][wave][lane] = dg[i];
+        red[1][wave][lane] = db[i];
+        __syncthreads();
+        if (wave == 0) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4 a = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+                f32x4 b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+                *(f32x4*)(wg + c * 4) = a;
+                *(f32x4*)(wb + c * 4) = b;
+            }
+        }
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int cols, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        a += ws[(int64_t)k * cols + c];
+        b += ws[((int64_t)nblk + k) * cols + c];
+    }
+    if (dgamma) dgamma[c] += a * scale;
+    if (dbeta) dbeta[c] += b * scale;
+}
+
+int ln_grid(int64_t rows) {
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
+
+template <typename T, typename XT>
+void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
+                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups) {
+#define LNF(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups)
+    if (cols <= 1024) LNF(4);
+    else if (cols <= 1536) LNF(6);
+    else if (cols <= 2048) LNF(8);
+    else LNF(16);
+#undef LNF
+}
+
+template <typename T, typename DT, typename XT>
+void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
+                   const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
+                   int cols) {
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols)
+    if (cols <= 1024) LNB(4);
+    else if (cols <= 1536) LNB(6);
+    else LNB(8);
+#undef LNB
+}
+
+}  // namespace
+
+extern "C" int mico_layernorm_bwd_nblk(int64_t rows) { return ln_grid(rows); }
+
+extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* y32,
+                                  float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add,
+                                  int post_rows_per_group, int post_groups, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
+    MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
+    MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
+    MICO_CHECK(x_dtype == MICO_F32 || x_dtype == dtype, "mico_layernorm_fwd: x_dtype must be fp32 or dtype");
+    if (post_add) MICO_CHECK(post_rows_per_group > 0 && post_groups > 0, "mico_layernorm_fwd: bad post_add grouping");
+    if (rows <= 0) return MICO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ln_grid(rows));
+    DISPATCH_T16(dtype, {
+        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups);
+        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups);
+    });
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                                  const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
+                                  float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
+                                  int cols, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
+    MICO_CHECK(dy && x && gamma && mean && rstd, "mico_layernorm_bwd: null pointer");
+    MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 2048, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 2048 (got %d)", cols);
+    MICO_CHECK((dy_dtype == MICO_F32 || dy_dtype == dtype) && (x_dtype == MICO_F32 || x_dtype == dtype), "mico_layernorm_bwd: bad in dtype");
+    MICO_CHECK(!(dgamma || dbeta) || ws, "mico_layernorm_bwd: dgamma/dbeta need a workspace");
+    if (rows <= 0) return MICO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ln_grid(rows);
+    const dim3 grid(nblk);
+    float* wsp = (dgamma || dbeta) ? ws : nullptr;
+    DISPATCH_T16(dtype, {
+        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
+        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
+        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
+        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
+    });
+    MICO_LAUNCH_CHECK();
+    if (wsp) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
+        MICO_LAUNCH_CHECK();
+    }
+    return MICO_OK;
+}

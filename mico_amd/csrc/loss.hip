@@ -1,0 +1,89 @@
+// Row-wise cross-entropy with label smoothing, forward and gradient in one kernel (see include/mico_hip.h).
+// One 256-thread workgroup per row; online max/sum-exp in a single pass over the row (fp32 math), block reduction
+// through LDS; the optional gradient pass re-reads the row (L2-resident for the small ITC/ITM rows; one extra HBM
+// read for the 30522-wide LM-head rows) and writes dlogits in the GEMM's 16-bit dtype, so fp32 logits of the LM head
+// never exist in HBM.
+#include "common.h"
+
+namespace {
+
+template <typename LT> __device__ __forceinline__ float ld_logit(const LT* p, int64_t i) { return (float)p[i]; }
+
+template <typename LT, typename DT>
+__global__ __launch_bounds__(256) void ce_kernel(const LT* __restrict__ logits, int64_t ld, int cols,
+                                                 const int64_t* __restrict__ target, int ignore_index, float ls,
+                                                 float lscale, float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                                 DT* __restrict__ dlogits, int64_t ld_d, const float* __restrict__ dscale_ptr,
+                                                 float dscale) {
+    __shared__ float red[3][4];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LT* x = logits + row * ld;
+    const int64_t t = target[row];
+    const bool ignored = (t == ignore_index) || t < 0 || t >= cols;
+    float m = -1.0e30f, s = 0.f, sx = 0.f;
+    for (int c = tid; c < cols; c += 256) {
+        const float v = ld_logit(x, c) * lscale;
+        sx += v;
+        if (v > m) { s = s * __expf(m - v) + 1.f; m = v; }
+        else s += __expf(v - m);
+    }
+    // wave reduce (m, s), then block
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+        m = mn;
+        sx += __shfl_xor(sx, o, 64);
+    }
+    if (lane == 0) { red[0][wave] = m; red[1][wave] = s; red[2][wave] = sx; }
+    __syncthreads();
+    float M = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    float S = 0.f, SX = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { S += red[1][w] * __expf(red[0][w] - M); SX += red[2][w]; }
+    const float lse = M + __logf(S);
+    if (tid == 0) {
+        float loss = 0.f;
+        if (!ignored) {
+            const float xt = ld_logit(x, t) * lscale;
+            loss = (1.f - ls) * (lse - xt) + ls * (lse - SX / (float)cols);
+        }
+        if (row_loss) row_loss[row] = loss;
+        if (row_lse) row_lse[row] = lse;
+    }
+    if (!dlogits) return;
+    float ds = dscale * lscale;
+    if (dscale_ptr) ds *= dscale_ptr[0];
+    if (ignored) ds = 0.f;
+    const float smooth = ls / (float)cols;
+    DT* d = dlogits + row * ld_d;
+    for (int c = tid; c < cols; c += 256) {
+        const float v = ld_logit(x, c) * lscale;
+        float gsm = __expf(v - lse) - smooth;
+        if (c == t) gsm -= (1.f - ls);
+        d[c] = (DT)(gsm * ds);
+    }
+}
+
+}  // namespace
+
+extern "C" int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t rows, int cols,
+                               const int64_t* target, int ignore_index, float label_smoothing, float logits_scale,
+                               float* row_loss, float* row_lse, void* dlogits, int dlogits_dtype, int64_t ld_d,
+                               const float* dscale_ptr, float dscale, int dtype, void* stream) {
+    MICO_CHECK(logits && target && cols > 0, "mico_ce_fwd_bwd: bad args");
+    MICO_CHECK(logits_dtype == MICO_F32 || logits_dtype == MICO_F16 || logits_dtype == MICO_BF16, "mico_ce_fwd_bwd: logits dtype");
+    MICO_CHECK(!dlogits || dlogits_dtype == logits_dtype, "mico_ce_fwd_bwd: dlogits dtype must equal the logits dtype");
+    (void)dtype;
+    if (rows <= 0) return MICO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)rows), block(256);
+#define CE(LT) hipLaunchKernelGGL((ce_kernel<LT, LT>), grid, block, 0, st, (const LT*)logits, ld, cols, target, ignore_index, label_smoothing, logits_scale, row_loss, row_lse, (LT*)dlogits, ld_d, dscale_ptr, dscale)
+    if (logits_dtype == MICO_F32) CE(float);
+    else if (logits_dtype == MICO_F16) CE(f16);
+    else CE(bf16);
+#undef CE
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}

@@ -1,0 +1,215 @@
+"""Raw kernel launchers: torch tensors in (device memory + stream plumbing only), libmico_hip.so C-ABI calls out.
+
+No autograd here and no fallback: every function requires CUDA(HIP) tensors and raises MicoHipError otherwise.
+All launches go to torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import F16, BF16, F32, ACT_NONE, ACT_GELU, ACT_GELU_GRAD, GemmEpilogue, AttnParams, MicoHipError, check
+
+_DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
+
+
+def dt_code(dtype):
+    return _DT[dtype]
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MicoHipError("mico_amd kernels need device tensors (got a CPU tensor); there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
+         row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
+         accumulate=False, split_k=1, dtype=None):
+    """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
+    leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
+    dtype = dtype or A.dtype
+    if M is None:
+        M = A.shape[1] if ta else A.shape[0]
+    if K is None:
+        K = A.shape[0] if ta else A.shape[1]
+    if N is None:
+        N = B.shape[1] if tb else B.shape[0]
+    e = GemmEpilogue()
+    e.bias = _p(bias)
+    e.aux_out = _p(aux_out)
+    e.aux_in = _p(aux_in)
+    aux = aux_out if aux_out is not None else aux_in
+    e.ldaux = aux.stride(0) if aux is not None else 0
+    e.act = act
+    e.row_scale = _p(row_scale)
+    e.rows_per_scale = rows_per_scale
+    e.resid = _p(resid)
+    e.pos = _p(pos)
+    e.pos_rows = pos_rows
+    e.remap_group, e.remap_skip, e.remap_offset = remap
+    e.alpha = alpha
+    e.accumulate = 1 if accumulate else 0
+    rc = _lib.lib().mico_gemm(int(ta), int(tb), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0),
+                              dt_code(out.dtype), C.byref(e), split_k, dt_code(dtype), _st())
+    check(rc, "mico_gemm")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
+                  post_rows_per_group=0, post_groups=0, dtype=torch.float16):
+    rows, cols = x.shape[0], x.shape[1]
+    rc = _lib.lib().mico_layernorm_fwd(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(out32), _p(mean),
+                                       _p(rstd), rows, cols, eps, _p(post_add), post_rows_per_group, post_groups,
+                                       dt_code(dtype), _st())
+    check(rc, "mico_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
+                  grad_scale=1.0, dtype=torch.float16):
+    rows, cols = x.shape[0], x.shape[1]
+    ws = None
+    if dgamma is not None or dbeta is not None:
+        nblk = _lib.lib().mico_layernorm_bwd_nblk(rows)
+        ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
+                                       _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
+                                       _p(ws), rows, cols, dt_code(dtype), _st())
+    check(rc, "mico_layernorm_bwd")
+
+
+def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides):
+    p = AttnParams()
+    p.B, p.H, p.Sq, p.Sk, p.hd = B, H, Sq, Sk, hd
+    p.q_bs, p.q_rs = q_strides
+    p.k_bs, p.k_rs = k_strides
+    p.v_bs, p.v_rs = v_strides
+    p.o_bs, p.o_rs = o_strides
+    p.scale = scale
+    p.mask = _p(mask)
+    if mask is None:
+        p.mask_mode = 0
+    elif mask.dim() == 2:
+        p.mask_mode = 1
+    else:
+        p.mask_mode = 2
+    return p
+
+
+def attn_fwd(q, k, v, o, lse, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides, v_strides, o_strides):
+    """q/k/v/o are 16-bit tensors (possibly views into one fused projection buffer); *_strides = (batch, row) in
+    elements.  mask: additive fp32 [B,Sk] or [B,Sq,Sk]."""
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides)
+    rc = _lib.lib().mico_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), C.byref(p), dt_code(q.dtype), _st())
+    check(rc, "mico_attn_fwd")
+
+
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, delta, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides,
+             v_strides, o_strides):
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides)
+    rc = _lib.lib().mico_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk), _p(dv), _p(delta),
+                                  C.byref(p), dt_code(q.dtype), _st())
+    check(rc, "mico_attn_bwd")
+
+
+def rope(x, bs, rs, B, N, H, hd, cos_t, sin_t, inverse=False):
+    check(_lib.lib().mico_rope(_p(x), bs, rs, B, N, H, hd, _p(cos_t), _p(sin_t), int(inverse), dt_code(x.dtype), _st()),
+          "mico_rope")
+
+
+def im2row(pixels, rows16, P, kpad):
+    B, Cc, H, W = pixels.shape
+    check(_lib.lib().mico_im2row(_p(pixels), _p(rows16), B, Cc, H, W, P, kpad, dt_code(rows16.dtype), _st()), "mico_im2row")
+
+
+def cast_f32_to_16(src, dst, *, cols=None, cols_pad=None, scale=1.0):
+    rows = src.shape[0]
+    cols = cols if cols is not None else src.shape[1]
+    cols_pad = cols_pad if cols_pad is not None else dst.shape[1]
+    check(_lib.lib().mico_cast_f32_to_16(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, cols_pad, scale,
+                                         dt_code(dst.dtype), _st()), "mico_cast_f32_to_16")
+    return dst
+
+
+def cast_16_to_f32(src, dst, *, scale=1.0, accumulate=False):
+    rows, cols = src.shape
+    check(_lib.lib().mico_cast_16_to_f32(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, scale,
+                                         int(accumulate), dt_code(src.dtype), _st()), "mico_cast_16_to_f32")
+    return dst
+
+
+def gather_rows_cast(src, dst, *, remap=(0, 0, 0), row_scale=None, rows_per_scale=0, scale=1.0):
+    rows, cols = dst.shape
+    check(_lib.lib().mico_gather_rows_cast(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, remap[0], remap[1],
+                                           remap[2], _p(row_scale), rows_per_scale, scale, dt_code(dst.dtype), _st()),
+          "mico_gather_rows_cast")
+    return dst
+
+
+def colsum(x, out, *, rows=None, cols=None, ld=None, scale=1.0, accumulate=False):
+    rows = rows if rows is not None else x.shape[0]
+    cols = cols if cols is not None else x.shape[1]
+    ld = ld if ld is not None else x.stride(0)
+    check(_lib.lib().mico_colsum(_p(x), dt_code(x.dtype), ld, rows, cols, _p(out), scale, int(accumulate), _st()),
+          "mico_colsum")
+    return out
+
+
+def cls_rows(x, B, group_rows, cls, pos0):
+    check(_lib.lib().mico_cls_rows(_p(x), x.stride(0), B, group_rows, _p(cls), _p(pos0), x.shape[1], _st()), "mico_cls_rows")
+
+
+def add_f32(a, b, y=None, y16=None, scale16=1.0, dtype=torch.float16):
+    check(_lib.lib().mico_add_f32(_p(a), _p(b), _p(y), _p(y16), a.numel(), scale16,
+                                  dt_code(y16.dtype if y16 is not None else dtype), _st()), "mico_add_f32")
+
+
+def swiglu_fwd(x1, x2, h):
+    check(_lib.lib().mico_swiglu_fwd(_p(x1), _p(x2), _p(h), x1.numel(), dt_code(x1.dtype), _st()), "mico_swiglu_fwd")
+
+
+def swiglu_bwd(x1, x2, dh, dx1, dx2):
+    check(_lib.lib().mico_swiglu_bwd(_p(x1), _p(x2), _p(dh), _p(dx1), _p(dx2), x1.numel(), dt_code(x1.dtype), _st()),
+          "mico_swiglu_bwd")
+
+
+def bert_embed_fwd(ids, word, pos, type0, out, S):
+    rows, cols = out.shape
+    check(_lib.lib().mico_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(out), rows, S, cols, word.shape[0], _st()),
+          "mico_bert_embed_fwd")
+
+
+def embed_scatter_add(ids, dsum, dword, dpos, dtype0, S, scale=1.0):
+    rows, cols = dsum.shape
+    vocab = dword.shape[0] if dword is not None else 0
+    check(_lib.lib().mico_embed_scatter_add(_p(ids), _p(dsum), _p(dword), _p(dpos), _p(dtype0), rows, S, cols, vocab, scale,
+                                            _st()), "mico_embed_scatter_add")
+
+
+def ce_fwd_bwd(logits, target, *, cols=None, ignore_index=-100, label_smoothing=0.0, logits_scale=1.0, row_loss=None,
+               row_lse=None, dlogits=None, dscale_ptr=None, dscale=1.0):
+    rows = logits.shape[0]
+    cols = cols if cols is not None else logits.shape[1]
+    check(_lib.lib().mico_ce_fwd_bwd(_p(logits), dt_code(logits.dtype), logits.stride(0), rows, cols, _p(target),
+                                     ignore_index, label_smoothing, logits_scale, _p(row_loss), _p(row_lse), _p(dlogits),
+                                     dt_code(dlogits.dtype) if dlogits is not None else 0,
+                                     dlogits.stride(0) if dlogits is not None else 0, _p(dscale_ptr), dscale, 0, _st()),
+          "mico_ce_fwd_bwd")
+
+
+def l2norm_fwd(x, y, inv_norm):
+    check(_lib.lib().mico_l2norm_fwd(_p(x), _p(y), _p(inv_norm), x.shape[0], x.shape[1], _st()), "mico_l2norm_fwd")
+
+
+def l2norm_bwd(dy, y, inv_norm, dx):
+    check(_lib.lib().mico_l2norm_bwd(_p(dy), _p(y), _p(inv_norm), _p(dx), y.shape[0], y.shape[1], _st()), "mico_l2norm_bwd")

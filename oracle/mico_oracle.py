@@ -1,0 +1,437 @@
+"""TEST INFRASTRUCTURE ONLY - the CPU oracle for the MiCo omni-modal forward/backward hot path.
+
+A plain-PyTorch fp32 *restatement* of the reference's algorithm, written functionally over a state_dict whose
+keys are the reference's own (`vision_encoder.visual.*`, `multimodal_encoder.bert.*`, ...).  It exists to check
+the HIP product path (mico_amd/) - only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import it; mico_amd/ never does (the product path raises if the HIP library is missing, it never falls back
+here).
+
+Parity status: PINNED.  oracle/make_golden.py imports the reference itself (oracle/ref_import.py, build
+container only) and writes tests/golden/*.pt; tests/test_oracle_vs_golden.py checks every function below against
+those fixtures (fp32, <= 2e-5 relative).  Not pinned (third-party arithmetic absent from /root/reference, see
+SURVEY.md section 8c): HF generate()/beam search, torchvision resize, torchaudio fbank.
+
+Each function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------------------------
+# architecture table: model/evaclip/model_configs/{EVA01-CLIP-g-14,EVA02-CLIP-B-16,EVA02-CLIP-L-14}.json and
+# model/mico.py:323-349 (vision_encoder_type -> model name / vision_dim)
+# --------------------------------------------------------------------------------------------------------------
+ARCHS = {
+    "evaclip01_giant": dict(width=1408, depth=40, heads=16, patch=14, mlp_hidden=6144, rope=False, subln=False,
+                            swiglu=False, drop_path_rate=0.4, embed_dim=1024),
+    "evaclip02_base": dict(width=768, depth=12, heads=12, patch=16, mlp_hidden=2048, rope=True, subln=True,
+                           swiglu=True, drop_path_rate=0.0, embed_dim=512),
+    "evaclip02_base_self": dict(width=768, depth=12, heads=12, patch=16, mlp_hidden=2048, rope=True, subln=True,
+                                swiglu=True, drop_path_rate=0.0, embed_dim=512),
+    "evaclip02_large": dict(width=1024, depth=24, heads=16, patch=14, mlp_hidden=2730, rope=True, subln=True,
+                            swiglu=True, drop_path_rate=0.0, embed_dim=768),
+}
+VIT_EPS = 1e-6  # model/evaclip/model.py:124
+BERT_EPS = 1e-12  # model/bert-base-uncased-crossattn/config.json
+BERT_HEADS = 12
+BERT_LAYERS = 12
+
+
+def gelu(x):
+    """model/mico.py:22-28 == nn.GELU (erf form)."""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def layer_norm(x, w, b, eps):
+    """model/evaclip/transformer.py:121-127 / torch.nn.LayerNorm."""
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# EVA ViT tower
+# --------------------------------------------------------------------------------------------------------------
+def rope_tables(hd, grid, pt_seq_len=16):
+    """model/evaclip/rope.py:79-117 (VisionRotaryEmbeddingFast, freqs_for='lang', dim = hd // 2,
+    ft_seq_len = grid because intp_freq is true in the EVA02 configs)."""
+    dim = hd // 2
+    freqs = 1.0 / (10000 ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    t = torch.arange(grid) / grid * pt_seq_len
+    f = torch.einsum("i,f->if", t, freqs)
+    f = f.repeat_interleave(2, dim=-1)  # '... n -> ... (n r)', r=2
+    fh = f[:, None, :].expand(grid, grid, dim)
+    fw = f[None, :, :].expand(grid, grid, dim)
+    fr = torch.cat((fh, fw), dim=-1).reshape(grid * grid, 2 * dim)
+    return fr.cos(), fr.sin()
+
+
+def rotate_half(x):
+    """model/evaclip/rope.py:23-27."""
+    x = x.reshape(*x.shape[:-1], -1, 2)
+    x1, x2 = x.unbind(dim=-1)
+    return torch.stack((-x2, x1), dim=-1).reshape(*x.shape[:-2], -1)
+
+
+def patch_embed(sd, pre, x, patch):
+    """model/evaclip/eva_vit_model.py:442-448 (conv k=s=P, flatten, transpose)."""
+    y = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"], stride=patch)
+    return y.flatten(2).transpose(1, 2)
+
+
+def eva_attention(sd, p, x, arch, rope):
+    """model/evaclip/eva_vit_model.py:293-365 (xattn is hard-wired False at :379)."""
+    B, N, C = x.shape
+    H = arch["heads"]
+    hd = C // H
+    if arch["subln"]:
+        q = F.linear(x, sd[p + "q_proj.weight"], sd[p + "q_bias"])
+        k = F.linear(x, sd[p + "k_proj.weight"], None)
+        v = F.linear(x, sd[p + "v_proj.weight"], sd[p + "v_bias"])
+        q = q.reshape(B, N, H, hd).permute(0, 2, 1, 3)
+        k = k.reshape(B, N, H, hd).permute(0, 2, 1, 3)
+        v = v.reshape(B, N, H, hd).permute(0, 2, 1, 3)
+    else:
+        qb = sd[p + "q_bias"]
+        bias = torch.cat((qb, torch.zeros_like(qb), sd[p + "v_bias"]))
+        qkv = F.linear(x, sd[p + "qkv.weight"], bias).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+    if rope is not None:
+        cos, sin = rope
+        q = torch.cat((q[:, :, :1], q[:, :, 1:] * cos + rotate_half(q[:, :, 1:]) * sin), dim=2)
+        k = torch.cat((k[:, :, :1], k[:, :, 1:] * cos + rotate_half(k[:, :, 1:]) * sin), dim=2)
+    q = q * hd ** -0.5
+    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    o = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    if arch["subln"]:
+        o = layer_norm(o, sd[p + "inner_attn_ln.weight"], sd[p + "inner_attn_ln.bias"], VIT_EPS)
+    return F.linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def eva_mlp(sd, p, x, arch):
+    """model/evaclip/eva_vit_model.py:190-199 (Mlp) / :217-224 (SwiGLU)."""
+    if arch["swiglu"]:
+        h = F.silu(F.linear(x, sd[p + "w1.weight"], sd[p + "w1.bias"])) * F.linear(x, sd[p + "w2.weight"],
+                                                                                     sd[p + "w2.bias"])
+        h = layer_norm(h, sd[p + "ffn_ln.weight"], sd[p + "ffn_ln.bias"], VIT_EPS)
+        return F.linear(h, sd[p + "w3.weight"], sd[p + "w3.bias"])
+    h = F.gelu(F.linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+    return F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+
+
+def vit_depth(sd, pre):
+    n = 0
+    while (pre + f"blocks.{n}.norm1.weight") in sd:
+        n += 1
+    return n
+
+
+def eva_vit_forward(sd, x, arch, pre="vision_encoder.visual.", drop_path_scale=None, taps=None):
+    """EVAVisionTransformer.forward_features(return_all_features=True), eval mode:
+    model/evaclip/eva_vit_model.py:611-650; Block.forward :409-416 (gamma None, postnorm False).
+
+    drop_path_scale: optional [depth, 2, B] per-sample multipliers (0 or 1/keep) standing in for the train-mode
+    Bernoulli draw of drop_path (:121-138) so stochastic depth can be parity-tested with injected masks.
+    taps: optional list that receives the residual stream after every block."""
+    B = x.shape[0]
+    t = patch_embed(sd, pre, x, arch["patch"])
+    t = torch.cat((sd[pre + "cls_token"].expand(B, -1, -1), t), dim=1) + sd[pre + "pos_embed"]
+    rope = None
+    if arch["rope"]:
+        rope = rope_tables(arch["width"] // arch["heads"], x.shape[-1] // arch["patch"])
+    for i in range(vit_depth(sd, pre)):
+        p = pre + f"blocks.{i}."
+        a = eva_attention(sd, p + "attn.", layer_norm(t, sd[p + "norm1.weight"], sd[p + "norm1.bias"], VIT_EPS),
+                          arch, rope)
+        if drop_path_scale is not None:
+            a = a * drop_path_scale[i, 0].view(B, 1, 1)
+        t = t + a
+        m = eva_mlp(sd, p + "mlp.", layer_norm(t, sd[p + "norm2.weight"], sd[p + "norm2.bias"], VIT_EPS), arch)
+        if drop_path_scale is not None:
+            m = m * drop_path_scale[i, 1].view(B, 1, 1)
+        t = t + m
+        if taps is not None:
+            taps.append(t)
+    return layer_norm(t, sd[pre + "norm.weight"], sd[pre + "norm.bias"], VIT_EPS)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BERT with cross-attention
+# --------------------------------------------------------------------------------------------------------------
+def extended_mask(attention_mask):
+    """model/bert.py:697-781: 2-D -> [b,1,1,S], 3-D -> [b,1,S,S]; (1 - m) * -10000; no automatic causal mask."""
+    m = attention_mask.to(torch.float32)
+    m = m[:, None, :, :] if m.dim() == 3 else m[:, None, None, :]
+    return (1.0 - m) * -10000.0
+
+
+def bert_attention(sd, p, hidden, kv_src, add_mask):
+    """model/bert.py:184-283 (BertSelfAttention) + :293-297 (BertSelfOutput), dropout off."""
+    b, S, D = hidden.shape
+    H, hd = BERT_HEADS, D // BERT_HEADS
+
+    def heads(t):
+        return t.view(t.shape[0], t.shape[1], H, hd).permute(0, 2, 1, 3)
+
+    q = heads(F.linear(hidden, sd[p + "self.query.weight"], sd[p + "self.query.bias"]))
+    k = heads(F.linear(kv_src, sd[p + "self.key.weight"], sd[p + "self.key.bias"]))
+    v = heads(F.linear(kv_src, sd[p + "self.value.weight"], sd[p + "self.value.bias"]))
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if add_mask is not None:
+        s = s + add_mask
+    ctx = (s.softmax(dim=-1) @ v).permute(0, 2, 1, 3).reshape(b, S, D)
+    out = F.linear(ctx, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    return layer_norm(out + hidden, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT_EPS)
+
+
+def bert_forward(sd, input_ids, attention_mask, encoder_hidden_states=None, pre="multimodal_encoder.bert.",
+                 n_layers=None):
+    """BertModel.forward, eval mode: model/bert.py:785-916; embeddings :101-149; BertLayer :393-461 (self-attn,
+    then cross-attn when encoder_hidden_states is given - its mask is all ones -> additive 0, :872), FFN :349-375."""
+    S = input_ids.shape[1]
+    e = pre + "embeddings."
+    x = sd[e + "word_embeddings.weight"][input_ids] + sd[e + "token_type_embeddings.weight"][0] \
+        + sd[e + "position_embeddings.weight"][:S]
+    x = layer_norm(x, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], BERT_EPS)
+    am = extended_mask(attention_mask)
+    L = n_layers
+    if L is None:
+        L = 0
+        while (pre + f"encoder.layer.{L}.attention.self.query.weight") in sd:
+            L += 1
+    for i in range(L):
+        p = pre + f"encoder.layer.{i}."
+        x = bert_attention(sd, p + "attention.", x, x, am)
+        if encoder_hidden_states is not None:
+            x = bert_attention(sd, p + "crossattention.", x, encoder_hidden_states, None)
+        h = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        h = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        x = layer_norm(h + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT_EPS)
+    return x
+
+
+def bert_lm_logits(sd, seq, pre="multimodal_encoder.cls."):
+    """model/bert.py:575-609 (transform dense+GELU+LN, decoder tied to the word embeddings + output bias)."""
+    p = pre + "predictions."
+    h = gelu(F.linear(seq, sd[p + "transform.dense.weight"], sd[p + "transform.dense.bias"]))
+    h = layer_norm(h, sd[p + "transform.LayerNorm.weight"], sd[p + "transform.LayerNorm.bias"], BERT_EPS)
+    return F.linear(h, sd[p + "decoder.weight"], sd[p + "bias"])
+
+
+def bert_mlm(sd, input_ids, attention_mask, encoder_hidden_states=None, labels=None):
+    """BertForMaskedLM.forward: model/bert.py:1047-1097 -> dict(loss, logits, sequence_output)."""
+    seq = bert_forward(sd, input_ids, attention_mask, encoder_hidden_states)
+    logits = bert_lm_logits(sd, seq)
+    loss = None
+    if labels is not None:
+        loss = F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.view(-1))  # ignore_index=-100
+    return dict(loss=loss, logits=logits, sequence_output=seq)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# MiCo facade (model/mico.py)
+# --------------------------------------------------------------------------------------------------------------
+def forward_vision_encoder(sd, arch, pixels, **kw):
+    """model/mico.py:115-137."""
+    b, n = pixels.shape[:2]
+    out = eva_vit_forward(sd, pixels.reshape(b * n, *pixels.shape[2:]), arch, **kw)
+    return out.reshape(b, n, *out.shape[-2:])
+
+
+def forward_audio_encoder(sd, arch, spec, **kw):
+    """model/mico.py:139-143 (1-channel spectrogram repeated to 3 channels)."""
+    return forward_vision_encoder(sd, arch, spec.unsqueeze(2).repeat(1, 1, 3, 1, 1), **kw)
+
+
+def pool_for_contra(feature):
+    """model/mico.py:157-182 (CLS of each frame, mean over frames)."""
+    return feature[:, :, 0].mean(dim=1)
+
+
+def contra_feat(sd, head, pooled):
+    """Contra_head (mico.py:36-41, bias-free) or the fused nn.Linear heads (:391-394), then F.normalize
+    (data/model/vast.py:221-279)."""
+    if (head + ".linear.weight") in sd:
+        y = F.linear(pooled, sd[head + ".linear.weight"])
+    else:
+        y = F.linear(pooled, sd[head + ".weight"], sd[head + ".bias"])
+    return F.normalize(y, dim=-1)
+
+
+def multimodal_input(sd, modality, feats, pool_video=False):
+    """model/mico.py:187-243: [pool_video], Linear+LN(1e-12), + frame embedding (nearest-interpolated when n differs),
+    reshape (b, n*x, 768), + type embedding."""
+    b, n, x, c = feats.shape
+    if pool_video:
+        feats = torch.cat([feats[:, :, 0:1], feats[:, :, 1:].mean(2, keepdim=True)], dim=2)
+    p = f"hidden_trans_{modality}_multimodal."
+    y = layer_norm(F.linear(feats, sd[p + "0.weight"], sd[p + "0.bias"]), sd[p + "1.weight"], sd[p + "1.bias"],
+                   BERT_EPS)
+    fe = sd[f"{modality}_frame_embedding"]
+    if n != fe.shape[1]:
+        fe = F.interpolate(fe.float().permute(0, 2, 1), n, mode="nearest").permute(0, 2, 1)
+    y = y + fe.unsqueeze(-2)
+    y = y.reshape(b, -1, y.shape[-1])
+    return y + sd[f"{modality}_type_embeddings"]
+
+
+def itm_head(sd, cls_tok):
+    """Match_head: model/mico.py:44-52."""
+    h = gelu(F.linear(cls_tok, sd["itm_head.linear1.weight"], sd["itm_head.linear1.bias"]))
+    h = layer_norm(h, sd["itm_head.layernorm.weight"], sd["itm_head.layernorm.bias"], BERT_EPS)
+    return F.linear(h, sd["itm_head.linear2.weight"], sd["itm_head.linear2.bias"])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# alignment loss (spec: data/model/vast.py:383-512 generalised with MiCo's depth heads)
+# --------------------------------------------------------------------------------------------------------------
+COND_MODALITY = {"v": "vision", "a": "audio", "d": "depth"}
+
+
+def encode_batch(sd, arch, batch, pool_video=False, drop_path_scale=None):
+    """The encoder part of batch_get (vast.py:81-314): towers, pooled features, condition tensors.
+    batch keys: vision_pixels [b,n,3,h,w], audio_spectrograms [b,n,h,w], depth_pixels [b,n,3,h,w] (any subset),
+    input_ids / attention_mask [b,S]."""
+    out = {}
+    keys = {"v": "vision_pixels", "a": "audio_spectrograms", "d": "depth_pixels"}
+    for m, key in keys.items():
+        if key not in batch:
+            continue
+        kw = {}
+        if drop_path_scale is not None and m in drop_path_scale:
+            kw["drop_path_scale"] = drop_path_scale[m]
+        if m == "a":
+            o = forward_audio_encoder(sd, arch, batch[key], **kw)
+        else:
+            o = forward_vision_encoder(sd, arch, batch[key], **kw)
+        out["output_" + m] = o
+        out["pooled_" + m] = pool_for_contra(o)
+        out["condition_feats_" + m] = multimodal_input(sd, COND_MODALITY[m], o, pool_video)
+    if "input_ids" in batch:
+        seq = bert_forward(sd, batch["input_ids"], batch["attention_mask"])
+        out["caption_output"] = seq
+        out["feat_t"] = contra_feat(sd, "contra_head_t", seq[:, 0])
+    return out
+
+
+FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "va": "contra_head_va",
+               "vd": "contra_head_id"}
+
+
+def feat_cond(sd, enc, cond):
+    """feat_<cond> of vast.py:221-279: single-modality Contra_head, or the fused Linear over concatenated pooled
+    features (contra_head_va; MiCo adds contra_head_id for image+depth, mico.py:392)."""
+    pooled = torch.cat([enc["pooled_" + m] for m in cond], dim=1)
+    return contra_feat(sd, FUSED_HEADS[cond], pooled)
+
+
+def condition_feats(enc, cond):
+    """condition_feats_<cond>: concatenation along the token axis (vast.py:192-210)."""
+    return torch.cat([enc["condition_feats_" + m] for m in cond], dim=1)
+
+
+def itc_loss(feat_t, feat_c, feat_t_all, feat_c_all, temp, rank, label_smoothing=0.1):
+    """vast.py:405-415.  *_all are the gathered (no-grad) global-batch features."""
+    bs = feat_t.shape[0]
+    sim_c2t = feat_c @ feat_t_all.t() / temp
+    sim_t2c = feat_t @ feat_c_all.t() / temp
+    targets = torch.arange(rank * bs, rank * bs + bs, device=feat_t.device)
+    loss = (F.cross_entropy(sim_c2t, targets, label_smoothing=label_smoothing)
+            + F.cross_entropy(sim_t2c, targets, label_smoothing=label_smoothing)) / 2
+    return loss, sim_t2c, sim_c2t
+
+
+def itm_weights(sim, rank):
+    """vast.py:423-427: softmax + 1e-4 with the own-rank diagonal zeroed (no grad)."""
+    bs = sim.shape[0]
+    w = F.softmax(sim.detach(), dim=1) + 1e-4
+    w[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
+    return w
+
+
+def itm_loss(sd, input_ids, attention_mask, cond, cond_all, ids_all, mask_all, neg_cond_idx, neg_text_idx,
+             itm_ratio):
+    """vast.py:429-457 with the multinomial draws replaced by injected indices (neg_*_idx [bs], int64)."""
+    bs = input_ids.shape[0]
+    ids = torch.cat((input_ids, input_ids, ids_all[neg_text_idx]), dim=0)
+    am = torch.cat((attention_mask, attention_mask, mask_all[neg_text_idx]), dim=0)
+    c = torch.cat((cond, cond_all[neg_cond_idx], cond), dim=0)
+    out = bert_forward(sd, ids, am, c)
+    logits = itm_head(sd, out[:, 0])
+    gt = torch.zeros(bs * 3, dtype=torch.long, device=logits.device)
+    gt[:bs] = 1
+    return itm_ratio * F.cross_entropy(logits, gt), logits
+
+
+def cap_loss(sd, masked_ids, attention_mask, labels, cond):
+    """vast.py:493-509: 3-D mask = key padding AND lower-triangular; BertForMaskedLM(..., labels).loss."""
+    S = attention_mask.shape[1]
+    m3 = attention_mask.unsqueeze(1).expand(-1, S, -1).clone()
+    m3 = torch.tril(m3)
+    return bert_mlm(sd, masked_ids, m3, cond, labels)["loss"]
+
+
+def mico_forward(sd, arch, batch, task, cfg, rank=0, world=None, injected=None):
+    """MiCo.forward(batch, task, compute_loss=True) as specified by VAST.forward (vast.py:317-348) /
+    forward_ret (:383-464) / forward_cap (:485-512).  Single-process: `world` optionally holds the other ranks'
+    gathered tensors ({'feat_t_all','ids_all','mask_all', 'feat_<c>_all', 'cond_<c>_all'}); by default the
+    global batch is the local batch (W=1).  `injected` carries the RNG draws: neg_cond_idx / neg_text_idx per
+    subtask, masked_ids / labels for cap."""
+    enc = encode_batch(sd, arch, batch, cfg.get("pool_video", False), (injected or {}).get("drop_path_scale"))
+    ids, am = batch["input_ids"], batch["attention_mask"]
+    out = {}
+    for t in task.split("_"):
+        subtasks = t.split("%")[1:]
+        if t.startswith("ret"):
+            l_itc, l_itm = [], []
+            feat_t = enc["feat_t"]
+            feat_t_all = world["feat_t_all"] if world else feat_t.detach()
+            ids_all = world["ids_all"] if world else ids
+            mask_all = world["mask_all"] if world else am
+            for st in subtasks:
+                c = st[1:]
+                fc = feat_cond(sd, enc, c)
+                fc_all = world[f"feat_{c}_all"] if world else fc.detach()
+                li, sim_t2c, sim_c2t = itc_loss(feat_t, fc, feat_t_all, fc_all, sd["contra_temp"], rank)
+                l_itc.append(li)
+                cond = condition_feats(enc, c)
+                cond_all = world[f"cond_{c}_all"] if world else cond
+                inj = injected[st]
+                lm, _ = itm_loss(sd, ids, am, cond, cond_all, ids_all, mask_all, inj["neg_cond_idx"],
+                                 inj["neg_text_idx"], cfg["itm_ratio"])
+                l_itm.append(lm)
+            out["loss_itc"] = sum(l_itc) / len(l_itc)
+            out["loss_itm"] = sum(l_itm) / len(l_itm)
+        elif t.startswith("cap"):
+            ls = []
+            for st in subtasks:
+                cond = condition_feats(enc, st[1:])
+                ls.append(cap_loss(sd, injected["cap"]["masked_ids"], am, injected["cap"]["labels"], cond))
+            out["loss_cap"] = sum(ls) / len(ls)
+        else:
+            raise NotImplementedError(t)
+    return out, enc
+
+
+def token_masker(tokens, mask_prob, rng, mask_token=103, range_start=106, range_end=30522):
+    """TokenMasker.perform_mask (data/model/general_module.py:64-97) with `rng` a random.Random: position 0 and
+    pads (id 0) never masked, every row retried until >= 1 token is masked; 80% [MASK] / 10% random / 10% keep."""
+    import numpy as np
+    toks = np.array(tokens.cpu().numpy())
+    ind = np.zeros(toks.shape, dtype=np.int64)
+    for i in range(len(ind)):
+        while all(ind[i] == 0):
+            for j in range(1, len(ind[0])):
+                if toks[i][j] != 0 and rng.random() < mask_prob:
+                    ind[i][j] = 1
+    labels = -np.ones(toks.shape, dtype=np.int64) * 100
+    for i in range(toks.shape[0]):
+        for j in range(toks.shape[1]):
+            if ind[i][j] == 1:
+                src = toks[i][j]
+                p = rng.random()
+                if p < 0.8:
+                    toks[i][j] = mask_token
+                elif p < 0.9:
+                    toks[i][j] = rng.choice(list(range(range_start, range_end)))
+                labels[i][j] = src
+    return torch.from_numpy(toks).long(), torch.from_numpy(labels).long()

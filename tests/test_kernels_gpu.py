@@ -1,0 +1,315 @@
+"""Per-kernel numerics: every libmico_hip.so entry point against a plain PyTorch fp32 evaluation of the same op on
+the same (16-bit-rounded) inputs.  These call through the C-ABI (mico_amd.ops -> ctypes)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12)).item()
+
+
+def tol(dtype, k=1.0):
+    return (2e-3 if dtype == torch.float16 else 1.6e-2) * k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 200), (1024, 1408, 1408), (130, 24, 72), (257 * 3, 768, 592)])
+def test_gemm_plain(cuda, dtype, ta, tb, M, N, K):
+    from mico_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ldm, ldn, ldk = ops.pad8(M), ops.pad8(N), ops.pad8(K)
+    A = torch.randn((K, ldm) if ta else (M, ldk), device=cuda, generator=g).to(dtype)
+    B = torch.randn((K, ldn) if tb else (N, ldk), device=cuda, generator=g).to(dtype)
+    Af = (A[:, :M].t() if ta else A[:, :K]).float()
+    Bf = (B[:, :N].t() if tb else B[:, :K]).float()
+    ref = Af @ Bf.t()
+    out = torch.full((M, N), float("nan"), device=cuda, dtype=torch.float32)
+    ops.gemm(A, B, out, ta=ta, tb=tb, M=M, N=N, K=K, dtype=dtype)
+    assert rel_err(out, ref) < 1e-5 * math.sqrt(K) + 1e-6
+    out16 = torch.empty((M, N), device=cuda, dtype=dtype)
+    ops.gemm(A, B, out16, ta=ta, tb=tb, M=M, N=N, K=K, dtype=dtype)
+    assert rel_err(out16, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(cuda, dtype):
+    from mico_amd import ops
+    torch.manual_seed(2)
+    M, N, K = 514, 264, 328
+    A = (0.5 * torch.randn(M, K, device=cuda)).to(dtype)
+    W = (0.1 * torch.randn(N, K, device=cuda)).to(dtype)
+    bias = torch.randn(N, device=cuda)
+    acc = A.float() @ W.float().t()
+    # bias + GELU with pre-activation copy
+    h = torch.empty(M, N, device=cuda, dtype=dtype)
+    a = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(A, W, a, bias=bias, aux_out=h, act=ops.ACT_GELU)
+    assert rel_err(h, acc + bias) < tol(dtype)
+    assert rel_err(a, F.gelu(acc + bias)) < tol(dtype)
+    # GELU grad epilogue
+    dh = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(A, W, dh, aux_in=h, act=ops.ACT_GELU_GRAD, alpha=0.5)
+    hf = h.float()
+    gp = 0.5 * (1 + torch.erf(hf / math.sqrt(2))) + hf * torch.exp(-0.5 * hf * hf) / math.sqrt(2 * math.pi)
+    assert rel_err(dh, 0.5 * acc * gp) < tol(dtype)
+    # bias + per-sample scale + residual (in place, fp32)
+    rows_per = 257
+    rs = torch.rand((M + rows_per - 1) // rows_per, device=cuda) + 0.5
+    x = torch.randn(M, N, device=cuda)
+    ref = x + (acc + bias) * rs.repeat_interleave(rows_per)[:M, None]
+    ops.gemm(A, W, x, bias=bias, row_scale=rs, rows_per_scale=rows_per, resid=x)
+    assert rel_err(x, ref) < 1e-5 * math.sqrt(K)
+    # patch rows -> token rows with positional table
+    B_, npatch = 2, 257
+    pos = torch.randn(npatch + 1, N, device=cuda)
+    xt = torch.zeros(B_ * (npatch + 1), N, device=cuda)
+    ops.gemm(A, W, xt, bias=bias, pos=pos, pos_rows=npatch + 1, remap=(npatch, 1, 1))
+    ref = torch.zeros_like(xt).view(B_, npatch + 1, N)
+    ref[:, 1:] = (acc + bias).view(B_, npatch, N) + pos[1:]
+    assert rel_err(xt, ref.view(-1, N)) < 1e-5 * math.sqrt(K)
+    # weight-gradient form with split-K accumulation: dW[N,K] += dY^T X
+    dY = (0.1 * torch.randn(M, N, device=cuda)).to(dtype)
+    dW = torch.ones(N, K, device=cuda)
+    ops.gemm(dY, A, dW, ta=True, tb=True, accumulate=True, split_k=4, alpha=2.0)
+    assert rel_err(dW, 1 + 2.0 * dY.float().t() @ A.float()) < 1e-5 * math.sqrt(M)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cols", [768, 1408, 2048])
+@pytest.mark.parametrize("xdt", ["f32", "16"])
+def test_layernorm(cuda, dtype, cols, xdt):
+    from mico_amd import ops
+    torch.manual_seed(3)
+    rows = 1027
+    x = torch.randn(rows, cols, device=cuda) * 2 + 0.3
+    if xdt == "16":
+        x = x.to(dtype)
+    gmm = 1 + 0.1 * torch.randn(cols, device=cuda)
+    bta = 0.1 * torch.randn(cols, device=cuda)
+    xr = x.float().requires_grad_(True)
+    gr, br = gmm.clone().requires_grad_(True), bta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (cols,), gr, br, 1e-6)
+    y16 = torch.empty(rows, cols, device=cuda, dtype=dtype)
+    y32 = torch.empty(rows, cols, device=cuda)
+    mean = torch.empty(rows, device=cuda)
+    rstd = torch.empty(rows, device=cuda)
+    ops.layernorm_fwd(x, gmm, bta, 1e-6, out16=y16, out32=y32, mean=mean, rstd=rstd, dtype=dtype)
+    assert rel_err(y32, ref) < 2e-6
+    assert rel_err(y16, ref) < tol(dtype)
+    dy = torch.randn(rows, cols, device=cuda)
+    ref.backward(dy)
+    add = torch.randn(rows, cols, device=cuda)
+    dx = torch.empty(rows, cols, device=cuda)
+    dx16 = torch.empty(rows, cols, device=cuda, dtype=dtype)
+    dg = torch.ones(cols, device=cuda)
+    db = torch.ones(cols, device=cuda)
+    ops.layernorm_bwd(dy, x, gmm, mean, rstd, dx_add=add, dx32=dx, dx16=dx16, scale16=2.0, dgamma=dg, dbeta=db,
+                      grad_scale=0.5, dtype=dtype)
+    assert rel_err(dx, xr.grad + add) < 1e-5
+    assert rel_err(dx16, 2.0 * (xr.grad + add)) < tol(dtype)
+    assert rel_err(dg, 1 + 0.5 * gr.grad) < 2e-5
+    assert rel_err(db, 1 + 0.5 * br.grad) < 2e-5
+    # post-add table (frame + type embeddings)
+    table = torch.randn(4, cols, device=cuda)
+    y2 = torch.empty(rows, cols, device=cuda)
+    ops.layernorm_fwd(x, gmm, bta, 1e-6, out32=y2, post_add=table, post_rows_per_group=7, post_groups=4, dtype=dtype)
+    idx = (torch.arange(rows, device=cuda) // 7) % 4
+    assert rel_err(y2, ref.detach() + table[idx]) < 2e-6
+
+
+def _attn_ref(q, k, v, scale, mask):
+    s = torch.einsum("bihd,bjhd->bhij", q, k) * scale
+    if mask is not None:
+        s = s + (mask[:, None, None, :] if mask.dim() == 2 else mask[:, None])
+    p = s.softmax(-1)
+    return torch.einsum("bhij,bjhd->bihd", p, v)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["vit_g", "vit_b", "bert_self2d", "bert_self3d", "bert_cross"])
+def test_attention(cuda, dtype, case):
+    from mico_amd import ops
+    torch.manual_seed(4)
+    if case == "vit_g":
+        B, H, Sq, Sk, hd, mask = 3, 16, 257, 257, 88, None
+    elif case == "vit_b":
+        B, H, Sq, Sk, hd, mask = 2, 12, 197, 197, 64, None
+    elif case == "bert_self2d":
+        B, H, Sq, Sk, hd = 5, 12, 77, 77, 64
+        keep = (torch.arange(Sk, device=cuda)[None] < torch.tensor([77, 30, 12, 50, 1], device=cuda)[:, None]).float()
+        mask = (1 - keep) * -10000.0
+    elif case == "bert_self3d":
+        B, H, Sq, Sk, hd = 4, 12, 40, 40, 64
+        keep = (torch.arange(Sk, device=cuda)[None] < torch.tensor([40, 30, 12, 7], device=cuda)[:, None]).float()
+        mask = (1 - torch.tril(keep[:, None, :].expand(B, Sq, Sk))) * -10000.0
+        mask = mask.contiguous()
+    else:
+        B, H, Sq, Sk, hd, mask = 3, 12, 77, 1285, 64, None
+    scale = hd ** -0.5
+    D = H * hd
+    self_attn = Sq == Sk and case.startswith("vit")
+    if self_attn:   # fused [B, N, 3, H, hd] projection buffer, as the ViT uses it
+        qkv = torch.randn(B, Sq, 3 * D, device=cuda).to(dtype)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        strides = dict(q_strides=(Sq * 3 * D, 3 * D), k_strides=(Sk * 3 * D, 3 * D), v_strides=(Sk * 3 * D, 3 * D))
+    else:
+        q = torch.randn(B, Sq, D, device=cuda).to(dtype)
+        k = torch.randn(B, Sk, D, device=cuda).to(dtype)
+        v = torch.randn(B, Sk, D, device=cuda).to(dtype)
+        strides = dict(q_strides=(Sq * D, D), k_strides=(Sk * D, D), v_strides=(Sk * D, D))
+    qf = q.float().reshape(B, Sq, H, hd).detach().requires_grad_(True)
+    kf = k.float().reshape(B, Sk, H, hd).detach().requires_grad_(True)
+    vf = v.float().reshape(B, Sk, H, hd).detach().requires_grad_(True)
+    ref = _attn_ref(qf, kf, vf, scale, mask)
+    o = torch.empty(B, Sq, D, device=cuda, dtype=dtype)
+    lse = torch.empty(B, H, Sq, device=cuda)
+    kw = dict(B=B, H=H, Sq=Sq, Sk=Sk, hd=hd, scale=scale, mask=mask, o_strides=(Sq * D, D), **strides)
+    ops.attn_fwd(q, k, v, o, lse, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(o, ref.reshape(B, Sq, D)) < tol(dtype, 1.5)
+    do = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    ref.backward(do.float().reshape(B, Sq, H, hd))
+    if self_attn:
+        dqkv = torch.zeros_like(qkv)
+        dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+    else:
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    delta = torch.empty(B, H, Sq, device=cuda)
+    ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, delta, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(dq, qf.grad.reshape(B, Sq, D)) < tol(dtype, 3)
+    assert rel_err(dk, kf.grad.reshape(B, Sk, D)) < tol(dtype, 3)
+    assert rel_err(dv, vf.grad.reshape(B, Sk, D)) < tol(dtype, 3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(cuda, dtype):
+    from mico_amd import ops
+    torch.manual_seed(5)
+    # im2row == unfold, incl. zero padding and the 1-channel (audio) form
+    for Cc, P in [(3, 14), (1, 14), (3, 16)]:
+        px = torch.randn(3, Cc, 224, 224, device=cuda)
+        kreal = Cc * P * P
+        kpad = (kreal + 63) // 64 * 64
+        rows = torch.full((3 * (224 // P) ** 2, kpad), float("nan"), device=cuda, dtype=dtype)
+        ops.im2row(px, rows, P, kpad)
+        ref = F.unfold(px, P, stride=P).transpose(1, 2).reshape(-1, kreal)
+        assert torch.equal(rows[:, :kreal], ref.to(dtype))
+        assert (rows[:, kreal:] == 0).all()
+    # casts / gather / colsum / cls rows / add
+    src = torch.randn(77, 588, device=cuda)
+    dst = torch.empty(77, 640, device=cuda, dtype=dtype)
+    ops.cast_f32_to_16(src, dst, cols=588, cols_pad=640, scale=2.0)
+    assert torch.equal(dst[:, :588], (2.0 * src).to(dtype)) and (dst[:, 588:] == 0).all()
+    back = torch.ones(77, 640, device=cuda)
+    ops.cast_16_to_f32(dst, back, scale=0.5, accumulate=True)
+    assert rel_err(back, 1 + 0.5 * dst.float()) < 1e-6
+    g = torch.randn(2 * 257, 64, device=cuda)
+    rs = torch.tensor([0.5, 2.0], device=cuda)
+    out = torch.empty(2 * 256, 64, device=cuda, dtype=dtype)
+    ops.gather_rows_cast(g, out, remap=(256, 1, 1), row_scale=rs, rows_per_scale=257, scale=3.0)
+    ref = (g.view(2, 257, 64)[:, 1:] * rs[:, None, None] * 3.0).reshape(-1, 64)
+    assert rel_err(out, ref) < tol(dtype)
+    xs = torch.randn(5000, 300, device=cuda)
+    cs = torch.ones(300, device=cuda)
+    ops.colsum(xs, cs, scale=0.5, accumulate=True)
+    assert rel_err(cs, 1 + 0.5 * xs.sum(0)) < 1e-5
+    ops.colsum(xs.to(dtype), cs, accumulate=False)
+    assert rel_err(cs, xs.to(dtype).float().sum(0)) < 1e-5
+    x = torch.zeros(3 * 5, 32, device=cuda)
+    cls, pos0 = torch.randn(32, device=cuda), torch.randn(32, device=cuda)
+    ops.cls_rows(x, 3, 5, cls, pos0)
+    assert torch.equal(x.view(3, 5, 32)[:, 0], (cls + pos0).expand(3, 32)) and (x.view(3, 5, 32)[:, 1:] == 0).all()
+    a, b = torch.randn(1000, 64, device=cuda), torch.randn(1000, 64, device=cuda)
+    y = torch.empty_like(a)
+    y16 = torch.empty(1000, 64, device=cuda, dtype=dtype)
+    ops.add_f32(a, b, y, y16, scale16=4.0)
+    assert torch.equal(y, a + b) and rel_err(y16, 4 * (a + b)) < tol(dtype)
+    # swiglu
+    x1 = torch.randn(300, 2048, device=cuda).to(dtype)
+    x2 = torch.randn(300, 2048, device=cuda).to(dtype)
+    h = torch.empty_like(x1)
+    ops.swiglu_fwd(x1, x2, h)
+    x1f, x2f = x1.float().requires_grad_(True), x2.float().requires_grad_(True)
+    ref = F.silu(x1f) * x2f
+    assert rel_err(h, ref) < tol(dtype)
+    dh = torch.randn(300, 2048, device=cuda).to(dtype)
+    ref.backward(dh.float())
+    d1, d2 = torch.empty_like(x1), torch.empty_like(x2)
+    ops.swiglu_bwd(x1, x2, dh, d1, d2)
+    assert rel_err(d1, x1f.grad) < tol(dtype) and rel_err(d2, x2f.grad) < tol(dtype)
+    # rope (B, N, H, hd) tokens 1.. only, and its transpose
+    B, N, H, hd = 2, 197, 12, 64
+    t = torch.randn(B, N, H * hd, device=cuda).to(dtype)
+    cos, sin = torch.randn(N - 1, hd, device=cuda), torch.randn(N - 1, hd, device=cuda)
+    tf = t.float().view(B, N, H, hd)
+    x2_ = tf[:, 1:].reshape(B, N - 1, H, hd // 2, 2)
+    rot = torch.stack((-x2_[..., 1], x2_[..., 0]), -1).reshape(B, N - 1, H, hd)
+    ref = torch.cat((tf[:, :1], tf[:, 1:] * cos[None, :, None] + rot * sin[None, :, None]), 1).reshape(B, N, H * hd)
+    t2 = t.clone()
+    ops.rope(t2, N * H * hd, H * hd, B, N, H, hd, cos, sin)
+    assert rel_err(t2, ref) < tol(dtype)
+    # inverse == autograd transpose
+    tg = t.float().view(B, N, H, hd).clone().requires_grad_(True)
+    xx = tg[:, 1:].reshape(B, N - 1, H, hd // 2, 2)
+    rr = torch.stack((-xx[..., 1], xx[..., 0]), -1).reshape(B, N - 1, H, hd)
+    yy = torch.cat((tg[:, :1], tg[:, 1:] * cos[None, :, None] + rr * sin[None, :, None]), 1)
+    gy = torch.randn(B, N, H * hd, device=cuda).to(dtype)
+    yy.backward(gy.float().view(B, N, H, hd))
+    g2 = gy.clone()
+    ops.rope(g2, N * H * hd, H * hd, B, N, H, hd, cos, sin, inverse=True)
+    assert rel_err(g2, tg.grad.reshape(B, N, H * hd)) < tol(dtype)
+
+
+def test_embed_loss_l2(cuda):
+    from mico_amd import ops
+    torch.manual_seed(6)
+    vocab, S, b, D = 1000, 20, 6, 768
+    ids = torch.randint(0, vocab, (b, S), device=cuda)
+    word, pos, typ = torch.randn(vocab, D, device=cuda), torch.randn(512, D, device=cuda), torch.randn(2, D, device=cuda)
+    out = torch.empty(b * S, D, device=cuda)
+    ops.bert_embed_fwd(ids, word, pos, typ[0], out, S)
+    assert torch.equal(out.view(b, S, D), word[ids] + typ[0] + pos[:S])
+    dsum = torch.randn(b * S, D, device=cuda)
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros(D, device=cuda)
+    ops.embed_scatter_add(ids, dsum, dword, dpos, dtyp, S, scale=0.5)
+    ref = torch.zeros_like(word).index_add_(0, ids.view(-1), 0.5 * dsum)
+    assert rel_err(dword, ref) < 1e-5
+    assert rel_err(dpos[:S], 0.5 * dsum.view(b, S, D).sum(0)) < 1e-5
+    assert rel_err(dtyp, 0.5 * dsum.sum(0)) < 1e-5
+    # cross-entropy with label smoothing / ignore index / logits scale, fp32 and 16-bit logits
+    for dt, cols, ls in [(torch.float32, 128, 0.1), (torch.float16, 30522, 0.0), (torch.bfloat16, 2, 0.0)]:
+        rows = 37
+        ld = (cols + 7) // 8 * 8
+        logits = torch.randn(rows, ld, device=cuda).to(dt)
+        tgt = torch.randint(0, cols, (rows,), device=cuda)
+        tgt[::5] = -100
+        lf = logits[:, :cols].float().detach().requires_grad_(True)
+        ref = F.cross_entropy(lf / 0.07, tgt, label_smoothing=ls, reduction="none")
+        row_loss = torch.empty(rows, device=cuda)
+        dl = torch.zeros_like(logits)
+        gscale = torch.tensor([2.0], device=cuda)
+        ops.ce_fwd_bwd(logits, tgt, cols=cols, label_smoothing=ls, logits_scale=1 / 0.07, row_loss=row_loss, dlogits=dl,
+                       dscale_ptr=gscale, dscale=0.25)
+        assert rel_err(row_loss, ref) < (1e-5 if dt == torch.float32 else 1e-4)
+        (0.5 * ref.sum()).backward()
+        assert rel_err(dl[:, :cols], lf.grad) < (1e-5 if dt == torch.float32 else 1.6e-2)
+    x = torch.randn(64, 512, device=cuda)
+    y, inv = torch.empty_like(x), torch.empty(64, device=cuda)
+    ops.l2norm_fwd(x, y, inv)
+    xr = x.clone().requires_grad_(True)
+    ref = F.normalize(xr, dim=-1)
+    assert rel_err(y, ref) < 1e-6
+    dy = torch.randn_like(x)
+    ref.backward(dy)
+    dx = torch.empty_like(x)
+    ops.l2norm_bwd(dy, y, inv, dx)
+    assert rel_err(dx, xr.grad) < 1e-5
