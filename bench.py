@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py - MiCo omni-modal alignment step (ViT-g/14 fwd+bwd) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the single-GPU ViT-g/14 configuration the metric is quoted on): per GPU b = 64 samples
+of image (1 frame, 224^2) + audio (4 spectrogram windows of 224x224 = 10 s of mel-spec) + text (77 tokens), synthetic
+inputs resident in HBM, random-init weights of the real architecture (EVA01-CLIP-g/14 tower shared by image and audio,
+BERT-base with cross-attention), one step = forward + backward of the full alignment loss "ret%tva_cap%tva" (ITC + ITM with
+in-batch hard negatives + causal masked-caption LM; step-B of SURVEY.md section 8d), bf16 MFMA with fp32 accumulation /
+residual stream / statistics.  For N > 1 every rank runs that workload on its own shard (weak scaling), the contrastive
+features are exchanged with one packed RCCL all-gather, hard-negative condition rows with an index-then-fetch all-to-all,
+and gradients are averaged with bucketed all-reduces overlapped with backward.
+
+One JSON line on rank 0 (see the repo prompt for the field contract) with two extra objects:
+  roofline     - the dominant kernel (MFMA GEMM) timed per launch with HIP events inside the timed region;
+  cpu_baseline - the CPU oracle (oracle/mico_oracle.py, a restatement of the reference parity-locked to it) timed on the
+                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic forward GF / sample for step-B at config-3 shapes: 2 * MAC of every
+# GEMM incl. attention, LM head only where a loss consumes it; fwd+bwd = 3 x fwd
+ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74}
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--vision", default="evaclip01_giant")
+    ap.add_argument("--layers", type=int, default=None, help="truncate the ViT (debug only; invalidates the metric)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--task", default="ret%tva_cap%tva")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd_cpu, args):
+    """Oracle step-B forward+backward on the host cores, bounded sample: --cpu-batch samples, ONE untimed-warmup-free step."""
+    from oracle import mico_oracle as O
+    from mico_amd.weights import synth_inputs
+    import random
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    arch = O.ARCHS[args.vision]
+    b = args.cpu_batch
+    inp = synth_inputs(dict(b=b, vision=1, audio=4, S=77), seed=99)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_cpu.items()}
+    sd["multimodal_encoder.cls.predictions.decoder.weight"] = sd["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    mi, lab = O.token_masker(inp["input_ids"], 0.6, random.Random(0))
+    idx = torch.arange(b).roll(1)
+    injected = {"tva": dict(neg_cond_idx=idx, neg_text_idx=idx), "cap": dict(masked_ids=mi, labels=lab)}
+    t0 = time.time()
+    out, _ = O.mico_forward(sd, arch, inp, args.task, dict(itm_ratio=0.1), injected=injected)
+    sum(out.values()).backward()
+    dt = time.time() - t0
+    return dict(value=b / dt, unit="samples/s", cores=ncores, kind="port",
+                sample=f"oracle/mico_oracle.py fp32, same step ({args.task}) at b={b} (image 1 + audio 4 frames + 77 tokens), "
+                       f"1 step, {dt:.1f} s on {ncores} threads")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mico_amd import runtime, ops
+    from mico_amd.model import MiCo, default_cfg
+    from mico_amd.weights import synth_state_dict, synth_inputs
+    from mico_amd.distributed import GradBucketReducer
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    runtime.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    cfg = default_cfg(args.vision, vision_layers=args.layers)
+    model = MiCo(cfg)
+    sd_cpu = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
+    model.load_state_dict(sd_cpu, strict=False)
+    model.to(dev)
+    model.eval() if args.eval_mode else model.train()
+    b = args.batch
+    batch = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, vision=1, audio=4, S=77), seed=1234 + rank).items()}
+    reducer = GradBucketReducer(model.parameters()) if world > 1 else None
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        losses = model(dict(batch), args.task, compute_loss=True)
+        total = sum(losses.values())
+        total.backward()
+        if reducer is not None:
+            reducer.finish()
+        return losses
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer = ops.KernelTimer()
+    ops.GEMM_TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    samples = b * world * args.steps
+    value = samples / elapsed
+    summ = timer.summary()
+    names = {(0, 0): "gemm_kernel<T,false,false> (y = x W^T, forward)", (0, 1): "gemm_kernel<T,false,true> (dx = dy W)",
+             (1, 1): "gemm_kernel<T,true,true> (dW = dy^T x)"}
+    per_variant = {names[k]: dict(launches=v["launches"], avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / v["ms"] / 1e9)
+                   for k, v in summ.items()}
+    tot_flops = sum(v["flops"] for v in summ.values())
+    tot_ms = sum(v["ms"] for v in summ.values())
+    dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+    roofline = dict(bound="mfma", kernel=names[dom[0]], achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / MFMA_PEAK_TFLOPS, traffic=None, launches=dom[1]["launches"],
+                    avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
+                    all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
+    workload = "vitg_img1_aud4_txt77_stepB"
+    full = args.layers is None and args.vision == "evaclip01_giant" and args.task == "ret%tva_cap%tva"
+    step_tflops = ALG_TFLOP_PER_SAMPLE[workload] * value / world if full else None
+    res = {
+        "metric": "omni-modal samples/sec (ViT-g/14 fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, "
+                               f"b={b}/GPU, task {args.task} (ITC+ITM+CAP)", "per_gpu_batch": b, "global_batch": b * world,
+                   "vision": args.vision, "vit_layers": args.layers or "full", "parallelism": f"dp{world}",
+                   "droppath": not args.eval_mode, "bert_dropout": False},
+        "samples_per_sec_per_gpu": value / world,
+        "step_algorithmic_tflops_per_gpu": step_tflops,
+        "step_mfma_frac": (step_tflops / MFMA_PEAK_TFLOPS) if step_tflops else None,
+        "losses": {k: float(v) for k, v in losses.items()},
+        "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(sd_cpu, args)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,9 +46,9 @@ const char* mico_last_error_string(void);
  *   act: MICO_ACT_GELU -> v = gelu_erf(v);  MICO_ACT_GELU_GRAD -> v *= gelu'(aux_in[m,n]);
  *        MICO_ACT_SILU_MUL_GRAD etc. see enum
  *   v *= row_scale[m / rows_per_scale]        (row_scale != NULL: DropPath per-sample factor, eva_vit_model.py:121-138)
- *   v += resid[m,n]                           (resid != NULL, fp32, ld = ldc; may alias C)
- *   v += pos[(m % pos_rows) , n]              (pos != NULL, fp32 [pos_rows,N]: positional table, eva_vit_model.py:619)
+ *   v += resid[m',n]                          (resid != NULL, fp32, ld = ldc; may alias C)
  *   out row index: m' = m + (m / remap_group) * remap_skip + remap_offset   (patch rows -> token rows, :616-619)
+ *   v += pos[(m' % pos_rows) , n]             (pos != NULL, fp32 [pos_rows,N]: positional table, eva_vit_model.py:619)
  *   C[m',n] = v  (fp32 if c_dtype == MICO_F32 (beta=1 accumulates: C += v, uses atomics when split_k > 1) else T)
  * ------------------------------------------------------------------------------------------------------------- */
 #define MICO_ACT_NONE 0
@@ -90,11 +90,12 @@ int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
                        int64_t rows, int cols, float eps,
                        const float* post_add, int post_rows_per_group, int post_groups,
                        int dtype, void* stream);
-/* dx = LN'(dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 and/or dx16 (dx16 = T(dx * scale16)).
+/* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
+ * (dx16 = T(dx * scale16)).
  * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced
  * and ACCUMULATED (+=) into dgamma/dbeta (fp32 [cols]) scaled by grad_scale. */
 int mico_layernorm_bwd_nblk(int64_t rows);
-int mico_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype,
+int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        const float* dx_add, float* dx32, void* dx16, float scale16,
                        float* dgamma, float* dbeta, float grad_scale, float* ws,
@@ -158,6 +159,15 @@ int mico_cls_rows(float* x, int64_t ld, int B, int group_rows, const float* cls,
 /* y[r,:] = a[r,:] + b[r,:] (fp32), optional 16-bit copy */
 int mico_add_f32(const float* a, const float* b, float* y, void* y16, int64_t n, float scale16, int dtype, void* stream);
 
+/* exact-erf GELU (nn.GELU; mico.py:22-28) forward / backward, fp32 and 16-bit flat arrays. */
+int mico_gelu_f32(const float* x, float* y, int64_t n, void* stream);
+int mico_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int mico_gelu_16(const void* x, void* y, int64_t n, int dtype, void* stream);
+int mico_gelu_bwd_16(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+/* CLS pooling (mico.py:157-182): pooled[b,:] = mean_f tokens[(b*n+f)*frame_stride + 0..D); backward adds into dtokens. */
+int mico_cls_pool_fwd(const float* tokens, float* pooled, int b, int n, int64_t frame_stride, int D, void* stream);
+int mico_cls_pool_bwd(const float* dpooled, float* dtokens, int b, int n, int64_t frame_stride, int D, void* stream);
+
 /* SwiGLU gate (eva_vit_model.py:217-220): h = silu(x1) * x2, 16-bit in/out, and its backward. */
 int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t n, int dtype, void* stream);
 int mico_swiglu_bwd(const void* x1, const void* x2, const void* dh, void* dx1, void* dx2, int64_t n, int dtype, void* stream);
@@ -182,6 +192,10 @@ int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t ro
                     float* row_loss, float* row_lse,
                     void* dlogits, int dlogits_dtype, int64_t ld_d, const float* dscale_ptr, float dscale,
                     int dtype, void* stream);
+/* Small exact-fp32 GEMM for the tiny heads and similarity matrices (contra heads, itm head, ITC logits; vast.py:405-408,
+ * mico.py:36-52): C = alpha * opA(A) opB(B) + beta * C, same ta/tb convention as mico_gemm, any sizes, fp32 everywhere. */
+int mico_sgemm_small(int ta, int tb, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                     float* C, int64_t ldc, float alpha, float beta, const float* bias, void* stream);
 /* L2 normalise rows (F.normalize, eps 1e-12) forward / backward, fp32. */
 int mico_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int cols, void* stream);
 int mico_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int cols, void* stream);

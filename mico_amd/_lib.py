@@ -40,7 +40,7 @@ PROTOTYPES = {
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
                            c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
-    "mico_layernorm_bwd": [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
+    "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
                            c_i64, c_int, c_int, c_vp],
     "mico_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
@@ -58,6 +58,13 @@ PROTOTYPES = {
     "mico_embed_scatter_add": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_f, c_vp],
     "mico_ce_fwd_bwd": [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_int, c_i64,
                         c_vp, c_f, c_int, c_vp],
+    "mico_sgemm_small": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f, c_f, c_vp, c_vp],
+    "mico_gelu_f32": [c_vp, c_vp, c_i64, c_vp],
+    "mico_gelu_bwd_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "mico_gelu_16": [c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_gelu_bwd_16": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_cls_pool_fwd": [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
+    "mico_cls_pool_bwd": [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
     "mico_l2norm_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_l2norm_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }

@@ -424,3 +424,138 @@ extern "C" int mico_l2norm_bwd(const float* dy, const float* y, const float* inv
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
+
+// ---- small exact-fp32 GEMM (heads, similarity matrices): 16x16 LDS-tiled, one output per thread ---------------------
+namespace {
+__global__ __launch_bounds__(256) void sgemm_small_kernel(int ta, int tb, int M, int N, int K, const float* __restrict__ A,
+                                                          int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                          float* __restrict__ Cm, int64_t ldc, float alpha, float beta,
+                                                          const float* __restrict__ bias) {
+    __shared__ float as[16][17], bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        {   // A tile [16 m][16 k]
+            const int mm = blockIdx.y * 16 + ty, kk = k0 + tx;
+            float v = 0.f;
+            if (mm < M && kk < K) v = ta ? A[(int64_t)kk * lda + mm] : A[(int64_t)mm * lda + kk];
+            as[ty][tx] = v;
+            const int nn = blockIdx.x * 16 + ty;
+            float w = 0.f;
+            if (nn < N && kk < K) w = tb ? B[(int64_t)kk * ldb + nn] : B[(int64_t)nn * ldb + kk];
+            bs[ty][tx] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(as[ty][k], bs[tx][k], acc);
+        __syncthreads();
+    }
+    if (m < M && n < N) {
+        float v = alpha * acc;
+        if (bias) v += bias[n];
+        float* c = Cm + (int64_t)m * ldc + n;
+        *c = (beta != 0.f) ? v + beta * *c : v;
+    }
+}
+}  // namespace
+
+extern "C" int mico_sgemm_small(int ta, int tb, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                float* Cm, int64_t ldc, float alpha, float beta, const float* bias, void* stream) {
+    MICO_CHECK(A && B && Cm && M > 0 && N > 0 && K > 0, "mico_sgemm_small: bad args");
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ST, ta, tb, M, N, K, A, lda, B, ldb, Cm, ldc, alpha, beta, bias);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+// ---- GELU helpers and CLS pooling ---------------------------------------------------------------------------------------
+namespace {
+__global__ void gelu_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) y[i] = gelu_f(x[i]);
+}
+__global__ void gelu_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) dx[i] = dy[i] * gelu_grad_f(x[i]);
+}
+template <typename T>
+__global__ void gelu_16_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * EB) {
+        float a[8];
+        unpack8<T>(((const s16x8*)x)[i], a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = gelu_f(a[k]);
+        ((s16x8*)y)[i] = pack8<T>(a);
+    }
+}
+template <typename T>
+__global__ void gelu_bwd_16_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * EB) {
+        float a[8], d[8];
+        unpack8<T>(((const s16x8*)x)[i], a);
+        unpack8<T>(((const s16x8*)dy)[i], d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] *= gelu_grad_f(a[k]);
+        ((s16x8*)dx)[i] = pack8<T>(d);
+    }
+}
+// tokens [b, n, N, D] fp32 -> pooled[b, D] = mean_n tokens[b, n, 0, :]   (model/mico.py:157-164)
+__global__ void cls_pool_fwd_kernel(const float* __restrict__ tok, float* __restrict__ out, int b, int n, int64_t frame_stride, int D) {
+    const int64_t total = (int64_t)b * D;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t bi = i / D;
+        const int c = (int)(i - bi * D);
+        float s = 0.f;
+        for (int f = 0; f < n; ++f) s += tok[(bi * n + f) * frame_stride + c];
+        out[i] = s / (float)n;
+    }
+}
+// dtok[b, n, 0, :] += dpooled[b, :] / n
+__global__ void cls_pool_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtok, int b, int n, int64_t frame_stride, int D) {
+    const int64_t total = (int64_t)b * n * D;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t bf = i / D;
+        const int c = (int)(i - bf * D);
+        dtok[bf * frame_stride + c] += dout[(bf / n) * D + c] / (float)n;
+    }
+}
+}  // namespace
+
+extern "C" int mico_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
+    MICO_CHECK(x && y, "mico_gelu_f32: bad args");
+    if (n <= 0) return MICO_OK;
+    hipLaunchKernelGGL(gelu_f32_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, y, n);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+extern "C" int mico_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    MICO_CHECK(x && dy && dx, "mico_gelu_bwd_f32: bad args");
+    if (n <= 0) return MICO_OK;
+    hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, dy, dx, n);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+extern "C" int mico_gelu_16(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && x && y && n % 8 == 0, "mico_gelu_16: bad args");
+    if (n <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(gelu_16_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x, (T*)y, n / 8));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+extern "C" int mico_gelu_bwd_16(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype) && x && dy && dx && n % 8 == 0, "mico_gelu_bwd_16: bad args");
+    if (n <= 0) return MICO_OK;
+    DISPATCH_T16(dtype, hipLaunchKernelGGL(gelu_bwd_16_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x, (const T*)dy, (T*)dx, n / 8));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+extern "C" int mico_cls_pool_fwd(const float* tokens, float* pooled, int b, int n, int64_t frame_stride, int D, void* stream) {
+    MICO_CHECK(tokens && pooled && b > 0 && n > 0, "mico_cls_pool_fwd: bad args");
+    hipLaunchKernelGGL(cls_pool_fwd_kernel, dim3(egrid((int64_t)b * D)), dim3(EB), 0, ST, tokens, pooled, b, n, frame_stride, D);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+extern "C" int mico_cls_pool_bwd(const float* dpooled, float* dtokens, int b, int n, int64_t frame_stride, int D, void* stream) {
+    MICO_CHECK(dpooled && dtokens && b > 0 && n > 0, "mico_cls_pool_bwd: bad args");
+    hipLaunchKernelGGL(cls_pool_bwd_kernel, dim3(egrid((int64_t)b * n * D)), dim3(EB), 0, ST, dpooled, dtokens, b, n, frame_stride, D);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}

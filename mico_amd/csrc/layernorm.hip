@@ -80,7 +80,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ dx_add,
                                                            float* __restrict__ dx32, T* __restrict__ dx16, float scale16,
-                                                           float* __restrict__ ws, int64_t rows, int cols) {
+                                                           float* __restrict__ ws, int64_t rows, int cols, float dy_scale) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
             if (c < nv) {
-                f32x4 d = RowIO<DT>::load(dy + row * cols + c * 4);
+                f32x4 d = RowIO<DT>::load(dy + row * cols + c * 4) * dy_scale;
                 xh[i] = (RowIO<XT>::load(x + row * cols + c * 4) - mu) * rs;
                 g[i] = d * *(const f32x4*)(gamma + c * 4);
                 dg[i] += d * xh[i];
@@ -184,8 +184,8 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
 template <typename T, typename DT, typename XT>
 void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                    const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
-                   int cols) {
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols)
+                   int cols, float dy_scale) {
+#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else LNB(8);
@@ -215,7 +215,7 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
     return MICO_OK;
 }
 
-extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype, const float* gamma,
                                   const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
                                   float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
                                   int cols, int dtype, void* stream) {
@@ -230,10 +230,10 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, const void* x, i
     const dim3 grid(nblk);
     float* wsp = (dgamma || dbeta) ? ws : nullptr;
     DISPATCH_T16(dtype, {
-        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
-        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
-        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
-        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols);
+        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
+        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
+        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
+        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {

@@ -1,0 +1,864 @@
+"""Autograd functions of the MI355X engine: hand-written forward AND backward schedules over libmico_hip.so kernels.
+
+Granularity is one Function per tower (EVA ViT, BERT) plus a few small ones (linear, layer-norm, losses): PyTorch's
+autograd only routes gradients between them and into the fp32 nn.Parameters; every FLOP inside runs in the HIP kernels
+(mico_amd/ops.py).  Residual streams and their gradients are fp32 buffers updated in place by GEMM epilogues; GEMM
+operands are 16-bit (runtime.compute_dtype()).
+"""
+import math
+
+import torch
+
+from . import ops, runtime
+
+
+def _split_k(m_out, n_out, k_red):
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    ktiles = (k_red + 63) // 64
+    s = max(1, min(1024 // max(tiles, 1), ktiles // 8))
+    return s
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None):
+    """dw[N_out, N_in] += inv_s * dy16^T x16   (reduction over the rows)."""
+    n_out = n_out or dw.shape[0]
+    n_in = n_in or dw.shape[1]
+    ops.gemm(dy16, x16, dw, ta=True, tb=True, M=n_out, N=n_in, K=dy16.shape[0], accumulate=True, alpha=inv_s,
+             split_k=_split_k(n_out, n_in, dy16.shape[0]))
+
+
+# ======================================================================================================================
+# EVA ViT tower  (reference: model/evaclip/eva_vit_model.py:611-650 forward_features, :409-416 Block, :293-365 Attention,
+# :190-224 Mlp / SwiGLU, :427-448 PatchEmbed)
+# ======================================================================================================================
+class TowerSpec:
+    def __init__(self, arch, names, grid, rope=None):
+        self.arch = arch
+        self.names = names
+        self.idx = {n: i for i, n in enumerate(names)}
+        self.D = arch["width"]
+        self.H = arch["heads"]
+        self.hd = self.D // self.H
+        self.P = arch["patch"]
+        self.grid = grid
+        self.np = grid * grid
+        self.N = self.np + 1
+        self.hidden = arch["mlp_hidden"]
+        self.eps = 1e-6
+        self.rope = rope   # (cos, sin) fp32 [np, hd] device tensors or None
+        self.kpad3 = (3 * self.P * self.P + 63) // 64 * 64
+        self.kpad1 = (self.P * self.P + 63) // 64 * 64
+
+
+class EvaTowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, groups, dp_scale, *params):
+        dt = runtime.compute_dtype()
+        P = lambda n: params[spec.idx[n]]
+        dev = params[0].device
+        D, N, np_, H, hd = spec.D, spec.N, spec.np, spec.H, spec.hd
+        arch = spec.arch
+        depth = arch["depth_built"]
+        Bf = sum(g.shape[0] for g in groups)
+        M = Bf * N
+        x = _empty((M, D), torch.float32, dev)
+        # ---- patch embedding: im2row + GEMM(+bias +pos, patch rows -> token rows) ; CLS rows ----
+        pe_w, pe_b, pos = P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed")
+        pos2 = pos.detach().reshape(N, D)
+        saved_rows = []
+        f0 = 0
+        for g in groups:
+            C = g.shape[1]
+            kpad = spec.kpad3 if C == 3 else spec.kpad1
+            if C == 3:
+                w16 = runtime.w16(("pe3", id(pe_w)), [pe_w], lambda d: runtime.cast_weight(pe_w, d, k_pad=kpad))
+            else:
+                w16 = runtime.w16(("pe1", id(pe_w)), [pe_w], lambda d: runtime.cast_weight(pe_w.detach().sum(1), d, k_pad=kpad))
+            rows16 = _empty((g.shape[0] * np_, kpad), dt, dev)
+            ops.im2row(g.contiguous().float(), rows16, spec.P, kpad)
+            ops.gemm(rows16, w16, x[f0 * N:], M=g.shape[0] * np_, N=D, K=kpad, bias=pe_b, pos=pos2, pos_rows=N,
+                     remap=(np_, 1, 1))
+            saved_rows.append(rows16)
+            f0 += g.shape[0]
+        ops.cls_rows(x, Bf, N, P("cls_token").detach().reshape(D), pos2[0])
+
+        acts = []
+        strides3 = dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D),
+                        o_strides=(N * D, D))
+        for i in range(depth):
+            b = f"blocks.{i}."
+            a = {}
+            dp1 = dp_scale[i, 0].contiguous() if dp_scale is not None else None
+            dp2 = dp_scale[i, 1].contiguous() if dp_scale is not None else None
+            # --- attention branch ---
+            ln1 = _empty((M, D), dt, dev)
+            mean1, rstd1 = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+            ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, out16=ln1, mean=mean1, rstd=rstd1, dtype=dt)
+            if arch["subln"]:
+                wq, wk, wv = P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")
+                wqkv = runtime.w16(("qkv", id(wq)), [wq, wk, wv],
+                                   lambda d: runtime.cast_weight(torch.cat((wq.detach(), wk.detach(), wv.detach()), 0), d))
+            else:
+                wq = P(b + "attn.qkv.weight")
+                wqkv = runtime.w16(("qkv", id(wq)), [wq], lambda d: runtime.cast_weight(wq, d))
+            qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
+            qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
+            qkv = _empty((M, 3 * D), dt, dev)
+            ops.gemm(ln1, wqkv, qkv, bias=qkv_bias)
+            if spec.rope is not None:
+                ops.rope(qkv, N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1])
+                ops.rope(qkv[:, D:], N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1])
+            ao = _empty((M, D), dt, dev)
+            lse = _empty((Bf, H, N), torch.float32, dev)
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
+            proj_in = ao
+            if arch["subln"]:
+                aln = _empty((M, D), dt, dev)
+                mean_a, rstd_a = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+                ops.layernorm_fwd(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"), spec.eps,
+                                  out16=aln, mean=mean_a, rstd=rstd_a, dtype=dt)
+                a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
+                proj_in = aln
+            wp = P(b + "attn.proj.weight")
+            wp16 = runtime.w16(("w", id(wp)), [wp], lambda d: runtime.cast_weight(wp, d))
+            x_mid = _empty((M, D), torch.float32, dev)
+            ops.gemm(proj_in, wp16, x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=dp1, rows_per_scale=N)
+            # --- MLP branch ---
+            ln2 = _empty((M, D), dt, dev)
+            mean2, rstd2 = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+            ops.layernorm_fwd(x_mid, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, out16=ln2, mean=mean2, rstd=rstd2, dtype=dt)
+            x_out = _empty((M, D), torch.float32, dev)
+            Hd = spec.hidden
+            if arch["swiglu"]:
+                w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
+                w1_16 = runtime.w16(("w", id(w1)), [w1], lambda d: runtime.cast_weight(w1, d))
+                w2_16 = runtime.w16(("w", id(w2)), [w2], lambda d: runtime.cast_weight(w2, d))
+                w3_16 = runtime.w16(("w", id(w3)), [w3], lambda d: runtime.cast_weight(w3, d))
+                x1, x2 = _empty((M, Hd), dt, dev), _empty((M, Hd), dt, dev)
+                ops.gemm(ln2, w1_16, x1, bias=P(b + "mlp.w1.bias"))
+                ops.gemm(ln2, w2_16, x2, bias=P(b + "mlp.w2.bias"))
+                hsw = _empty((M, Hd), dt, dev)
+                ops.swiglu_fwd(x1, x2, hsw)
+                hln = _empty((M, Hd), dt, dev)
+                mean_f, rstd_f = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+                ops.layernorm_fwd(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, out16=hln,
+                                  mean=mean_f, rstd=rstd_f, dtype=dt)
+                ops.gemm(hln, w3_16, x_out, bias=P(b + "mlp.w3.bias"), resid=x_mid, row_scale=dp2, rows_per_scale=N)
+                a.update(x1=x1, x2=x2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
+            else:
+                w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+                w1_16 = runtime.w16(("w", id(w1)), [w1], lambda d: runtime.cast_weight(w1, d))
+                w2_16 = runtime.w16(("w", id(w2)), [w2], lambda d: runtime.cast_weight(w2, d))
+                h = _empty((M, Hd), dt, dev)
+                act = _empty((M, Hd), dt, dev)
+                ops.gemm(ln2, w1_16, act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
+                ops.gemm(act, w2_16, x_out, bias=P(b + "mlp.fc2.bias"), resid=x_mid, row_scale=dp2, rows_per_scale=N)
+                a.update(h=h, act=act)
+            a.update(x_in=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, mean2=mean2,
+                     rstd2=rstd2, ln2=ln2, dp1=dp1, dp2=dp2)
+            acts.append(a)
+            x = x_out
+        out = _empty((M, D), torch.float32, dev)
+        mean_n, rstd_n = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+        ops.layernorm_fwd(x, P("norm.weight"), P("norm.bias"), spec.eps, out32=out, mean=mean_n, rstd=rstd_n, dtype=dt)
+        ctx.spec, ctx.params, ctx.acts, ctx.dt = spec, params, acts, dt
+        ctx.final = (x, mean_n, rstd_n)
+        ctx.groups_meta = [(g.shape[0], g.shape[1]) for g in groups]
+        ctx.saved_rows = saved_rows
+        ctx.Bf = Bf
+        return out.view(Bf, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        spec, params, dt = ctx.spec, ctx.params, ctx.dt
+        P = lambda n: params[spec.idx[n]]
+        dev = dout.device
+        D, N, np_, H, hd, Bf = spec.D, spec.N, spec.np, spec.H, spec.hd, ctx.Bf
+        arch = spec.arch
+        M = Bf * N
+        S = runtime.grad_scale()
+        inv_s = 1.0 / S
+        grads = [None] * len(params)
+
+        def G(name, like=None):
+            i = spec.idx[name]
+            if grads[i] is None:
+                grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
+            return grads[i]
+
+        def w16_of(p):
+            return runtime.w16(("w", id(p)), [p], lambda d: runtime.cast_weight(p, d))
+
+        strides3 = dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D),
+                        o_strides=(N * D, D))
+        x_last, mean_n, rstd_n = ctx.final
+        g = _empty((M, D), torch.float32, dev)   # running gradient of the fp32 residual stream (updated in place)
+        ops.layernorm_bwd(dout.contiguous().view(M, D), x_last, P("norm.weight"), mean_n, rstd_n, dx32=g,
+                          dgamma=G("norm.weight"), dbeta=G("norm.bias"), dtype=dt)
+        ctx.final = None
+        Hd = spec.hidden
+        for i in reversed(range(arch["depth_built"])):
+            b = f"blocks.{i}."
+            a = ctx.acts.pop()
+            # ---------------- MLP branch ----------------
+            g16 = _empty((M, D), dt, dev)
+            ops.gather_rows_cast(g, g16, row_scale=a["dp2"], rows_per_scale=N, scale=S)
+            dln2 = _empty((M, D), torch.float32, dev)
+            if arch["swiglu"]:
+                w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
+                linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
+                ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
+                dhln = _empty((M, Hd), dt, dev)
+                ops.gemm(g16, w16_of(w3), dhln, tb=True, M=M, N=Hd, K=D)
+                dhsw = _empty((M, Hd), dt, dev)
+                ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
+                                  dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
+                dx1, dx2 = dhln, _empty((M, Hd), dt, dev)   # reuse dhln storage for dx1
+                ops.swiglu_bwd(a["x1"], a["x2"], dhsw, dx1, dx2)
+                linear_wgrad(dx1, a["ln2"], G(b + "mlp.w1.weight"), inv_s)
+                linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
+                ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
+                ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
+                ops.gemm(dx1, w16_of(w1), dln2, tb=True, M=M, N=D, K=Hd)
+                ops.gemm(dx2, w16_of(w2), dln2, tb=True, M=M, N=D, K=Hd, accumulate=True)
+                del dhln, dhsw, dx1, dx2
+            else:
+                w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+                linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
+                ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
+                dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
+                ops.gemm(g16, w16_of(w2), dh, tb=True, M=M, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
+                linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
+                ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
+                ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M, N=D, K=Hd)
+                del dh
+            ops.layernorm_bwd(dln2, a["x_mid"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
+                              dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt)
+            # ---------------- attention branch ----------------
+            ops.gather_rows_cast(g, g16, row_scale=a["dp1"], rows_per_scale=N, scale=S)
+            wp = P(b + "attn.proj.weight")
+            proj_in = a["aln"] if arch["subln"] else a["ao"]
+            linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
+            ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
+            dao = _empty((M, D), dt, dev)
+            ops.gemm(g16, w16_of(wp), dao, tb=True, M=M, N=D, K=D)
+            if arch["subln"]:
+                dao2 = _empty((M, D), dt, dev)
+                ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,
+                                  dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
+                                  grad_scale=inv_s, dtype=dt)
+                dao = dao2
+            qkv = a["qkv"]
+            dqkv = _empty((M, 3 * D), dt, dev)
+            delta = _empty((Bf, H, N), torch.float32, dev)
+            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["ao"], dao, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
+                         B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
+            if spec.rope is not None:
+                ops.rope(dqkv, N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
+                ops.rope(dqkv[:, D:], N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
+            dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+            ops.colsum(dqkv, dbias, scale=inv_s)
+            G(b + "attn.q_bias").add_(dbias[:D])
+            G(b + "attn.v_bias").add_(dbias[2 * D:])
+            if arch["subln"]:
+                wq, wk, wv = P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")
+                wqkv = runtime.w16(("qkv", id(wq)), [wq, wk, wv], None)
+                dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
+                linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
+                G(b + "attn.q_proj.weight").add_(dwf[:D])
+                G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
+                G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
+            else:
+                wq = P(b + "attn.qkv.weight")
+                wqkv = runtime.w16(("qkv", id(wq)), [wq], None)
+                linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
+            dln1 = dln2
+            ops.gemm(dqkv, wqkv, dln1, tb=True, M=M, N=D, K=3 * D)
+            ops.layernorm_bwd(dln1, a["x_in"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
+                              dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt)
+            del a, dqkv, dao, dln1, dln2, g16
+        # ---------------- patch embedding ----------------
+        dpos = torch.zeros(N * D, dtype=torch.float32, device=dev)
+        ops.colsum(g, dpos, rows=Bf, cols=N * D, ld=N * D)
+        G("pos_embed").add_(dpos.view(1, N, D))
+        G("cls_token").add_(dpos[:D].view(1, 1, D))
+        pe_w = P("patch_embed.proj.weight")
+        PP = spec.P * spec.P
+        f0 = 0
+        for (nf, C), rows16 in zip(ctx.groups_meta, ctx.saved_rows):
+            gp16 = _empty((nf * np_, D), dt, dev)
+            ops.gather_rows_cast(g[f0 * N:], gp16, remap=(np_, 1, 1), scale=S)
+            kpad = rows16.shape[1]
+            dw = torch.zeros((D, kpad), dtype=torch.float32, device=dev)
+            linear_wgrad(gp16, rows16, dw, inv_s)
+            if C == 3:
+                G("patch_embed.proj.weight").add_(dw[:, :3 * PP].reshape(D, 3, spec.P, spec.P))
+            else:
+                G("patch_embed.proj.weight").add_(dw[:, :PP].reshape(D, 1, spec.P, spec.P))
+            ops.colsum(gp16, G("patch_embed.proj.bias"), scale=inv_s, accumulate=True)
+            f0 += nf
+        ctx.saved_rows = None
+        return (None, None, None) + tuple(grads)
+
+
+# ======================================================================================================================
+# small fp32 functions (heads, pooling, normalisation) - exact fp32 kernels
+# ======================================================================================================================
+class _LinearF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        y = _empty((x2.shape[0], w.shape[0]), torch.float32, x.device)
+        ops.sgemm(x2, w.detach(), y, bias=b.detach() if b is not None else None)
+        ctx.save_for_backward(x2, w)
+        ctx.has_b = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w.shape[0]).contiguous().float()
+        dx = _empty(x2.shape, torch.float32, dy.device)
+        ops.sgemm(dy2, w.detach(), dx, tb=True)                  # dx = dy W
+        dw = _empty(w.shape, torch.float32, dy.device)
+        ops.sgemm(dy2, x2, dw, ta=True, tb=True)                 # dW = dy^T x
+        db = None
+        if ctx.has_b:
+            db = torch.zeros(w.shape[0], dtype=torch.float32, device=dy.device)
+            ops.colsum(dy2, db)
+        return dx.view(ctx.xshape), dw, db
+
+
+def linear_f32(x, w, b=None):
+    return _LinearF32.apply(x, w, b)
+
+
+class _MatmulNT(torch.autograd.Function):
+    """a [m,k] @ b[n,k]^T * alpha (fp32, exact) - similarity matrices (vast.py:405-408)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        y = _empty((a.shape[0], b.shape[0]), torch.float32, a.device)
+        ops.sgemm(a, b, y, alpha=alpha)
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _empty(a.shape, torch.float32, dy.device)
+            ops.sgemm(dy, b, da, tb=True, alpha=ctx.alpha)
+        if ctx.needs_input_grad[1]:
+            db = _empty(b.shape, torch.float32, dy.device)
+            ops.sgemm(dy, a, db, ta=True, tb=True, alpha=ctx.alpha)
+        return da, db, None
+
+
+def matmul_nt(a, b, alpha=1.0):
+    return _MatmulNT.apply(a, b, alpha)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        inv = _empty((x.shape[0],), torch.float32, x.device)
+        ops.l2norm_fwd(x, y, inv)
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        ops.l2norm_bwd(dy.contiguous(), y, inv, dx)
+        return dx
+
+
+def l2_normalize(x):
+    """F.normalize(x, dim=-1) (vast.py:245,253 ...)."""
+    return _L2Norm.apply(x)
+
+
+class _GeluF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        ops.gelu_f32(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        ops.gelu_bwd_f32(x, dy.contiguous(), dx)
+        return dx
+
+
+def gelu_f32(x):
+    return _GeluF32.apply(x)
+
+
+class _LayerNormF32(torch.autograd.Function):
+    """fp32 in / fp32 out LayerNorm for small tensors (Match_head, mico.py:49)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean, rstd = _empty((rows,), torch.float32, x.device), _empty((rows,), torch.float32, x.device)
+        ops.layernorm_fwd(x2, g.detach(), b.detach(), eps, out32=y, mean=mean, rstd=rstd, dtype=runtime.compute_dtype())
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.xshape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(x2.shape).contiguous().float()
+        dx = torch.empty_like(x2)
+        dg, db = torch.zeros_like(g, dtype=torch.float32), torch.zeros_like(g, dtype=torch.float32)
+        ops.layernorm_bwd(dy2, x2, g.detach(), mean, rstd, dx32=dx, dgamma=dg, dbeta=db, dtype=runtime.compute_dtype())
+        return dx.view(ctx.xshape), dg, db, None
+
+
+def layer_norm_f32(x, g, b, eps):
+    return _LayerNormF32.apply(x, g, b, eps)
+
+
+class _ClsPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens):   # [b, n, N, D] fp32
+        b, n, N, D = tokens.shape
+        tokens = tokens.contiguous()
+        out = _empty((b, D), torch.float32, tokens.device)
+        ops.cls_pool_fwd(tokens, out, b, n, N * D, D)
+        ctx.shape = (b, n, N, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, n, N, D = ctx.shape
+        dt = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
+        ops.cls_pool_bwd(dy.contiguous(), dt, b, n, N * D, D)
+        return dt
+
+
+def cls_pool(tokens):
+    """feature[:, :, 0].mean(1)  (mico.py:157-182)."""
+    return _ClsPool.apply(tokens)
+
+
+# ======================================================================================================================
+# condition packing: Linear(Dv -> 768) + LN(1e-12) + frame embedding + type embedding   (mico.py:187-243, 400-403)
+# ======================================================================================================================
+class _CondPack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, w, b, g, beta, table, rows_per_group):
+        """feats [rows, Dv] fp32; table [groups, 768] fp32 (frame + type embedding per frame slot);
+        output row r gets table[(r // rows_per_group) % groups]."""
+        dt = runtime.compute_dtype()
+        dev = feats.device
+        rows, Dv = feats.shape
+        Dm = w.shape[0]
+        x16 = _empty((rows, Dv), dt, dev)
+        ops.cast_f32_to_16(feats.contiguous(), x16)
+        w16 = runtime.w16(("w", id(w)), [w], lambda d: runtime.cast_weight(w, d))
+        u = _empty((rows, Dm), torch.float32, dev)
+        ops.gemm(x16, w16, u, bias=b.detach())
+        y = _empty((rows, Dm), torch.float32, dev)
+        mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+        ops.layernorm_fwd(u, g.detach(), beta.detach(), 1e-12, out32=y, mean=mean, rstd=rstd, post_add=table.detach().contiguous(),
+                          post_rows_per_group=rows_per_group, post_groups=table.shape[0], dtype=dt)
+        ctx.save_for_backward(x16, u, mean, rstd, w, g)
+        ctx.meta = (rows_per_group, table.shape[0], dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, u, mean, rstd, w, g = ctx.saved_tensors
+        rpg, groups, dt = ctx.meta
+        dev = dy.device
+        rows, Dm = u.shape
+        S = runtime.grad_scale()
+        inv_s = 1.0 / S
+        dy = dy.contiguous()
+        du16 = _empty((rows, Dm), dt, dev)
+        dg, dbeta = torch.zeros_like(g, dtype=torch.float32), torch.zeros_like(g, dtype=torch.float32)
+        ops.layernorm_bwd(dy, u, g.detach(), mean, rstd, dx16=du16, scale16=S, dgamma=dg, dbeta=dbeta, dtype=dt)
+        dw = torch.zeros(w.shape, dtype=torch.float32, device=dev)
+        linear_wgrad(du16, x16, dw, inv_s)
+        db = torch.zeros(Dm, dtype=torch.float32, device=dev)
+        ops.colsum(du16, db, scale=inv_s)
+        w16 = runtime.w16(("w", id(w)), [w], lambda d: runtime.cast_weight(w, d))
+        dx = _empty((rows, x16.shape[1]), torch.float32, dev)
+        ops.gemm(du16, w16, dx, tb=True, M=rows, N=x16.shape[1], K=Dm, alpha=inv_s)
+        # table gradient: rows are ordered (sample, frame slot, token): sum over samples, then over the tokens of a slot
+        per = rpg * groups
+        nb = rows // per
+        tmp = torch.zeros(per * Dm, dtype=torch.float32, device=dev)
+        ops.colsum(dy, tmp, rows=nb, cols=per * Dm, ld=per * Dm)
+        dtable = torch.zeros((groups, Dm), dtype=torch.float32, device=dev)
+        for f in range(groups):
+            ops.colsum(tmp[f * rpg * Dm:], dtable[f], rows=rpg, cols=Dm, ld=Dm)
+        return dx, dw, db, dg, dbeta, dtable, None
+
+
+def cond_pack(feats, w, b, g, beta, table, rows_per_group):
+    return _CondPack.apply(feats, w, b, g, beta, table, rows_per_group)
+
+
+# ======================================================================================================================
+# BERT with cross-attention (reference: model/bert.py:785-916 BertModel.forward, :393-461 BertLayer, :184-297 attention,
+# :349-375 FFN, :101-149 embeddings).  Dropout is not applied (eval semantics).
+# ======================================================================================================================
+class BertSpec:
+    def __init__(self, names, n_layers, heads=12, hidden=768, inter=3072, eps=1e-12):
+        self.names = names
+        self.idx = {n: i for i, n in enumerate(names)}
+        self.L, self.H, self.D, self.I, self.eps = n_layers, heads, hidden, inter, eps
+
+
+def _fused_w(key, plist, dt_unused=None):
+    return runtime.w16((key, id(plist[0])), plist,
+                       lambda d: runtime.cast_weight(torch.cat([p.detach() for p in plist], 0), d))
+
+
+class BertFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, input_ids, add_mask, cond, *params):
+        dt = runtime.compute_dtype()
+        P = lambda n: params[spec.idx[n]]
+        dev = input_ids.device
+        b, S = input_ids.shape
+        D, H, I = spec.D, spec.H, spec.I
+        hd = D // H
+        rows = b * S
+        ids = input_ids.contiguous()
+        emb = _empty((rows, D), torch.float32, dev)
+        ops.bert_embed_fwd(ids, P("embeddings.word_embeddings.weight").detach(), P("embeddings.position_embeddings.weight").detach(),
+                           P("embeddings.token_type_embeddings.weight").detach()[0].contiguous(), emb, S)
+        x32, x16 = _empty((rows, D), torch.float32, dev), _empty((rows, D), dt, dev)
+        mean_e, rstd_e = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+        ops.layernorm_fwd(emb, P("embeddings.LayerNorm.weight"), P("embeddings.LayerNorm.bias"), spec.eps, out16=x16, out32=x32,
+                          mean=mean_e, rstd=rstd_e, dtype=dt)
+        cond16 = None
+        E = 0
+        if cond is not None:
+            E = cond.shape[1]
+            cond16 = _empty((b * E, D), dt, dev)
+            ops.cast_f32_to_16(cond.contiguous().view(b * E, D), cond16)
+        mask = add_mask.contiguous() if add_mask is not None else None
+        scale = 1.0 / math.sqrt(hd)
+        acts = []
+
+        def ln_out(u, pre):
+            o32, o16 = _empty((rows, D), torch.float32, dev), _empty((rows, D), dt, dev)
+            m_, r_ = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+            ops.layernorm_fwd(u, P(pre + "LayerNorm.weight"), P(pre + "LayerNorm.bias"), spec.eps, out16=o16, out32=o32, mean=m_, rstd=r_, dtype=dt)
+            return o32, o16, m_, r_
+
+        for li in range(spec.L):
+            p = f"encoder.layer.{li}."
+            a = dict(x16=x16)
+            sa = p + "attention.self."
+            wqkv = _fused_w("bqkv", [P(sa + "query.weight"), P(sa + "key.weight"), P(sa + "value.weight")])
+            bqkv = torch.cat((P(sa + "query.bias").detach(), P(sa + "key.bias").detach(), P(sa + "value.bias").detach()))
+            qkv = _empty((rows, 3 * D), dt, dev)
+            ops.gemm(x16, wqkv, qkv, bias=bqkv)
+            co = _empty((rows, D), dt, dev)
+            lse = _empty((b, H, S), torch.float32, dev)
+            st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], co, lse, B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, **st)
+            wo = P(p + "attention.output.dense.weight")
+            u = _empty((rows, D), torch.float32, dev)
+            ops.gemm(co, _fused_w("w1", [wo]), u, bias=P(p + "attention.output.dense.bias"), resid=x32)
+            x32, x16, m1, r1 = ln_out(u, p + "attention.output.")
+            a.update(qkv=qkv, co=co, lse=lse, u=u, m1=m1, r1=r1)
+            if cond16 is not None:
+                ca = p + "crossattention.self."
+                a["x16a"] = x16
+                q = _empty((rows, D), dt, dev)
+                ops.gemm(x16, _fused_w("w1", [P(ca + "query.weight")]), q, bias=P(ca + "query.bias"))
+                wkv = _fused_w("bkv", [P(ca + "key.weight"), P(ca + "value.weight")])
+                bkv = torch.cat((P(ca + "key.bias").detach(), P(ca + "value.bias").detach()))
+                kv = _empty((b * E, 2 * D), dt, dev)
+                ops.gemm(cond16, wkv, kv, bias=bkv)
+                cc = _empty((rows, D), dt, dev)
+                lse_c = _empty((b, H, S), torch.float32, dev)
+                stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
+                ops.attn_fwd(q, kv, kv[:, D:], cc, lse_c, B=b, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None, **stc)
+                u2 = _empty((rows, D), torch.float32, dev)
+                ops.gemm(cc, _fused_w("w1", [P(p + "crossattention.output.dense.weight")]), u2,
+                         bias=P(p + "crossattention.output.dense.bias"), resid=x32)
+                x32, x16, m2, r2 = ln_out(u2, p + "crossattention.output.")
+                a.update(q=q, kv=kv, cc=cc, lse_c=lse_c, u2=u2, m2=m2, r2=r2)
+            a["x16b"] = x16
+            h = _empty((rows, I), dt, dev)
+            act = _empty((rows, I), dt, dev)
+            ops.gemm(x16, _fused_w("w1", [P(p + "intermediate.dense.weight")]), act, bias=P(p + "intermediate.dense.bias"),
+                     aux_out=h, act=ops.ACT_GELU)
+            u3 = _empty((rows, D), torch.float32, dev)
+            ops.gemm(act, _fused_w("w1", [P(p + "output.dense.weight")]), u3, bias=P(p + "output.dense.bias"), resid=x32)
+            x32, x16, m3, r3 = ln_out(u3, p + "output.")
+            a.update(h=h, act=act, u3=u3, m3=m3, r3=r3)
+            acts.append(a)
+        ctx.spec, ctx.params, ctx.acts, ctx.dt = spec, params, acts, dt
+        ctx.misc = (ids, emb, mean_e, rstd_e, cond16, mask, b, S, E)
+        ctx.cond_needs_grad = cond is not None and cond.requires_grad
+        return x32.view(b, S, D)
+
+    @staticmethod
+    def backward(ctx, dseq):
+        spec, params, dt = ctx.spec, ctx.params, ctx.dt
+        P = lambda n: params[spec.idx[n]]
+        ids, emb, mean_e, rstd_e, cond16, mask, b, S, E = ctx.misc
+        dev = dseq.device
+        D, H, I = spec.D, spec.H, spec.I
+        hd = D // H
+        rows = b * S
+        Sg = runtime.grad_scale()
+        inv_s = 1.0 / Sg
+        scale = 1.0 / math.sqrt(hd)
+        grads = [None] * len(params)
+
+        def G(name):
+            i = spec.idx[name]
+            if grads[i] is None:
+                grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
+            return grads[i]
+
+        g = dseq.contiguous().view(rows, D).float().clone()
+        dcond = torch.zeros((b * E, D), dtype=torch.float32, device=dev) if cond16 is not None else None
+
+        def ln_bwd(gin, u, m_, r_, pre):
+            """d(LN input) fp32 (in place into gin) and its scaled 16-bit copy."""
+            d16 = _empty((rows, D), dt, dev)
+            ops.layernorm_bwd(gin, u, P(pre + "LayerNorm.weight"), m_, r_, dx32=gin, dx16=d16, scale16=Sg,
+                              dgamma=G(pre + "LayerNorm.weight"), dbeta=G(pre + "LayerNorm.bias"), dtype=dt)
+            return d16
+
+        def split_rows(dwf, names):
+            o = 0
+            for n in names:
+                k = params[spec.idx[n]].shape[0]
+                G(n).add_(dwf[o:o + k])
+                o += k
+
+        for li in reversed(range(spec.L)):
+            p = f"encoder.layer.{li}."
+            a = ctx.acts.pop()
+            # ---- FFN ----
+            d16 = ln_bwd(g, a["u3"], a["m3"], a["r3"], p + "output.")          # g := dL/du3 (= dL/d(resid x32b) too)
+            linear_wgrad(d16, a["act"], G(p + "output.dense.weight"), inv_s)
+            ops.colsum(d16, G(p + "output.dense.bias"), scale=inv_s, accumulate=True)
+            dh = a["act"]
+            ops.gemm(d16, _fused_w("w1", [P(p + "output.dense.weight")]), dh, tb=True, M=rows, N=I, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
+            linear_wgrad(dh, a["x16b"], G(p + "intermediate.dense.weight"), inv_s)
+            ops.colsum(dh, G(p + "intermediate.dense.bias"), scale=inv_s, accumulate=True)
+            ops.gemm(dh, _fused_w("w1", [P(p + "intermediate.dense.weight")]), g, tb=True, M=rows, N=D, K=I, alpha=inv_s, resid=g)
+            # ---- cross attention ----
+            if cond16 is not None:
+                ca = p + "crossattention.self."
+                d16 = ln_bwd(g, a["u2"], a["m2"], a["r2"], p + "crossattention.output.")
+                linear_wgrad(d16, a["cc"], G(p + "crossattention.output.dense.weight"), inv_s)
+                ops.colsum(d16, G(p + "crossattention.output.dense.bias"), scale=inv_s, accumulate=True)
+                dcc = _empty((rows, D), dt, dev)
+                ops.gemm(d16, _fused_w("w1", [P(p + "crossattention.output.dense.weight")]), dcc, tb=True, M=rows, N=D, K=D)
+                dq = _empty((rows, D), dt, dev)
+                dkv = _empty((b * E, 2 * D), dt, dev)
+                delta = _empty((b, H, S), torch.float32, dev)
+                stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
+                kv = a["kv"]
+                ops.attn_bwd(a["q"], kv, kv[:, D:], a["cc"], dcc, a["lse_c"], dq, dkv, dkv[:, D:], delta, B=b, H=H, Sq=S, Sk=E,
+                             hd=hd, scale=scale, mask=None, **stc)
+                linear_wgrad(dq, a["x16a"], G(ca + "query.weight"), inv_s)
+                ops.colsum(dq, G(ca + "query.bias"), scale=inv_s, accumulate=True)
+                dwkv = torch.zeros((2 * D, D), dtype=torch.float32, device=dev)
+                linear_wgrad(dkv, cond16, dwkv, inv_s)
+                split_rows(dwkv, [ca + "key.weight", ca + "value.weight"])
+                dbkv = torch.zeros(2 * D, dtype=torch.float32, device=dev)
+                ops.colsum(dkv, dbkv, scale=inv_s)
+                split_rows(dbkv, [ca + "key.bias", ca + "value.bias"])
+                if ctx.cond_needs_grad:
+                    wkv = _fused_w("bkv", [P(ca + "key.weight"), P(ca + "value.weight")])
+                    ops.gemm(dkv, wkv, dcond, tb=True, M=b * E, N=D, K=2 * D, alpha=inv_s, accumulate=True)
+                ops.gemm(dq, _fused_w("w1", [P(ca + "query.weight")]), g, tb=True, M=rows, N=D, K=D, alpha=inv_s, resid=g)
+                del dq, dkv, dcc
+            # ---- self attention ----
+            sa = p + "attention.self."
+            d16 = ln_bwd(g, a["u"], a["m1"], a["r1"], p + "attention.output.")
+            linear_wgrad(d16, a["co"], G(p + "attention.output.dense.weight"), inv_s)
+            ops.colsum(d16, G(p + "attention.output.dense.bias"), scale=inv_s, accumulate=True)
+            dco = _empty((rows, D), dt, dev)
+            ops.gemm(d16, _fused_w("w1", [P(p + "attention.output.dense.weight")]), dco, tb=True, M=rows, N=D, K=D)
+            qkv = a["qkv"]
+            dqkv = _empty((rows, 3 * D), dt, dev)
+            delta = _empty((b, H, S), torch.float32, dev)
+            st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
+            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["co"], dco, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
+                         B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, **st)
+            dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
+            linear_wgrad(dqkv, a["x16"], dwf, inv_s)
+            split_rows(dwf, [sa + "query.weight", sa + "key.weight", sa + "value.weight"])
+            dbf = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+            ops.colsum(dqkv, dbf, scale=inv_s)
+            split_rows(dbf, [sa + "query.bias", sa + "key.bias", sa + "value.bias"])
+            wqkv = _fused_w("bqkv", [P(sa + "query.weight"), P(sa + "key.weight"), P(sa + "value.weight")])
+            ops.gemm(dqkv, wqkv, g, tb=True, M=rows, N=D, K=3 * D, alpha=inv_s, resid=g)
+            del a, dqkv, dco, d16
+        # ---- embeddings ----
+        ops.layernorm_bwd(g, emb, P("embeddings.LayerNorm.weight"), mean_e, rstd_e, dx32=g,
+                          dgamma=G("embeddings.LayerNorm.weight"), dbeta=G("embeddings.LayerNorm.bias"), dtype=dt)
+        dtype0 = torch.zeros(D, dtype=torch.float32, device=dev)
+        ops.embed_scatter_add(ids, g, G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"), dtype0, S)
+        G("embeddings.token_type_embeddings.weight")[0].add_(dtype0)
+        dc = dcond.view(b, E, D) if (dcond is not None and ctx.cond_needs_grad) else None
+        return (None, None, None, dc) + tuple(grads)
+
+
+# ======================================================================================================================
+# LM head + masked-token cross entropy (bert.py:575-609, 1085-1090): dense+GELU+LN -> tied decoder GEMM -> CE, fused so
+# that fp32 logits never exist; only labelled rows are pushed through the 768 x 30522 GEMM (identical result: ignored
+# rows contribute neither loss nor gradient).
+# ======================================================================================================================
+VOCAB_PAD = 64
+
+
+class LMHeadLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seq, labels, wt, bt, g, beta, wdec, bdec):
+        dt = runtime.compute_dtype()
+        dev = seq.device
+        D = seq.shape[-1]
+        x = seq.reshape(-1, D).contiguous().float()
+        lab = labels.reshape(-1).contiguous()
+        rows = x.shape[0]
+        V = wdec.shape[0]
+        Vp = (V + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD
+        x16 = _empty((rows, D), dt, dev)
+        ops.cast_f32_to_16(x, x16)
+        pre = _empty((rows, D), dt, dev)
+        act = _empty((rows, D), dt, dev)
+        ops.gemm(x16, _fused_w("w1", [wt]), act, bias=bt.detach(), aux_out=pre, act=ops.ACT_GELU)
+        hl = _empty((rows, D), dt, dev)
+        mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+        ops.layernorm_fwd(act, g.detach(), beta.detach(), 1e-12, out16=hl, mean=mean, rstd=rstd, dtype=dt)
+        wd16 = runtime.w16(("wdec", id(wdec)), [wdec], lambda d: runtime.cast_weight(wdec, d, n_pad=Vp))
+        bpad = torch.zeros(Vp, dtype=torch.float32, device=dev)
+        bpad[:V] = bdec.detach()
+        logits = _empty((rows, Vp), dt, dev)
+        ops.gemm(hl, wd16, logits, bias=bpad)
+        row_loss = _empty((rows,), torch.float32, dev)
+        ops.ce_fwd_bwd(logits, lab, cols=V, row_loss=row_loss)
+        n_valid = (lab != -100).sum().clamp_min(1).float()
+        loss = row_loss.sum() / n_valid
+        ctx.save_for_backward(x16, pre, act, hl, mean, rstd, logits, lab, n_valid, wt, g, wdec)
+        ctx.meta = (dt, V, Vp, seq.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        x16, pre, act, hl, mean, rstd, logits, lab, n_valid, wt, g, wdec = ctx.saved_tensors
+        dt, V, Vp, seq_shape = ctx.meta
+        dev = gout.device
+        rows, D = x16.shape
+        S = runtime.grad_scale()
+        inv_s = 1.0 / S
+        dsc = (gout.float() * S / n_valid).reshape(1).contiguous()
+        dlog = logits   # overwrite the logits with their gradient (same dtype / shape)
+        if Vp != V:
+            dlog[:, V:].zero_()
+        ops.ce_fwd_bwd(logits, lab, cols=V, dlogits=dlog, dscale_ptr=dsc)
+        dwdec = torch.zeros(wdec.shape, dtype=torch.float32, device=dev)
+        linear_wgrad(dlog, hl, dwdec, inv_s, n_out=V, n_in=D)
+        dbdec = torch.zeros(V, dtype=torch.float32, device=dev)
+        ops.colsum(dlog, dbdec, cols=V, scale=inv_s)
+        wd16 = runtime.w16(("wdec", id(wdec)), [wdec], lambda d: runtime.cast_weight(wdec, d, n_pad=Vp))
+        dhl = _empty((rows, D), dt, dev)
+        ops.gemm(dlog, wd16, dhl, tb=True, M=rows, N=D, K=Vp)
+        dact = _empty((rows, D), dt, dev)
+        dg, dbeta = torch.zeros_like(g, dtype=torch.float32), torch.zeros_like(g, dtype=torch.float32)
+        ops.layernorm_bwd(dhl, act, g.detach(), mean, rstd, dx16=dact, dgamma=dg, dbeta=dbeta, grad_scale=inv_s, dtype=dt)
+        dpre = dhl
+        ops.gelu_bwd_16(pre, dact, dpre)
+        dwt = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
+        linear_wgrad(dpre, x16, dwt, inv_s)
+        dbt = torch.zeros(D, dtype=torch.float32, device=dev)
+        ops.colsum(dpre, dbt, scale=inv_s)
+        dx = _empty((rows, D), torch.float32, dev)
+        ops.gemm(dpre, _fused_w("w1", [wt]), dx, tb=True, M=rows, N=D, K=D, alpha=inv_s)
+        return dx.view(seq_shape), None, dwt, dbt, dg, dbeta, dwdec, dbdec
+
+
+class LMLogitsFn(torch.autograd.Function):
+    """Inference-only LM logits (bert.py:1085): fp32 [rows, V] out; no backward (training uses LMHeadLossFn)."""
+
+    @staticmethod
+    def forward(ctx, seq, wt, bt, g, beta, wdec, bdec):
+        dt = runtime.compute_dtype()
+        dev = seq.device
+        D = seq.shape[-1]
+        x = seq.reshape(-1, D).contiguous().float()
+        rows = x.shape[0]
+        V = wdec.shape[0]
+        Vp = (V + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD
+        x16 = _empty((rows, D), dt, dev)
+        ops.cast_f32_to_16(x, x16)
+        act = _empty((rows, D), dt, dev)
+        ops.gemm(x16, _fused_w("w1", [wt]), act, bias=bt.detach(), act=ops.ACT_GELU)
+        hl = _empty((rows, D), dt, dev)
+        ops.layernorm_fwd(act, g.detach(), beta.detach(), 1e-12, out16=hl, dtype=dt)
+        wd16 = runtime.w16(("wdec", id(wdec)), [wdec], lambda d: runtime.cast_weight(wdec, d, n_pad=Vp))
+        bpad = torch.zeros(Vp, dtype=torch.float32, device=dev)
+        bpad[:V] = bdec.detach()
+        logits = _empty((rows, Vp), torch.float32, dev)
+        ops.gemm(hl, wd16, logits, bias=bpad)
+        ctx.mark_non_differentiable(logits)
+        return logits[:, :V].reshape(*seq.shape[:-1], V)
+
+    @staticmethod
+    def backward(ctx, *a):
+        raise RuntimeError("LMLogitsFn is inference-only; use labels=... to train the captioning head")
+
+
+# ======================================================================================================================
+# cross entropy over small fp32 logits (ITC with label smoothing, ITM)  - vast.py:411-415, 455
+# ======================================================================================================================
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, label_smoothing):
+        logits = logits.contiguous().float()
+        rows = logits.shape[0]
+        row_loss = _empty((rows,), torch.float32, logits.device)
+        ops.ce_fwd_bwd(logits, target.contiguous(), label_smoothing=label_smoothing, row_loss=row_loss)
+        n_valid = (target != -100).sum().clamp_min(1).float()
+        ctx.save_for_backward(logits, target, n_valid)
+        ctx.ls = label_smoothing
+        return row_loss.sum() / n_valid
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, n_valid = ctx.saved_tensors
+        d = torch.empty_like(logits)
+        dsc = (gout.float() / n_valid).reshape(1).contiguous()
+        ops.ce_fwd_bwd(logits, target.contiguous(), label_smoothing=ctx.ls, dlogits=d, dscale_ptr=dsc)
+        return d, None, None
+
+
+def cross_entropy(logits, target, label_smoothing=0.0):
+    return CrossEntropyFn.apply(logits, target, label_smoothing)

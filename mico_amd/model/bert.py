@@ -1,0 +1,216 @@
+"""Host-side mirror of the reference's BERT-with-cross-attention text head (model/bert.py:81-1108): same module tree and
+parameter names (`bert.embeddings.*`, `bert.encoder.layer.N.*`, `cls.predictions.*`), same call surface
+(BertForMaskedLM(input_ids, attention_mask[2-D|3-D], encoder_hidden_states, labels) -> obj with .loss / .logits /
+.sequence_output), arithmetic in mico_amd.functional.BertFn / LMHeadLossFn on libmico_hip.so.
+
+BERT_CONFIG restates model/bert-base-uncased-crossattn/config.json (shape contract).
+"""
+import os
+
+import torch
+from torch import nn
+
+from .. import functional as Fn
+
+BERT_CONFIG = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                   max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, pad_token_id=0,
+                   hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, add_cross_attention=True, is_decoder=True)
+
+TOKENIZER_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tokenizer")
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c["vocab_size"], c["hidden_size"], padding_idx=c["pad_token_id"])
+        self.position_embeddings = nn.Embedding(c["max_position_embeddings"], c["hidden_size"])
+        self.token_type_embeddings = nn.Embedding(c["type_vocab_size"], c["hidden_size"])
+        self.LayerNorm = nn.LayerNorm(c["hidden_size"], eps=c["layer_norm_eps"])
+        self.register_buffer("position_ids", torch.arange(c["max_position_embeddings"]).expand((1, -1)))
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        h = c["hidden_size"]
+        self.query, self.key, self.value = nn.Linear(h, h), nn.Linear(h, h), nn.Linear(h, h)
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, c, in_features=None):
+        super().__init__()
+        self.dense = nn.Linear(in_features or c["hidden_size"], c["hidden_size"])
+        self.LayerNorm = nn.LayerNorm(c["hidden_size"], eps=c["layer_norm_eps"])
+
+
+class _Attention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = _SelfAttention(c)
+        self.output = _SelfOutput(c)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c["hidden_size"], c["intermediate_size"])
+
+
+class _Layer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = _Attention(c)
+        self.crossattention = _Attention(c)
+        self.intermediate = _Intermediate(c)
+        self.output = _SelfOutput(c, c["intermediate_size"])
+
+
+class _Encoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(c) for _ in range(c["num_hidden_layers"])])
+
+
+class _Out(dict):
+    """attr-dict like the reference's easydict return value (bert.py:1093-1097)."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def extended_attention_mask(attention_mask):
+    """bert.py:697-781: 2-D [b,S] key mask or 3-D [b,S,S] -> additive fp32 (1 - m) * -10000 (no automatic causal mask)."""
+    if attention_mask.dim() not in (2, 3):
+        raise ValueError(f"Wrong shape for attention_mask (shape {tuple(attention_mask.shape)})")
+    return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
+
+
+class BertModel(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.config = c
+        self.embeddings = _Embeddings(c)
+        self.encoder = _Encoder(c)
+        self._spec = None
+
+    def _bert_spec(self):
+        named = list(self.named_parameters())
+        names = [n for n, _ in named]
+        if self._spec is None or self._spec.names != names:
+            self._spec = Fn.BertSpec(names, len(self.encoder.layer), self.config["num_attention_heads"],
+                                     self.config["hidden_size"], self.config["intermediate_size"], self.config["layer_norm_eps"])
+        return self._spec, [p for _, p in named]
+
+    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, **_):
+        if input_ids is None:
+            raise ValueError("You have to specify input_ids")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        spec, params = self._bert_spec()
+        seq = Fn.BertFn.apply(spec, input_ids, extended_attention_mask(attention_mask), encoder_hidden_states, *params)
+        return _Out(last_hidden_state=seq)
+
+
+class _Transform(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c["hidden_size"], c["hidden_size"])
+        self.LayerNorm = nn.LayerNorm(c["hidden_size"], eps=c["layer_norm_eps"])
+
+
+class _Predictions(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.transform = _Transform(c)
+        self.decoder = nn.Linear(c["hidden_size"], c["vocab_size"], bias=False)
+        self.bias = nn.Parameter(torch.zeros(c["vocab_size"]))
+        self.decoder.bias = self.bias   # bert.py:604
+
+
+class _MLMHead(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.predictions = _Predictions(c)
+
+
+class _LazyLogits:
+    def __init__(self, fn):
+        self._fn, self._v = fn, None
+
+    def get(self):
+        if self._v is None:
+            self._v = self._fn()
+        return self._v
+
+
+class _MLMOut(_Out):
+    """`.logits` is computed on first access: the reference always evaluates the 768x30522 LM head (bert.py:1085) even when
+    only .sequence_output is consumed; results are identical, the wasted GEMM is not."""
+
+    def __getattr__(self, k):
+        if k == "logits":
+            lazy = dict.get(self, "_lazy_logits")
+            return lazy.get() if lazy is not None else None
+        return dict.get(self, k)
+
+
+class BertForMaskedLM(nn.Module):
+    def __init__(self, config=None):
+        super().__init__()
+        c = dict(BERT_CONFIG)
+        if config:
+            c.update(config)
+        self.config = c
+        self.bert = BertModel(c)
+        self.cls = _MLMHead(c)
+        self._init_weights()
+        # weight tying (transformers==4.31 post_init via get_output_embeddings, bert.py:1038-1041)
+        self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+        self.tokenizer = None
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                m.weight.data.normal_(mean=0.0, std=0.02)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.Embedding):
+                m.weight.data.normal_(mean=0.0, std=0.02)
+                if m.padding_idx is not None:
+                    m.weight.data[m.padding_idx].zero_()
+            elif isinstance(m, nn.LayerNorm):
+                m.bias.data.zero_()
+                m.weight.data.fill_(1.0)
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
+
+    def _head_params(self):
+        pr = self.cls.predictions
+        return (pr.transform.dense.weight, pr.transform.dense.bias, pr.transform.LayerNorm.weight, pr.transform.LayerNorm.bias,
+                pr.decoder.weight, pr.bias)
+
+    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, labels=None, **_):
+        seq = self.bert(input_ids, attention_mask, encoder_hidden_states).last_hidden_state
+        out = _MLMOut(loss=None, sequence_output=seq)
+        hp = self._head_params()
+        if labels is not None:
+            out["loss"] = Fn.LMHeadLossFn.apply(seq, labels, *hp)
+        dict.__setitem__(out, "_lazy_logits", _LazyLogits(lambda: Fn.LMLogitsFn.apply(seq.detach(), *[p.detach() for p in hp])))
+        return out
+
+    def generate(self, *a, **k):
+        raise NotImplementedError("caption decoding (HF beam search, inference_demo.py:161-174) is SURVEY.md section 8 row f1 - not built yet")
+
+
+def build_tokenizer():
+    """BertTokenizer over the bert-base-uncased WordPiece vocabulary, with the special ids the reference sets
+    (mico.py:109-113): bos=[CLS] 101, eos=[SEP] 102, pad=[PAD] 0, mask=[MASK] 103."""
+    from transformers import BertTokenizer
+    tok = BertTokenizer.from_pretrained(TOKENIZER_DIR)   # vocab.txt + tokenizer_config.json (mico.py:109)
+    tok.bos_token_id = tok.convert_tokens_to_ids(["[CLS]"])[0]
+    tok.eos_token_id = tok.convert_tokens_to_ids(["[SEP]"])[0]
+    tok.pad_token_id = tok.convert_tokens_to_ids(["[PAD]"])[0]
+    tok.mask_token_id = tok.convert_tokens_to_ids(["[MASK]"])[0]
+    return tok

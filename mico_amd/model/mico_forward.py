@@ -1,0 +1,167 @@
+"""MiCo.forward(batch, task, compute_loss) - the omni-modal alignment step.
+
+Specification: the VAST sibling's trainer-facing forward (data/model/vast.py:317-348), forward_ret (:383-464: ITC with
+label smoothing 0.1 against the all-gathered global batch, ITM with in-batch hard negatives) and forward_cap (:485-512:
+causal masked-caption LM), generalised with MiCo's depth heads (model/mico.py:390,392,402,406).  These functions become
+methods of mico_amd.model.mico.MiCo.
+
+batch keys: vision_pixels [b,n,3,h,w] | audio_spectrograms [b,n,h,w] | depth_pixels [b,n,3,h,w] (any subset);
+            raw_captions (list[str]) or input_ids/attention_mask [b,S].
+            optional `_injected`: {subtask: {neg_cond_idx, neg_text_idx}, "cap": {masked_ids, labels}} replaces the RNG draws
+            (torch.multinomial / TokenMasker) for parity tests; optional `_world`: simulated gathered tensors.
+"""
+import torch
+
+from .. import distributed as D
+from .. import functional as Fn
+
+COND_MODALITY = {"v": "vision", "a": "audio", "d": "depth"}
+FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "va": "contra_head_va", "vd": "contra_head_id"}
+SUBTASKS = ("tv", "ta", "td", "tva", "tvd")
+
+
+def _tokens(self, batch):
+    if "input_ids" in batch:
+        return batch["input_ids"], batch["attention_mask"]
+    if "caption_tokens" in batch:
+        ct = batch["caption_tokens"]
+        return ct.input_ids, ct.attention_mask
+    dev = self.contra_temp.device
+    tok = self.multimodal_encoder.tokenizer(batch["raw_captions"], padding="max_length", truncation=True,
+                                            max_length=self.max_caption_len, return_tensors="pt")
+    batch["input_ids"], batch["attention_mask"] = tok.input_ids.to(dev), tok.attention_mask.to(dev)
+    return batch["input_ids"], batch["attention_mask"]
+
+
+def encode_batch(self, batch):
+    """batch_get of vast.py:81-314 for every modality present: ONE tower pass over all frames of all modalities (they share
+    the ViT), pooled features, packed condition tensors, text feature."""
+    enc = {}
+    groups, meta = [], []
+    for m, key in (("v", "vision_pixels"), ("a", "audio_spectrograms"), ("d", "depth_pixels")):
+        if key not in batch:
+            continue
+        x = batch[key]
+        b, n = x.shape[:2]
+        g = x.reshape(b * n, 1, *x.shape[-2:]) if m == "a" else x.reshape(b * n, *x.shape[2:])
+        groups.append(g)
+        meta.append((m, b, n))
+    if groups:
+        tokens = self.vision_encoder.visual.forward_groups(groups)
+        f0 = 0
+        for m, b, n in meta:
+            o = tokens[f0:f0 + b * n].view(b, n, *tokens.shape[-2:])
+            f0 += b * n
+            enc["output_" + m] = o
+            enc["pooled_" + m] = Fn.cls_pool(o)
+            enc["condition_feats_" + m] = self._pack(COND_MODALITY[m], o)
+    if "input_ids" in batch or "raw_captions" in batch or "caption_tokens" in batch:
+        ids, am = _tokens(self, batch)
+        seq = self.multimodal_encoder.bert(input_ids=ids, attention_mask=am).last_hidden_state
+        enc["caption_output"] = seq
+        enc["feat_t"] = Fn.l2_normalize(self.contra_head_t(self.pool_text_for_contra(seq)))
+    return enc
+
+
+def _feat_cond(self, enc, cond):
+    pooled = torch.cat([enc["pooled_" + m] for m in cond], dim=1) if len(cond) > 1 else enc["pooled_" + cond]
+    return Fn.l2_normalize(getattr(self, FUSED_HEADS[cond])(pooled))
+
+
+def _condition_feats(self, enc, cond):
+    if len(cond) == 1:
+        return enc["condition_feats_" + cond]
+    return torch.cat([enc["condition_feats_" + m] for m in cond], dim=1)
+
+
+def _forward_ret(self, batch, enc, subtasks):
+    inj = batch.get("_injected", {})
+    world = batch.get("_world")
+    ids, am = _tokens(self, batch)
+    rank = world["rank"] if world else D.rank()
+    bs = ids.shape[0]
+    feat_t = enc["feat_t"]
+    feats = {st: _feat_cond(self, enc, st[1:]) for st in subtasks}
+    if world:
+        feat_t_all, ids_all, mask_all = world["feat_t_all"], world["ids_all"], world["mask_all"]
+        feats_all = {st: world[f"feat_{st[1:]}_all"] for st in subtasks}
+    else:   # ONE packed collective for every small per-step tensor (reference: 3 + len(subtasks) all_gathers)
+        packed = D.packed_all_gather([feat_t, ids, am] + [feats[st] for st in subtasks])
+        feat_t_all, ids_all, mask_all = packed[0], packed[1], packed[2]
+        feats_all = dict(zip(subtasks, packed[3:]))
+    targets = torch.arange(rank * bs, rank * bs + bs, device=ids.device)
+    loss_itc, loss_itm = [], []
+    for st in subtasks:
+        fc, fc_all = feats[st], feats_all[st]
+        sim_c2t = Fn.matmul_nt(fc, feat_t_all) / self.contra_temp                       # vast.py:405-408
+        sim_t2c = Fn.matmul_nt(feat_t, fc_all) / self.contra_temp
+        loss_itc.append((Fn.cross_entropy(sim_c2t, targets, 0.1) + Fn.cross_entropy(sim_t2c, targets, 0.1)) / 2)
+        # ---- ITM hard negatives (vast.py:421-457) ----
+        cond = _condition_feats(self, enc, st[1:])
+        if st in inj:
+            neg_c, neg_t = inj[st]["neg_cond_idx"].to(ids.device), inj[st]["neg_text_idx"].to(ids.device)
+        else:
+            with torch.no_grad():
+                w_t2c = torch.softmax(sim_t2c.detach(), dim=1) + 1e-4
+                w_t2c[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
+                w_c2t = torch.softmax(sim_c2t.detach(), dim=1) + 1e-4
+                w_c2t[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
+                neg_c = torch.multinomial(w_t2c, 1).view(-1)     # one device-side draw per row, no .item() host syncs
+                neg_t = torch.multinomial(w_c2t, 1).view(-1)
+        if world:
+            cond_neg = world[f"cond_{st[1:]}_fetch"](cond, neg_c)
+        else:
+            cond_neg = D.fetch_rows(cond, neg_c)
+        ids1 = torch.cat((ids, ids, ids_all[neg_t]), dim=0)
+        am1 = torch.cat((am, am, mask_all[neg_t]), dim=0)
+        cond3 = torch.cat((cond, cond_neg, cond), dim=0)
+        out = self.multimodal_encoder.bert(input_ids=ids1, attention_mask=am1, encoder_hidden_states=cond3).last_hidden_state
+        logits = self.itm_head(out[:, 0])
+        gt = torch.zeros(bs * 3, dtype=torch.long, device=ids.device)
+        gt[:bs] = 1
+        loss_itm.append(self.itm_ratio * Fn.cross_entropy(logits, gt))
+    return {"loss_itc": sum(loss_itc) / len(loss_itc), "loss_itm": sum(loss_itm) / len(loss_itm)}
+
+
+def _forward_cap(self, batch, enc, subtasks):
+    inj = batch.get("_injected", {})
+    ids, am = _tokens(self, batch)
+    if "cap" in inj:
+        masked_ids, labels = inj["cap"]["masked_ids"].to(ids.device), inj["cap"]["labels"].to(ids.device)
+    else:
+        masked_ids, labels = self.text_masker(ids, 0.6)
+    S = am.shape[1]
+    m3 = torch.tril(am.unsqueeze(1).expand(-1, S, -1)).contiguous()                       # vast.py:497-499
+    losses = []
+    for st in subtasks:
+        cond = _condition_feats(self, enc, st[1:])
+        losses.append(self.multimodal_encoder(input_ids=masked_ids, attention_mask=m3, encoder_hidden_states=cond,
+                                              labels=labels).loss)
+    return {"loss_cap": sum(losses) / len(losses)}
+
+
+def forward(self, batch, task, compute_loss=True):
+    """Returns {"loss_itc", "loss_itm", "loss_cap"} for task strings like "ret%tva%tv_cap%tva" (vast.py:317-348)."""
+    batch = dict(batch) if not isinstance(batch, dict) else batch
+    enc = encode_batch(self, batch)
+    out = {}
+    for t in task.split("_"):
+        subtasks = t.split("%")[1:]
+        for st in subtasks:
+            assert st in SUBTASKS, st
+        if t.startswith("ret"):
+            if compute_loss:
+                out.update(_forward_ret(self, batch, enc, subtasks))
+            else:   # evaluation dict of vast.py:466-483
+                ids, am = _tokens(self, batch)
+                out.update(feat_t=enc["feat_t"], input_ids=ids, attention_mask=am)
+                for st in subtasks:
+                    out[f"feat_cond_{st}"] = _feat_cond(self, enc, st[1:])
+                    out[f"condition_feats_{st}"] = _condition_feats(self, enc, st[1:])
+        elif t.startswith("cap"):
+            if not compute_loss:
+                raise NotImplementedError("caption generation is SURVEY.md section 8 row f1")
+            out.update(_forward_cap(self, batch, enc, subtasks))
+        else:
+            raise NotImplementedError(t)
+    return out

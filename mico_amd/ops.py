@@ -29,6 +29,27 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the GEMM kernel (bench.py's roofline leg).  Events are recorded on the
+    stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self, variants=((0, 0), (0, 1), (1, 1))):
+        self.variants = set(variants)
+        self.records = []   # (variant, flops, start_event, end_event)
+
+    def summary(self):
+        out = {}
+        for var, flops, e0, e1 in self.records:
+            d = out.setdefault(var, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+GEMM_TIMER = None
+
+
 def pad8(n):
     return (n + 7) // 8 * 8
 
@@ -60,8 +81,16 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.remap_group, e.remap_skip, e.remap_offset = remap
     e.alpha = alpha
     e.accumulate = 1 if accumulate else 0
+    timer = GEMM_TIMER
+    timed = timer is not None and (int(ta), int(tb)) in timer.variants
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = _lib.lib().mico_gemm(int(ta), int(tb), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0),
                               dt_code(out.dtype), C.byref(e), split_k, dt_code(dtype), _st())
+    if timed:
+        e1.record()
+        timer.records.append(((int(ta), int(tb)), 2.0 * M * N * K, e0, e1))
     check(rc, "mico_gemm")
     return out
 
@@ -75,14 +104,14 @@ def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rst
     check(rc, "mico_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, *, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
                   grad_scale=1.0, dtype=torch.float16):
     rows, cols = x.shape[0], x.shape[1]
     ws = None
     if dgamma is not None or dbeta is not None:
         nblk = _lib.lib().mico_layernorm_bwd_nblk(rows)
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=x.device)
-    rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
+    rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), dy_scale, _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
                                        _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
                                        _p(ws), rows, cols, dt_code(dtype), _st())
     check(rc, "mico_layernorm_bwd")
@@ -213,3 +242,40 @@ def l2norm_fwd(x, y, inv_norm):
 
 def l2norm_bwd(dy, y, inv_norm, dx):
     check(_lib.lib().mico_l2norm_bwd(_p(dy), _p(y), _p(inv_norm), _p(dx), y.shape[0], y.shape[1], _st()), "mico_l2norm_bwd")
+
+
+def sgemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, alpha=1.0, beta=0.0, bias=None):
+    """Exact fp32 small GEMM (heads / similarity matrices)."""
+    if M is None:
+        M = A.shape[1] if ta else A.shape[0]
+    if K is None:
+        K = A.shape[0] if ta else A.shape[1]
+    if N is None:
+        N = B.shape[1] if tb else B.shape[0]
+    check(_lib.lib().mico_sgemm_small(int(ta), int(tb), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out),
+                                      out.stride(0), alpha, beta, _p(bias), _st()), "mico_sgemm_small")
+    return out
+
+
+def gelu_f32(x, y):
+    check(_lib.lib().mico_gelu_f32(_p(x), _p(y), x.numel(), _st()), "mico_gelu_f32")
+
+
+def gelu_bwd_f32(x, dy, dx):
+    check(_lib.lib().mico_gelu_bwd_f32(_p(x), _p(dy), _p(dx), x.numel(), _st()), "mico_gelu_bwd_f32")
+
+
+def gelu_16(x, y):
+    check(_lib.lib().mico_gelu_16(_p(x), _p(y), x.numel(), dt_code(x.dtype), _st()), "mico_gelu_16")
+
+
+def gelu_bwd_16(x, dy, dx):
+    check(_lib.lib().mico_gelu_bwd_16(_p(x), _p(dy), _p(dx), x.numel(), dt_code(x.dtype), _st()), "mico_gelu_bwd_16")
+
+
+def cls_pool_fwd(tokens, pooled, b, n, frame_stride, D):
+    check(_lib.lib().mico_cls_pool_fwd(_p(tokens), _p(pooled), b, n, frame_stride, D, _st()), "mico_cls_pool_fwd")
+
+
+def cls_pool_bwd(dpooled, dtokens, b, n, frame_stride, D):
+    check(_lib.lib().mico_cls_pool_bwd(_p(dpooled), _p(dtokens), b, n, frame_stride, D, _st()), "mico_cls_pool_bwd")

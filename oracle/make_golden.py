@@ -1,0 +1,328 @@
+"""TEST INFRASTRUCTURE - generates tests/golden/*.pt by running the REFERENCE (imported from /root/reference through
+oracle/ref_import.py) on CPU fp32.  Build container only; the fixtures it writes are plain tensors (inputs are
+regenerated from seeds by mico_amd.weights, only expected outputs are stored).
+
+    python -m oracle.make_golden            # all fixtures
+    python -m oracle.make_golden vit bert   # a subset
+
+Reference call sites exercised: model/mico.py:115-248 (encoders, pooling, condition packing, heads),
+model/evaclip/eva_vit_model.py:611-659, model/bert.py:785-916,1047-1097; the loss composition follows
+data/model/vast.py:383-464 (forward_ret) and :485-512 (forward_cap) line by line with the reference's modules, with the
+torch.multinomial / TokenMasker draws replaced by recorded indices.
+"""
+import os
+import random
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_import  # noqa: E402
+from mico_amd.weights import synth_state_dict, synth_inputs  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def fill(model, seed=0):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth_state_dict(shapes, seed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    # transformers==4.31 ties the LM decoder to the word embeddings (model/bert.py:1038-1041); 5.x does not -> tie here
+    me = model.multimodal_encoder
+    me.cls.predictions.decoder.weight = me.bert.embeddings.word_embeddings.weight
+    me.cls.predictions.decoder.bias = me.cls.predictions.bias
+    return sd
+
+
+def grad_digest(t):
+    f = t.detach().flatten().float()
+    return dict(head=f[:256].clone(), norm=f.norm().clone(), asum=f.abs().sum().clone(), shape=tuple(t.shape))
+
+
+def vit_fixture(vtype, depth, tag):
+    torch.manual_seed(0)
+    m = ref_import.build_mico(vtype, depth=depth)
+    fill(m)
+    vis = m.vision_encoder.visual
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    taps = []
+    hooks = [blk.register_forward_hook(lambda mod, i, o: taps.append(o.detach())) for blk in vis.blocks]
+    for p in m.parameters():
+        p.requires_grad_(True)
+    out = vis(x, return_all_features=True)
+    for h in hooks:
+        h.remove()
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    names = ["patch_embed.proj.weight", "patch_embed.proj.bias", "cls_token", "pos_embed", "norm.weight", "norm.bias"]
+    for i in sorted({0, depth - 1}):
+        for k, _ in vis.blocks[i].named_parameters():
+            names.append(f"blocks.{i}.{k}")
+    named = dict(vis.named_parameters())
+    fx = dict(
+        out=out.detach().clone(),
+        tap_mean=torch.stack([t.mean() for t in taps]), tap_amax=torch.stack([t.abs().max() for t in taps]),
+        tap_rows=torch.stack([t[:, [0, 1, 100]] for t in taps]),
+        grads={n: grad_digest(named[n].grad) for n in names if named[n].grad is not None},
+        meta=dict(vtype=vtype, depth=depth, input_seed=77),
+    )
+    torch.save(fx, os.path.join(OUT, f"vit_{tag}.pt"))
+    print("wrote", f"vit_{tag}.pt", tuple(out.shape), float(out.abs().max()))
+    return m
+
+
+def bert_fixture(m):
+    me = m.multimodal_encoder
+    for p in m.parameters():
+        p.grad = None
+    g = torch.Generator().manual_seed(5)
+    b, S, E = 3, 16, 40
+    ids = torch.randint(1000, 30000, (b, S), generator=g)
+    ids[:, 0] = 101
+    lens = torch.tensor([16, 9, 5])
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    ids = ids * mask
+    cond = torch.randn((b, E, 768), generator=g)
+    fx = dict(meta=dict(b=b, S=S, E=E, seed=5, lens=lens))
+    o = me(input_ids=ids, attention_mask=mask)
+    fx["self_seq"] = o.sequence_output.detach().clone()
+    fx["self_argmax"] = o.logits.argmax(-1).clone()
+    o = me(input_ids=ids, attention_mask=mask, encoder_hidden_states=cond)
+    fx["cross_seq"] = o.sequence_output.detach().clone()
+    fx["cross_argmax"] = o.logits.argmax(-1).clone()
+    m3 = torch.tril(mask.unsqueeze(1).expand(-1, S, -1).clone())
+    labels = torch.full((b, S), -100)
+    labels[0, 3], labels[0, 7], labels[1, 2], labels[2, 1] = 2000, 1037, 30521, 999
+    cond_r = cond.clone().requires_grad_(True)
+    o = me(input_ids=ids, attention_mask=m3, encoder_hidden_states=cond_r, labels=labels)
+    fx["causal_seq"] = o.sequence_output.detach().clone()
+    fx["causal_loss"] = o.loss.detach().clone()
+    fx["causal_argmax"] = o.logits.argmax(-1).clone()
+    fx["labels"] = labels
+    o.loss.backward()
+    named = dict(me.named_parameters())
+    gn = ["bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
+          "bert.embeddings.LayerNorm.weight", "bert.encoder.layer.0.attention.self.query.weight",
+          "bert.encoder.layer.0.crossattention.self.key.weight", "bert.encoder.layer.0.crossattention.self.value.bias",
+          "bert.encoder.layer.11.output.dense.weight", "bert.encoder.layer.11.output.LayerNorm.bias",
+          "cls.predictions.transform.dense.weight", "cls.predictions.bias"]
+    fx["causal_grads"] = {n: grad_digest(named[n].grad) for n in gn}
+    fx["causal_dcond"] = cond_r.grad.detach().clone()
+    torch.save(fx, os.path.join(OUT, "bert.pt"))
+    print("wrote bert.pt", float(fx["causal_loss"]))
+
+
+def facade_fixture(m, tag, b=2):
+    """inference_demo.py:128-158 style calls + every pool / condition-pack branch."""
+    for p in m.parameters():
+        p.grad = None
+    fx = dict(meta=dict(b=b, tag=tag))
+    cfgs = {"n1": dict(b=b, vision=1, audio=1, depth=1, S=20), "n4": dict(b=b, vision=4, audio=4, depth=1, S=20),
+            "n3": dict(b=b, vision=3, audio=2, depth=1, S=20)}   # n3: frame embedding nearest-interp branch (8->3, 4->2)
+    with torch.no_grad():
+        for name, c in cfgs.items():
+            inp = synth_inputs(c, seed=100)
+            vo = m.forward_vision_encoder(inp["vision_pixels"])
+            ao = m.forward_audio_encoder(inp["audio_spectrograms"])
+            do = m.forward_depth_encoder(inp["depth_pixels"])
+            r = {}
+            r["feat_v"] = F.normalize(m.contra_head_v(m.pool_vision_for_contra(vo)), dim=-1)
+            r["feat_a"] = F.normalize(m.contra_head_a(m.pool_audio_for_contra(ao)), dim=-1)
+            r["feat_d"] = F.normalize(m.contra_head_d(m.pool_depth_for_contra(do)), dim=-1)
+            r["feat_va"] = F.normalize(m.contra_head_va(torch.cat((m.pool_vision_for_contra(vo), m.pool_audio_for_contra(ao)), 1)), dim=-1)
+            r["feat_vd"] = F.normalize(m.contra_head_id(torch.cat((m.pool_vision_for_contra(vo), m.pool_depth_for_contra(do)), 1)), dim=-1)
+            to = m.forward_multimodal_encoder(inp["input_ids"], inp["attention_mask"]).sequence_output
+            r["feat_t"] = F.normalize(m.contra_head_t(m.pool_text_for_contra(to)), dim=-1)
+            r["sim_t2v"] = r["feat_t"] @ r["feat_v"].t()
+            for pv in (False, True):
+                m.config.pool_video = pv
+                cv = m.get_multimodal_forward_input_vision(vo)
+                ca = m.get_multimodal_forward_input_audio(ao)
+                cd = m.get_multimodal_forward_input_depth(do)
+                k = "pv" if pv else "full"
+                r[f"cond_v_{k}_rows"] = cv[:, [0, 1, cv.shape[1] - 1]].clone()
+                r[f"cond_v_{k}_sum"] = cv.sum((1, 2))
+                r[f"cond_a_{k}_rows"] = ca[:, [0, 1, ca.shape[1] - 1]].clone()
+                r[f"cond_d_{k}_rows"] = cd[:, [0, 1, cd.shape[1] - 1]].clone()
+                out = m.forward_multimodal_encoder(inp["input_ids"], inp["attention_mask"], cv).sequence_output
+                r[f"itm_score_{k}"] = F.softmax(m.itm_head(out[:, 0]), dim=1)[:, 1]
+            m.config.pool_video = False
+            r["vision_out_rows"] = vo[:, :, [0, 1, 50]].clone()
+            r["audio_out_rows"] = ao[:, :, [0, 1, 50]].clone()
+            fx[name] = r
+    torch.save(fx, os.path.join(OUT, f"facade_{tag}.pt"))
+    print("wrote", f"facade_{tag}.pt")
+
+
+def loss_fixture(m, tag, b=4):
+    """ITC + ITM + CAP for task 'ret%tva%tv_cap%tva' on a W=1 and a simulated W=2 world (two virtual ranks evaluated with
+    the reference modules; rank r's loss uses gathered = cat(rank0, rank1) exactly as concat_all_gather would)."""
+    itm_ratio = m.itm_ratio
+    fx = dict(meta=dict(b=b, tag=tag, task="ret%tva%tv_cap%tva", itm_ratio=itm_ratio))
+    rng = random.Random(11)
+    from oracle.mico_oracle import token_masker
+
+    def encode(inp):
+        vo = m.forward_vision_encoder(inp["vision_pixels"])
+        ao = m.forward_audio_encoder(inp["audio_spectrograms"])
+        to = m.multimodal_encoder.bert(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"]).last_hidden_state
+        e = dict(vo=vo, ao=ao)
+        e["feat_t"] = F.normalize(m.contra_head_t(m.pool_text_for_contra(to)), dim=-1)
+        pv, pa = m.pool_vision_for_contra(vo), m.pool_audio_for_contra(ao)
+        e["feat_v"] = F.normalize(m.contra_head_v(pv), dim=-1)
+        e["feat_va"] = F.normalize(m.contra_head_va(torch.cat((pv, pa), 1)), dim=-1)
+        cv, ca = m.get_multimodal_forward_input_vision(vo), m.get_multimodal_forward_input_audio(ao)
+        e["cond_v"], e["cond_va"] = cv, torch.cat((cv, ca), dim=1)
+        return e
+
+    def rank_loss(inp, e, world, rank, inj):
+        ids, am = inp["input_ids"], inp["attention_mask"]
+        bs = ids.shape[0]
+        l_itc, l_itm = [], []
+        for st in ("tva", "tv"):
+            c = st[1:]
+            fc = e["feat_" + c]
+            sim_c2t = fc @ world["feat_t_all"].t() / m.contra_temp                      # vast.py:405-408
+            sim_t2c = e["feat_t"] @ world[f"feat_{c}_all"].t() / m.contra_temp
+            targets = torch.arange(rank * bs, rank * bs + bs)
+            l_itc.append((F.cross_entropy(sim_c2t, targets, label_smoothing=0.1)
+                          + F.cross_entropy(sim_t2c, targets, label_smoothing=0.1)) / 2)   # :411-415
+            cond, cond_all = e["cond_" + c], world[f"cond_{c}_all"]
+            nci, nti = inj[st]["neg_cond_idx"], inj[st]["neg_text_idx"]
+            ids1 = torch.cat((ids, ids, world["ids_all"][nti]), 0)                           # :445-448
+            am1 = torch.cat((am, am, world["mask_all"][nti]), 0)
+            cf = torch.cat((cond, cond_all[nci], cond), 0)
+            out = m.multimodal_encoder.bert(input_ids=ids1, attention_mask=am1, encoder_hidden_states=cf).last_hidden_state
+            logits = m.itm_head(out[:, 0])
+            gt = torch.zeros(bs * 3, dtype=torch.long)
+            gt[:bs] = 1
+            l_itm.append(itm_ratio * F.cross_entropy(logits, gt))                            # :453-457
+        S = am.shape[1]
+        m3 = torch.tril(am.unsqueeze(1).expand(-1, S, -1).clone())                            # :497-499
+        cap = m.multimodal_encoder(input_ids=inj["cap"]["masked_ids"], attention_mask=m3,
+                                   encoder_hidden_states=e["cond_va"], labels=inj["cap"]["labels"]).loss
+        return dict(loss_itc=sum(l_itc) / 2, loss_itm=sum(l_itm) / 2, loss_cap=cap)
+
+    def make_inj(inp, e, world, rank):
+        bs = inp["input_ids"].shape[0]
+        inj = {}
+        for st in ("tva", "tv"):
+            c = st[1:]
+            with torch.no_grad():
+                w_t2c = F.softmax(e["feat_t"] @ world[f"feat_{c}_all"].t() / m.contra_temp, dim=1) + 1e-4   # :423-427
+                w_t2c[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
+                w_c2t = F.softmax(e["feat_" + c] @ world["feat_t_all"].t() / m.contra_temp, dim=1) + 1e-4
+                w_c2t[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
+            gg = torch.Generator().manual_seed(1000 + rank + len(st))
+            inj[st] = dict(neg_cond_idx=torch.multinomial(w_t2c, 1, generator=gg).view(-1),
+                           neg_text_idx=torch.multinomial(w_c2t, 1, generator=gg).view(-1),
+                           w_t2c=w_t2c.clone(), w_c2t=w_c2t.clone())
+        mi, lab = token_masker(inp["input_ids"], 0.6, rng)
+        inj["cap"] = dict(masked_ids=mi, labels=lab)
+        return inj
+
+    gnames = ["contra_temp", "contra_head_t.linear.weight", "contra_head_va.weight", "itm_head.linear2.weight",
+              "hidden_trans_vision_multimodal.0.weight", "vision_frame_embedding", "audio_type_embeddings",
+              "vision_encoder.visual.patch_embed.proj.weight", "vision_encoder.visual.cls_token",
+              "vision_encoder.visual.blocks.0.norm1.weight", "vision_encoder.visual.blocks.1.mlp.{}.weight",
+              "multimodal_encoder.bert.embeddings.word_embeddings.weight",
+              "multimodal_encoder.bert.encoder.layer.5.crossattention.self.key.weight",
+              "multimodal_encoder.cls.predictions.bias"]
+    named = dict(m.named_parameters())
+    gnames = [n.format("w3" if "vision_encoder.visual.blocks.1.mlp.w3.weight" in named else "fc2") for n in gnames]
+
+    for W in (1, 2):
+        inputs = [synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234 + r) for r in range(W)]
+        encs = [encode(i) for i in inputs]
+        world = dict(feat_t_all=torch.cat([e["feat_t"] for e in encs]).detach(),
+                     ids_all=torch.cat([i["input_ids"] for i in inputs]), mask_all=torch.cat([i["attention_mask"] for i in inputs]))
+        for c in ("v", "va"):
+            world[f"feat_{c}_all"] = torch.cat([e["feat_" + c] for e in encs]).detach()
+            # all_gather_with_grad: grads flow to every rank's condition_feats (distributed.py:12-47); for rank 0's
+            # loss only rank 0's parameters' grads are recorded below, matching one process of the DDP job before the
+            # gradient all-reduce.  Remote rows enter as constants here (their grad contribution belongs to the other
+            # rank's backward and reaches the parameters through DDP's all-reduce).
+            world[f"cond_{c}_all"] = torch.cat([encs[0]["cond_" + c]] + [e["cond_" + c].detach() for e in encs[1:]])
+        inj = make_inj(inputs[0], encs[0], world, 0)
+        for p in m.parameters():
+            p.grad = None
+        losses = rank_loss(inputs[0], encs[0], world, 0, inj)
+        total = sum(losses.values())
+        total.backward()
+        r = dict(losses={k: v.detach().clone() for k, v in losses.items()}, inj=inj,
+                 grads={n: grad_digest(named[n].grad) for n in gnames},
+                 world={k: v.detach().clone() for k, v in world.items() if not k.startswith("cond_")},
+                 feat_t=encs[0]["feat_t"].detach().clone(), feat_va=encs[0]["feat_va"].detach().clone())
+        if W == 2:   # the remote rank's condition rows that may be fetched as negatives (recomputed from seeds in tests)
+            r["remote_cond_va_sum"] = encs[1]["cond_va"].detach().sum((1, 2))
+        fx[f"W{W}"] = r
+        print(tag, "W", W, {k: float(v) for k, v in losses.items()})
+    torch.save(fx, os.path.join(OUT, f"loss_{tag}.pt"))
+    print("wrote", f"loss_{tag}.pt")
+
+
+def tokenizer_fixture(m):
+    tok = m.multimodal_encoder.tokenizer
+    texts = ["a man is skiing in a snowy day.", "A dog runs; the CAT sleeps!", "multimodal context omni-modal pretraining",
+             "", "x " * 60]
+    fx = dict(texts=texts)
+    for L in (30, 77):
+        o = tok(texts, padding="max_length", truncation=True, max_length=L, return_tensors="pt")
+        fx[f"ids_{L}"] = o.input_ids.clone()
+        fx[f"mask_{L}"] = o.attention_mask.clone()
+    fx["special"] = dict(bos=tok.bos_token_id, eos=tok.eos_token_id, pad=tok.pad_token_id, mask=tok.mask_token_id)
+    torch.save(fx, os.path.join(OUT, "tokenizer.pt"))
+    print("wrote tokenizer.pt", fx["ids_30"][0, :12].tolist())
+
+
+def vit_full_fixture():
+    """Full-depth EVA01-g/14: one image, CLS + two token rows of the final LN output (GPU parity target)."""
+    m = ref_import.build_mico("evaclip01_giant")
+    fill(m)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn((1, 1, 3, 224, 224), generator=g)
+    with torch.no_grad():
+        out = m.forward_vision_encoder(x)
+        feat = F.normalize(m.contra_head_v(m.pool_vision_for_contra(out)), dim=-1)
+    torch.save(dict(rows=out[0, 0, [0, 1, 128, 256]].clone(), amax=out.abs().max(), mean=out.mean(), feat_v=feat.clone(),
+                    meta=dict(input_seed=99)), os.path.join(OUT, "vit_g14_full.pt"))
+    print("wrote vit_g14_full.pt")
+
+
+def main(which):
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    want = lambda k: not which or k in which
+    if want("vit") or want("bert") or want("facade") or want("loss") or want("tok"):
+        mb = vit_fixture("evaclip02_base", 2, "b16_d2") if want("vit") else None
+        if mb is None:
+            mb = ref_import.build_mico("evaclip02_base", depth=2)
+            fill(mb)
+        if want("bert"):
+            bert_fixture(mb)
+        if want("tok"):
+            tokenizer_fixture(mb)
+        if want("facade"):
+            facade_fixture(mb, "b16_d2")
+        if want("loss"):
+            loss_fixture(mb, "b16_d2")
+        del mb
+    if want("vit") or want("loss") or want("facade"):
+        mg = vit_fixture("evaclip01_giant", 2, "g14_d2") if want("vit") else None
+        if mg is None:
+            mg = ref_import.build_mico("evaclip01_giant", depth=2)
+            fill(mg)
+        if want("facade"):
+            facade_fixture(mg, "g14_d2")
+        if want("loss"):
+            loss_fixture(mg, "g14_d2")
+        del mg
+    if want("full"):
+        vit_full_fixture()
+
+
+if __name__ == "__main__":
+    main(set(sys.argv[1:]))

@@ -111,12 +111,12 @@ def test_layernorm(cuda, dtype, cols, xdt):
     dx16 = torch.empty(rows, cols, device=cuda, dtype=dtype)
     dg = torch.ones(cols, device=cuda)
     db = torch.ones(cols, device=cuda)
-    ops.layernorm_bwd(dy, x, gmm, mean, rstd, dx_add=add, dx32=dx, dx16=dx16, scale16=2.0, dgamma=dg, dbeta=db,
+    ops.layernorm_bwd(dy, x, gmm, mean, rstd, dy_scale=0.5, dx_add=add, dx32=dx, dx16=dx16, scale16=2.0, dgamma=dg, dbeta=db,
                       grad_scale=0.5, dtype=dtype)
-    assert rel_err(dx, xr.grad + add) < 1e-5
-    assert rel_err(dx16, 2.0 * (xr.grad + add)) < tol(dtype)
-    assert rel_err(dg, 1 + 0.5 * gr.grad) < 2e-5
-    assert rel_err(db, 1 + 0.5 * br.grad) < 2e-5
+    assert rel_err(dx, 0.5 * xr.grad + add) < 1e-5
+    assert rel_err(dx16, 2.0 * (0.5 * xr.grad + add)) < tol(dtype)
+    assert rel_err(dg, 1 + 0.25 * gr.grad) < 2e-5
+    assert rel_err(db, 1 + 0.25 * br.grad) < 2e-5
     # post-add table (frame + type embeddings)
     table = torch.randn(4, cols, device=cuda)
     y2 = torch.empty(rows, cols, device=cuda)

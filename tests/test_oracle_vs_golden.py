@@ -1,0 +1,163 @@
+"""Pins the CPU oracle (oracle/mico_oracle.py) against fixtures produced by the REFERENCE itself (oracle/make_golden.py,
+build container).  fp32 vs fp32: the bar is 2e-5 relative.  Everything here runs on CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from common import golden, rel_err, build_model, grad_digest_check
+from oracle import mico_oracle as O
+from mico_amd.weights import synth_inputs
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module", params=[("evaclip02_base", "b16_d2"), ("evaclip01_giant", "g14_d2")])
+def setup(request):
+    vtype, tag = request.param
+    m, sd = build_model(vtype, 2)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    # weight tying of the LM decoder (transformers==4.31 behaviour of the reference, model/bert.py:1038-1041)
+    sd["multimodal_encoder.cls.predictions.decoder.weight"] = sd["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    sd["multimodal_encoder.cls.predictions.decoder.bias"] = sd["multimodal_encoder.cls.predictions.bias"]
+    return vtype, tag, sd, O.ARCHS[vtype]
+
+
+def test_vit_tower(setup):
+    vtype, tag, sd, arch = setup
+    fx = golden(f"vit_{tag}.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    taps = []
+    out = O.eva_vit_forward(sd, x, arch, taps=taps)
+    assert rel_err(out, fx["out"]) < TOL
+    assert rel_err(torch.stack([t.mean() for t in taps]), fx["tap_mean"]) < 1e-4
+    assert rel_err(torch.stack([t[:, [0, 1, 100]] for t in taps]), fx["tap_rows"]) < TOL
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    for n, d in fx["grads"].items():
+        assert grad_digest_check(d, sd["vision_encoder.visual." + n].grad, TOL) < 5e-5, n
+
+
+def test_bert(setup):
+    vtype, tag, sd, arch = setup
+    if tag != "b16_d2":
+        pytest.skip("BERT fixture is tower independent")
+    fx = golden("bert.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["seed"])
+    b, S, E = fx["meta"]["b"], fx["meta"]["S"], fx["meta"]["E"]
+    ids = torch.randint(1000, 30000, (b, S), generator=g)
+    ids[:, 0] = 101
+    mask = (torch.arange(S)[None] < fx["meta"]["lens"][:, None]).long()
+    ids = ids * mask
+    cond = torch.randn((b, E, 768), generator=g)
+    for p in sd.values():
+        p.grad = None
+    o = O.bert_mlm(sd, ids, mask)
+    assert rel_err(o["sequence_output"], fx["self_seq"]) < TOL
+    assert torch.equal(o["logits"].argmax(-1), fx["self_argmax"])
+    o = O.bert_mlm(sd, ids, mask, cond)
+    assert rel_err(o["sequence_output"], fx["cross_seq"]) < TOL
+    assert torch.equal(o["logits"].argmax(-1), fx["cross_argmax"])
+    m3 = torch.tril(mask.unsqueeze(1).expand(-1, S, -1).clone())
+    cr = cond.clone().requires_grad_(True)
+    o = O.bert_mlm(sd, ids, m3, cr, fx["labels"])
+    assert rel_err(o["sequence_output"], fx["causal_seq"]) < TOL
+    assert abs(o["loss"].item() - fx["causal_loss"].item()) < 1e-5 * fx["causal_loss"].item()
+    assert torch.equal(o["logits"].argmax(-1), fx["causal_argmax"])
+    o["loss"].backward()
+    assert rel_err(cr.grad, fx["causal_dcond"]) < 5e-5
+    for n, d in fx["causal_grads"].items():
+        key = "multimodal_encoder." + n
+        gr = sd[key].grad
+        if n == "bert.embeddings.word_embeddings.weight":   # tied with the LM decoder: same tensor object in sd
+            pass
+        assert grad_digest_check(d, gr, TOL) < 1e-4, n
+
+
+def test_facade(setup):
+    vtype, tag, sd, arch = setup
+    fx = golden(f"facade_{tag}.pt")
+    cfgs = {"n1": dict(b=2, vision=1, audio=1, depth=1, S=20), "n4": dict(b=2, vision=4, audio=4, depth=1, S=20),
+            "n3": dict(b=2, vision=3, audio=2, depth=1, S=20)}
+    with torch.no_grad():
+        for name, c in cfgs.items():
+            r = fx[name]
+            inp = synth_inputs(c, seed=100)
+            enc = O.encode_batch(sd, arch, inp)
+            assert rel_err(enc["output_v"][:, :, [0, 1, 50]], r["vision_out_rows"]) < TOL
+            assert rel_err(enc["output_a"][:, :, [0, 1, 50]], r["audio_out_rows"]) < TOL
+            assert rel_err(enc["feat_t"], r["feat_t"]) < TOL
+            for c_ in ("v", "a", "d", "va", "vd"):
+                assert rel_err(O.feat_cond(sd, enc, c_), r["feat_" + c_]) < TOL, c_
+            assert rel_err(enc["feat_t"] @ O.feat_cond(sd, enc, "v").t(), r["sim_t2v"]) < 1e-4
+            for pv, k in ((False, "full"), (True, "pv")):
+                cv = O.multimodal_input(sd, "vision", enc["output_v"], pv)
+                ca = O.multimodal_input(sd, "audio", enc["output_a"], pv)
+                cd = O.multimodal_input(sd, "depth", enc["output_d"], pv)
+                assert rel_err(cv[:, [0, 1, cv.shape[1] - 1]], r[f"cond_v_{k}_rows"]) < TOL
+                assert rel_err(cv.sum((1, 2)), r[f"cond_v_{k}_sum"]) < 1e-4
+                assert rel_err(ca[:, [0, 1, ca.shape[1] - 1]], r[f"cond_a_{k}_rows"]) < TOL
+                assert rel_err(cd[:, [0, 1, cd.shape[1] - 1]], r[f"cond_d_{k}_rows"]) < TOL
+                out = O.bert_forward(sd, inp["input_ids"], inp["attention_mask"], cv)
+                score = F.softmax(O.itm_head(sd, out[:, 0]), dim=1)[:, 1]
+                assert rel_err(score, r[f"itm_score_{k}"]) < 1e-4
+
+
+@pytest.mark.parametrize("W", [1, 2])
+def test_alignment_loss(setup, W):
+    vtype, tag, sd, arch = setup
+    fx = golden(f"loss_{tag}.pt")
+    r = fx[f"W{W}"]
+    b = fx["meta"]["b"]
+    for p in sd.values():
+        p.grad = None
+    inputs = [synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234 + k) for k in range(W)]
+    world = None
+    if W == 2:
+        with torch.no_grad():
+            enc1 = O.encode_batch(sd, arch, inputs[1])
+        world = dict(feat_t_all=r["world"]["feat_t_all"], ids_all=r["world"]["ids_all"], mask_all=r["world"]["mask_all"])
+        for c in ("v", "va"):
+            world[f"feat_{c}_all"] = r["world"][f"feat_{c}_all"]
+        assert rel_err(O.condition_feats(enc1, "va").sum((1, 2)), r["remote_cond_va_sum"]) < 1e-4
+    injected = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
+    injected["cap"] = r["inj"]["cap"]
+    cfg = dict(itm_ratio=fx["meta"]["itm_ratio"])
+    if W == 2:   # gathered condition memory = [local (with grad) | remote (constant)]
+        out, enc = _loss_w2(sd, arch, inputs[0], cfg, world, injected, O.encode_batch(sd, arch, inputs[1]))
+    else:
+        out, enc = O.mico_forward(sd, arch, inputs[0], fx["meta"]["task"], cfg, injected=injected)
+    for k, v in r["losses"].items():
+        assert abs(out[k].item() - v.item()) < 2e-5 * max(1.0, abs(v.item())), k
+    assert rel_err(enc["feat_t"], r["feat_t"]) < TOL
+    sum(out.values()).backward()
+    for n, d in r["grads"].items():
+        assert grad_digest_check(d, sd[n].grad, TOL) < 2e-4, n
+
+
+def _loss_w2(sd, arch, inp, cfg, world, injected, enc_remote):
+    enc = O.encode_batch(sd, arch, inp)
+    for c in ("v", "va"):
+        world[f"cond_{c}_all"] = torch.cat((O.condition_feats(enc, c), O.condition_feats(enc_remote, c).detach()))
+    ids, am = inp["input_ids"], inp["attention_mask"]
+    l_itc, l_itm = [], []
+    for st in ("tva", "tv"):
+        c = st[1:]
+        fc = O.feat_cond(sd, enc, c)
+        li, _, _ = O.itc_loss(enc["feat_t"], fc, world["feat_t_all"], world[f"feat_{c}_all"], sd["contra_temp"], 0)
+        l_itc.append(li)
+        lm, _ = O.itm_loss(sd, ids, am, O.condition_feats(enc, c), world[f"cond_{c}_all"], world["ids_all"], world["mask_all"],
+                           injected[st]["neg_cond_idx"], injected[st]["neg_text_idx"], cfg["itm_ratio"])
+        l_itm.append(lm)
+    cap = O.cap_loss(sd, injected["cap"]["masked_ids"], am, injected["cap"]["labels"], O.condition_feats(enc, "va"))
+    return dict(loss_itc=sum(l_itc) / 2, loss_itm=sum(l_itm) / 2, loss_cap=cap), enc
+
+
+def test_token_masker_matches_reference_rule():
+    import random
+    ids = torch.tensor([[101, 2000, 2001, 2002, 102, 0, 0], [101, 5, 102, 0, 0, 0, 0]])
+    toks, labels = O.token_masker(ids, 0.6, random.Random(3))
+    assert (labels[:, 0] == -100).all() and (labels[ids == 0] == -100).all()
+    assert ((labels != -100).sum(1) >= 1).all()
+    changed = toks != ids
+    assert (labels[changed] == ids[changed]).all()
