@@ -57,7 +57,9 @@ def cpu_baseline(sd_cpu, args):
     from oracle import mico_oracle as O
     from mico_amd.weights import synth_inputs
     import random
-    ncores = os.cpu_count() or 1
+    # 32 threads: PyTorch's CPU GEMMs on this path stop scaling (and regress badly) far below the 256 hardware threads of the
+    # GPU box's host - a first run with all 256 threads took 1292 s for the same sample.
+    ncores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
     arch = O.ARCHS[args.vision]
     b = args.cpu_batch

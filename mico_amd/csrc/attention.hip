@@ -442,7 +442,7 @@ extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (rc) return rc;
     const dim3 grid((p->Sq + 63) / 64, p->H, p->B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, hipLaunchKernelGGL((attn_fwd_kernel<T, HDP>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p)));
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, MICO_LAUNCH((attn_fwd_kernel<T, HDP>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p)));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -456,9 +456,9 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     hipStream_t st = (hipStream_t)stream;
     const dim3 block(256);
     const dim3 gq((p->Sq + 63) / 64, p->H, p->B), gk((p->Sk + 63) / 64, p->H, p->B);
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HDP>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p)));
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p)));
     MICO_LAUNCH_CHECK();
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HDP>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p)));
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p)));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

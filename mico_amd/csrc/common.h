@@ -27,7 +27,15 @@ int mico_set_err(int code, const char* fmt, ...);
         if (!(cond)) return mico_set_err(MICO_EINVAL, __VA_ARGS__); \
     } while (0)
 
-#define MICO_LAUNCH_CHECK()                                                        \
+// hipGetLastError() is sticky per host thread: clear whatever an unrelated earlier runtime call left behind before the
+// launch so MICO_LAUNCH_CHECK reports this launch only.
+#define MICO_LAUNCH(...)               \
+    do {                               \
+        (void)hipGetLastError();       \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
+#define MICO_LAUNCH_CHECK()                                                       \
     do {                                                                           \
         hipError_t e__ = hipGetLastError();                                        \
         if (e__ != hipSuccess) return mico_set_err(MICO_ELAUNCH, "%s: %s", __func__, hipGetErrorString(e__)); \

@@ -283,7 +283,7 @@ extern "C" int mico_cast_f32_to_16(const float* src, int64_t ld_src, void* dst, 
     MICO_CHECK(dtype_ok(dtype) && src && dst, "mico_cast_f32_to_16: bad args");
     MICO_CHECK(cols_pad % 4 == 0 && cols_pad >= cols && ld_dst % 4 == 0 && ld_dst >= cols_pad, "mico_cast_f32_to_16: cols_pad/ld_dst must be multiples of 4");
     if (rows <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(cast_f32_to_16_kernel<T>, dim3(egrid(rows * (cols_pad / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, cols_pad, scale));
+    DISPATCH_T16(dtype, MICO_LAUNCH(cast_f32_to_16_kernel<T>, dim3(egrid(rows * (cols_pad / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, cols_pad, scale));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -293,7 +293,7 @@ extern "C" int mico_cast_16_to_f32(const void* src, int64_t ld_src, float* dst, 
     MICO_CHECK(dtype_ok(dtype) && src && dst, "mico_cast_16_to_f32: bad args");
     MICO_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "mico_cast_16_to_f32: cols/ld must be multiples of 4");
     if (rows <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(cast_16_to_f32_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, (const T*)src, ld_src, dst, ld_dst, rows, cols, scale, accumulate));
+    DISPATCH_T16(dtype, MICO_LAUNCH(cast_16_to_f32_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, (const T*)src, ld_src, dst, ld_dst, rows, cols, scale, accumulate));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -305,7 +305,7 @@ extern "C" int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst
     MICO_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "mico_gather_rows_cast: cols/ld must be multiples of 4");
     if (row_scale) MICO_CHECK(rows_per_scale > 0, "mico_gather_rows_cast: rows_per_scale");
     if (rows <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(gather_rows_cast_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, remap_group, remap_skip, remap_offset, row_scale, rows_per_scale, scale));
+    DISPATCH_T16(dtype, MICO_LAUNCH(gather_rows_cast_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, remap_group, remap_skip, remap_offset, row_scale, rows_per_scale, scale));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -315,7 +315,7 @@ extern "C" int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows,
     MICO_CHECK(x && out && cols > 0, "mico_colsum: bad args");
     MICO_CHECK(x_dtype == MICO_F32 || x_dtype == MICO_F16 || x_dtype == MICO_BF16, "mico_colsum: bad dtype");
     if (!accumulate) {
-        hipLaunchKernelGGL(zero_kernel, dim3(egrid(cols)), dim3(EB), 0, ST, out, (int64_t)cols);
+        MICO_LAUNCH(zero_kernel, dim3(egrid(cols)), dim3(EB), 0, ST, out, (int64_t)cols);
         MICO_LAUNCH_CHECK();
     }
     if (rows <= 0) return MICO_OK;
@@ -326,9 +326,9 @@ extern "C" int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows,
     if (rpc < 16) rpc = 16;
     chunks = (rows + rpc - 1) / rpc;
     const dim3 grid(ncb, (unsigned)chunks);
-    if (x_dtype == MICO_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(EB), 0, ST, (const float*)x, ld, rows, cols, out, scale, rpc);
-    else if (x_dtype == MICO_F16) hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(EB), 0, ST, (const f16*)x, ld, rows, cols, out, scale, rpc);
-    else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(EB), 0, ST, (const bf16*)x, ld, rows, cols, out, scale, rpc);
+    if (x_dtype == MICO_F32) MICO_LAUNCH(colsum_kernel<float>, grid, dim3(EB), 0, ST, (const float*)x, ld, rows, cols, out, scale, rpc);
+    else if (x_dtype == MICO_F16) MICO_LAUNCH(colsum_kernel<f16>, grid, dim3(EB), 0, ST, (const f16*)x, ld, rows, cols, out, scale, rpc);
+    else MICO_LAUNCH(colsum_kernel<bf16>, grid, dim3(EB), 0, ST, (const bf16*)x, ld, rows, cols, out, scale, rpc);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -336,7 +336,7 @@ extern "C" int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows,
 extern "C" int mico_cls_rows(float* x, int64_t ld, int B, int group_rows, const float* cls, const float* pos0, int cols,
                              void* stream) {
     MICO_CHECK(x && cls && pos0 && B > 0 && cols > 0, "mico_cls_rows: bad args");
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(egrid((int64_t)B * cols)), dim3(EB), 0, ST, x, ld, B, group_rows, cls, pos0, cols);
+    MICO_LAUNCH(cls_rows_kernel, dim3(egrid((int64_t)B * cols)), dim3(EB), 0, ST, x, ld, B, group_rows, cls, pos0, cols);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -345,7 +345,7 @@ extern "C" int mico_add_f32(const float* a, const float* b, float* y, void* y16,
                             void* stream) {
     MICO_CHECK(dtype_ok(dtype) && a && (y || y16) && n % 4 == 0, "mico_add_f32: bad args (n must be a multiple of 4)");
     if (n <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(add_f32_kernel<T>, dim3(egrid(n / 4)), dim3(EB), 0, ST, a, b, y, (T*)y16, n / 4, scale16));
+    DISPATCH_T16(dtype, MICO_LAUNCH(add_f32_kernel<T>, dim3(egrid(n / 4)), dim3(EB), 0, ST, a, b, y, (T*)y16, n / 4, scale16));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -353,7 +353,7 @@ extern "C" int mico_add_f32(const float* a, const float* b, float* y, void* y16,
 extern "C" int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t n, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype) && x1 && x2 && h && n % 8 == 0, "mico_swiglu_fwd: bad args (n must be a multiple of 8)");
     if (n <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(swiglu_fwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (T*)h, n / 8));
+    DISPATCH_T16(dtype, MICO_LAUNCH(swiglu_fwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (T*)h, n / 8));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -362,7 +362,7 @@ extern "C" int mico_swiglu_bwd(const void* x1, const void* x2, const void* dh, v
                                void* stream) {
     MICO_CHECK(dtype_ok(dtype) && x1 && x2 && dh && dx1 && dx2 && n % 8 == 0, "mico_swiglu_bwd: bad args");
     if (n <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(swiglu_bwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (const T*)dh, (T*)dx1, (T*)dx2, n / 8));
+    DISPATCH_T16(dtype, MICO_LAUNCH(swiglu_bwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (const T*)dh, (T*)dx1, (T*)dx2, n / 8));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -374,7 +374,7 @@ extern "C" int mico_im2row(const float* pixels, void* rows16, int B, int C, int 
     MICO_CHECK(kpad % 8 == 0 && kpad >= C * P * P, "mico_im2row: kpad must be a multiple of 8 and >= C*P*P");
     if (B <= 0) return MICO_OK;
     const int64_t total = (int64_t)B * (H / P) * (W / P) * (kpad / 4);
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(im2row_kernel<T>, dim3(egrid(total)), dim3(EB), 0, ST, pixels, (T*)rows16, B, C, H, W, P, kpad));
+    DISPATCH_T16(dtype, MICO_LAUNCH(im2row_kernel<T>, dim3(egrid(total)), dim3(EB), 0, ST, pixels, (T*)rows16, B, C, H, W, P, kpad));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -385,7 +385,7 @@ extern "C" int mico_rope(void* x, int64_t bs, int64_t rs, int B, int N, int H, i
     MICO_CHECK(hd % 4 == 0 && rs % 4 == 0 && bs % 4 == 0, "mico_rope: hd and strides must be multiples of 4");
     if (B <= 0 || N <= 1) return MICO_OK;
     const int64_t total = (int64_t)B * (N - 1) * H * (hd / 4);
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(rope_kernel<T>, dim3(egrid(total)), dim3(EB), 0, ST, (T*)x, bs, rs, B, N, H, hd, cos_t, sin_t, inverse));
+    DISPATCH_T16(dtype, MICO_LAUNCH(rope_kernel<T>, dim3(egrid(total)), dim3(EB), 0, ST, (T*)x, bs, rs, B, N, H, hd, cos_t, sin_t, inverse));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -394,7 +394,7 @@ extern "C" int mico_bert_embed_fwd(const int64_t* ids, const float* word, const 
                                    float* sum32, int64_t rows, int S, int cols, int vocab, void* stream) {
     MICO_CHECK(ids && word && pos && type0 && sum32 && cols % 4 == 0 && S > 0, "mico_bert_embed_fwd: bad args");
     if (rows <= 0) return MICO_OK;
-    hipLaunchKernelGGL(bert_embed_kernel, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, ids, word, pos, type0, sum32, rows, S, cols, vocab);
+    MICO_LAUNCH(bert_embed_kernel, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, ids, word, pos, type0, sum32, rows, S, cols, vocab);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -403,7 +403,7 @@ extern "C" int mico_embed_scatter_add(const int64_t* ids, const float* dsum, flo
                                       int64_t rows, int S, int cols, int vocab, float scale, void* stream) {
     MICO_CHECK(ids && dsum && S > 0, "mico_embed_scatter_add: bad args");
     if (rows <= 0) return MICO_OK;
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(egrid(rows * cols)), dim3(EB), 0, ST, ids, dsum, dword, dpos, dtype0, rows, S, cols, vocab, scale);
+    MICO_LAUNCH(embed_scatter_kernel, dim3(egrid(rows * cols)), dim3(EB), 0, ST, ids, dsum, dword, dpos, dtype0, rows, S, cols, vocab, scale);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -411,7 +411,7 @@ extern "C" int mico_embed_scatter_add(const int64_t* ids, const float* dsum, flo
 extern "C" int mico_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int cols, void* stream) {
     MICO_CHECK(x && y, "mico_l2norm_fwd: bad args");
     if (rows <= 0) return MICO_OK;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, x, y, inv_norm, rows, cols);
+    MICO_LAUNCH(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, x, y, inv_norm, rows, cols);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -420,7 +420,7 @@ extern "C" int mico_l2norm_bwd(const float* dy, const float* y, const float* inv
                                void* stream) {
     MICO_CHECK(dy && y && inv_norm && dx, "mico_l2norm_bwd: bad args");
     if (rows <= 0) return MICO_OK;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, dy, y, inv_norm, dx, rows, cols);
+    MICO_LAUNCH(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST, dy, y, inv_norm, dx, rows, cols);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(int ta, int tb, int M,
 extern "C" int mico_sgemm_small(int ta, int tb, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                 float* Cm, int64_t ldc, float alpha, float beta, const float* bias, void* stream) {
     MICO_CHECK(A && B && Cm && M > 0 && N > 0 && K > 0, "mico_sgemm_small: bad args");
-    hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ST, ta, tb, M, N, K, A, lda, B, ldb, Cm, ldc, alpha, beta, bias);
+    MICO_LAUNCH(sgemm_small_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ST, ta, tb, M, N, K, A, lda, B, ldb, Cm, ldc, alpha, beta, bias);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -522,40 +522,40 @@ __global__ void cls_pool_bwd_kernel(const float* __restrict__ dout, float* __res
 extern "C" int mico_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
     MICO_CHECK(x && y, "mico_gelu_f32: bad args");
     if (n <= 0) return MICO_OK;
-    hipLaunchKernelGGL(gelu_f32_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, y, n);
+    MICO_LAUNCH(gelu_f32_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, y, n);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
 extern "C" int mico_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
     MICO_CHECK(x && dy && dx, "mico_gelu_bwd_f32: bad args");
     if (n <= 0) return MICO_OK;
-    hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, dy, dx, n);
+    MICO_LAUNCH(gelu_bwd_f32_kernel, dim3(egrid(n)), dim3(EB), 0, ST, x, dy, dx, n);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
 extern "C" int mico_gelu_16(const void* x, void* y, int64_t n, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype) && x && y && n % 8 == 0, "mico_gelu_16: bad args");
     if (n <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(gelu_16_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x, (T*)y, n / 8));
+    DISPATCH_T16(dtype, MICO_LAUNCH(gelu_16_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x, (T*)y, n / 8));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
 extern "C" int mico_gelu_bwd_16(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype) && x && dy && dx && n % 8 == 0, "mico_gelu_bwd_16: bad args");
     if (n <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, hipLaunchKernelGGL(gelu_bwd_16_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x, (const T*)dy, (T*)dx, n / 8));
+    DISPATCH_T16(dtype, MICO_LAUNCH(gelu_bwd_16_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x, (const T*)dy, (T*)dx, n / 8));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
 extern "C" int mico_cls_pool_fwd(const float* tokens, float* pooled, int b, int n, int64_t frame_stride, int D, void* stream) {
     MICO_CHECK(tokens && pooled && b > 0 && n > 0, "mico_cls_pool_fwd: bad args");
-    hipLaunchKernelGGL(cls_pool_fwd_kernel, dim3(egrid((int64_t)b * D)), dim3(EB), 0, ST, tokens, pooled, b, n, frame_stride, D);
+    MICO_LAUNCH(cls_pool_fwd_kernel, dim3(egrid((int64_t)b * D)), dim3(EB), 0, ST, tokens, pooled, b, n, frame_stride, D);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
 extern "C" int mico_cls_pool_bwd(const float* dpooled, float* dtokens, int b, int n, int64_t frame_stride, int D, void* stream) {
     MICO_CHECK(dpooled && dtokens && b > 0 && n > 0, "mico_cls_pool_bwd: bad args");
-    hipLaunchKernelGGL(cls_pool_bwd_kernel, dim3(egrid((int64_t)b * n * D)), dim3(EB), 0, ST, dpooled, dtokens, b, n, frame_stride, D);
+    MICO_LAUNCH(cls_pool_bwd_kernel, dim3(egrid((int64_t)b * n * D)), dim3(EB), 0, ST, dpooled, dtokens, b, n, frame_stride, D);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

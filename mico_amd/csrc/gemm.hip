@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 template <typename T>
 int launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles * g.split_k), block(256);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, g);
-    else if (ta && tb) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, g);
+    if (!ta && !tb) MICO_LAUNCH((gemm_kernel<T, false, false>), grid, block, 0, st, g);
+    else if (!ta && tb) MICO_LAUNCH((gemm_kernel<T, false, true>), grid, block, 0, st, g);
+    else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_kernel<T, true, false>), grid, block, 0, st, g);
     return 0;
 }
 

@@ -173,7 +173,7 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
 template <typename T, typename XT>
 void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
                    float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups) {
-#define LNF(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups)
+#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups)
     if (cols <= 1024) LNF(4);
     else if (cols <= 1536) LNF(6);
     else if (cols <= 2048) LNF(8);
@@ -185,7 +185,7 @@ template <typename T, typename DT, typename XT>
 void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                    const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
                    int cols, float dy_scale) {
-#define LNB(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale)
+#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else LNB(8);
@@ -237,7 +237,7 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
+        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
         MICO_LAUNCH_CHECK();
     }
     return MICO_OK;

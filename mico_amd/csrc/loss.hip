@@ -79,7 +79,7 @@ extern "C" int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld,
     if (rows <= 0) return MICO_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)rows), block(256);
-#define CE(LT) hipLaunchKernelGGL((ce_kernel<LT, LT>), grid, block, 0, st, (const LT*)logits, ld, cols, target, ignore_index, label_smoothing, logits_scale, row_loss, row_lse, (LT*)dlogits, ld_d, dscale_ptr, dscale)
+#define CE(LT) MICO_LAUNCH((ce_kernel<LT, LT>), grid, block, 0, st, (const LT*)logits, ld, cols, target, ignore_index, label_smoothing, logits_scale, row_loss, row_lse, (LT*)dlogits, ld_d, dscale_ptr, dscale)
     if (logits_dtype == MICO_F32) CE(float);
     else if (logits_dtype == MICO_F16) CE(f16);
     else CE(bf16);
