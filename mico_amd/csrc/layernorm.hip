@@ -148,22 +148,33 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
     }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int cols, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float scale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// folds the per-block partials: 32 columns per workgroup, 8 threads per column stride the partial rows, LDS tree
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int cols,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float scale) {
+    __shared__ float ra[8][33], rb[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        a += ws[(int64_t)k * cols + c];
-        b += ws[((int64_t)nblk + k) * cols + c];
+    if (c < cols) {
+        for (int k = ry; k < nblk; k += 8) {
+            a += ws[(int64_t)k * cols + c];
+            b += ws[((int64_t)nblk + k) * cols + c];
+        }
     }
-    if (dgamma) dgamma[c] += a * scale;
-    if (dbeta) dbeta[c] += b * scale;
+    ra[ry][cx] = a;
+    rb[ry][cx] = b;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += ra[k][cx]; b += rb[k][cx]; }
+        if (dgamma) dgamma[c] += a * scale;
+        if (dbeta) dbeta[c] += b * scale;
+    }
 }
 
 int ln_grid(int64_t rows) {
     int64_t nb = (rows + 3) / 4;
-    if (nb > 2048) nb = 2048;
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -237,7 +248,7 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {
-        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
+        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
         MICO_LAUNCH_CHECK();
     }
     return MICO_OK;

@@ -13,10 +13,20 @@ from . import ops, runtime
 
 
 def _split_k(m_out, n_out, k_red):
+    """Split factor for the long-reduction weight-gradient GEMMs: 512 workgroup slots (256 CUs x 2) must be filled in whole
+    waves - e.g. 48 x 11 = 528 tiles unsplit would run as one full wave plus a 16-block tail at 2x the time.  Cost model:
+    waves(s) * (k-tiles per split + fixed prologue / atomic-epilogue cost in k-tile units)."""
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     ktiles = (k_red + 63) // 64
-    s = max(1, min(1024 // max(tiles, 1), ktiles // 8))
-    return s
+    best, best_cost = 1, None
+    for s in range(1, 33):
+        if s > 1 and ktiles // s < 16:
+            break
+        waves = -(-(tiles * s) // 512)
+        cost = waves * (-(-ktiles // s) + 12)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s, cost
+    return best
 
 
 def _empty(shape, dtype, dev):

@@ -178,3 +178,20 @@ def test_no_cpu_fallback():
     m, _ = build_model("evaclip02_base", 1, device="cpu")
     with pytest.raises((MicoHipError, RuntimeError)):
         m.forward_vision_encoder(torch.zeros(1, 1, 3, 224, 224))
+
+
+def test_full_depth_vit_g(cuda):
+    """Full 40-block EVA01-g/14 on one image against the reference's own output (tests/golden/vit_g14_full.pt)."""
+    fx = golden("vit_g14_full.pt")
+    m, sd = build_model("evaclip01_giant", None, device=cuda)
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((1, 1, 3, 224, 224), generator=g).to(cuda)
+    from mico_amd.functional import l2_normalize
+    for dtype, tol in ((torch.float16, 1e-3), (torch.bfloat16, 2e-2)):
+        with runtime.precision(dtype), torch.no_grad():
+            out = m.forward_vision_encoder(x)
+            feat = l2_normalize(m.contra_head_v(m.pool_vision_for_contra(out)))
+        e_rows = err_vs(out[0, 0, [0, 1, 128, 256]], fx["rows"], fx["amax"])
+        e_feat = rel_err(feat, fx["feat_v"])
+        print(f"full g/14 {dtype}: token rows {e_rows:.2e}  feat_v {e_feat:.2e}  amax {out.abs().max().item():.3f}/{fx['amax'].item():.3f}")
+        assert e_rows < tol and e_feat < 2 * tol
