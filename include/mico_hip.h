@@ -71,6 +71,12 @@ typedef struct mico_gemm_epilogue {
     int remap_offset;
     float alpha;
     int accumulate;         /* fp32 output only: C += v */
+    /* k-segments (split-precision GEMM, fp16 parity configuration): the logical reduction of length K = nseg * kseg is the
+     * concatenation of nseg segments; segment s reads A columns a_seg_off[s].. and B columns b_seg_off[s]..  With
+     * A = [x_hi | x_lo], B = [W_hi | W_lo] and offsets a = {0, D, 0}, b = {0, 0, D} one launch computes
+     * x_hi W_hi + x_lo W_hi + x_hi W_lo  (~22 mantissa bits from fp16 MFMAs).  nseg == 0 disables. */
+    int nseg, kseg;
+    int a_seg_off[3], b_seg_off[3];
 } mico_gemm_epilogue;
 
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
@@ -84,11 +90,12 @@ int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
  *   x: [rows, cols] fp32 (x_dtype == MICO_F32) or 16-bit;  y16 / y32 optional outputs;  mean/rstd [rows] saved.
  *   post_add (optional, fp32 [post_groups, cols]): y += post_add[(row / post_rows_per_group) % post_groups]
  *   (frame + type embeddings of model/mico.py:201,209).
+ *   y16_split != 0: y16 is [rows, 2*cols] = [hi | lo] with lo = T(y - hi) (A operand of a split-precision mico_gemm).
  * ------------------------------------------------------------------------------------------------------------- */
 int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                        void* y16, float* y32, float* mean, float* rstd,
                        int64_t rows, int cols, float eps,
-                       const float* post_add, int post_rows_per_group, int post_groups,
+                       const float* post_add, int post_rows_per_group, int post_groups, int y16_split,
                        int dtype, void* stream);
 /* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
  * (dx16 = T(dx * scale16)).

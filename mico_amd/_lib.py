@@ -6,6 +6,11 @@ built (python __graft_entry__.py / make -C mico_amd/csrc) so a missing extension
 import ctypes as C
 import os
 
+# PyTorch-ROCm wheels bundle their own libamdhip64; it must be the HIP runtime already resident in the process when
+# libmico_hip.so is dlopen'ed, otherwise the loader binds our library to /opt/rocm's copy and the process ends up with two
+# runtimes (kernel launches from ours then fail with "no ROCm-capable device is detected").
+import torch  # noqa: F401  (import order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmico_hip.so")
 
@@ -20,6 +25,7 @@ class GemmEpilogue(C.Structure):
         ("bias", c_vp), ("aux_out", c_vp), ("aux_in", c_vp), ("ldaux", c_i64), ("act", c_int),
         ("row_scale", c_vp), ("rows_per_scale", c_int), ("resid", c_vp), ("pos", c_vp), ("pos_rows", c_int),
         ("remap_group", c_int), ("remap_skip", c_int), ("remap_offset", c_int), ("alpha", c_f), ("accumulate", c_int),
+        ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
     ]
 
 
@@ -38,7 +44,7 @@ PROTOTYPES = {
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
-                           c_int, c_vp],
+                           c_int, c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
     "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
                            c_i64, c_int, c_int, c_vp],

@@ -28,6 +28,7 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc;
     int ntm, ntn, ntiles, split_k, ktiles, ktiles_per_split;
     int c_dtype;
+    int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
 };
 
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
     const char* a_base = TA ? g.A + m0 * 2 : g.A + m0 * lda_b;
     const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
-    int64_t a_bytes = TA ? g.K * lda_b - m0 * 2 : (g.M - m0) * lda_b;
-    int64_t b_bytes = TB ? g.K * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+    int64_t a_bytes = TA ? g.ka_rows * lda_b - m0 * 2 : (g.M - m0) * lda_b;
+    int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
     if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
     if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
     __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
@@ -129,17 +130,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // logical k-tile -> physical k offsets of A and B.  With k-segments (split-precision GEMMs) the logical reduction is
+    // the concatenation of nseg segments of kseg elements, each mapped to its own physical column offset per operand.
+    const int nseg = g.e.nseg, kseg = g.e.kseg;
+    auto kmap = [&](int kt, int& ka, int& kb, int64_t& kda, int64_t& kdb) {
+        const int k0 = kt * BK;
+        if (nseg > 0) {
+            const int sg = k0 / kseg, kin = k0 - sg * kseg;
+            ka = g.e.a_seg_off[sg] + kin;
+            kb = g.e.b_seg_off[sg] + kin;
+            kda = g.e.a_seg_off[sg] + kseg;
+            kdb = g.e.b_seg_off[sg] + kseg;
+        } else {
+            ka = kb = k0;
+            kda = kdb = g.K;
+        }
+    };
     int cur = 0;
     if (kt0 < kt1) {
-        stage_tile<TA>(rsa, lds, wave, lane, lda_b, kt0 * BK, g.K, a_crem);
-        stage_tile<TB>(rsb, lds + TILE_BYTES, wave, lane, ldb_b, kt0 * BK, g.K, b_crem);
+        int ka, kb;
+        int64_t kda, kdb;
+        kmap(kt0, ka, kb, kda, kdb);
+        stage_tile<TA>(rsa, lds, wave, lane, lda_b, ka, kda, a_crem);
+        stage_tile<TB>(rsb, lds + TILE_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
     }
     for (int kt = kt0; kt < kt1; ++kt) {
         __syncthreads();   // stage `cur` landed (vmcnt(0) precedes the barrier); stage cur^1 no longer being read
         if (kt + 1 < kt1) {
             LDS_AS char* nxt = lds + (cur ^ 1) * STAGE_BYTES;
-            stage_tile<TA>(rsa, nxt, wave, lane, lda_b, (kt + 1) * BK, g.K, a_crem);
-            stage_tile<TB>(rsb, nxt + TILE_BYTES, wave, lane, ldb_b, (kt + 1) * BK, g.K, b_crem);
+            int ka, kb;
+            int64_t kda, kdb;
+            kmap(kt + 1, ka, kb, kda, kdb);
+            stage_tile<TA>(rsa, nxt, wave, lane, lda_b, ka, kda, a_crem);
+            stage_tile<TB>(rsb, nxt + TILE_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
         }
         LDS_AS const char* ta = lds + cur * STAGE_BYTES;
         LDS_AS const char* tb = ta + TILE_BYTES;
@@ -236,9 +259,10 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     MICO_CHECK(M > 0 && N > 0 && K > 0, "mico_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     MICO_CHECK(lda % 8 == 0 && ldb % 8 == 0, "mico_gemm: lda/ldb must be multiples of 8 elements (got %lld, %lld)", (long long)lda, (long long)ldb);
     MICO_CHECK(N % 4 == 0 && ldc % 4 == 0, "mico_gemm: N and ldc must be multiples of 4 (got %lld, %lld)", (long long)N, (long long)ldc);
-    if (!ta) MICO_CHECK(K % 8 == 0 && lda >= K, "mico_gemm: A[M,K] needs K %% 8 == 0 and lda >= K");
+    const bool segs = epi && epi->nseg > 0;
+    if (!ta) MICO_CHECK(K % 8 == 0 && (segs || lda >= K), "mico_gemm: A[M,K] needs K %% 8 == 0 and lda >= K");
     else MICO_CHECK(lda >= M, "mico_gemm: A^T[K,M] needs lda >= M");
-    if (!tb) MICO_CHECK(K % 8 == 0 && ldb >= K, "mico_gemm: B[N,K] needs K %% 8 == 0 and ldb >= K");
+    if (!tb) MICO_CHECK(K % 8 == 0 && (segs || ldb >= K), "mico_gemm: B[N,K] needs K %% 8 == 0 and ldb >= K");
     else MICO_CHECK(ldb >= N, "mico_gemm: B^T[K,N] needs ldb >= N");
     MICO_CHECK(c_dtype == MICO_F32 || c_dtype == dtype, "mico_gemm: c_dtype must be MICO_F32 or dtype");
     MICO_CHECK(128 * lda * 2 < 0x7FFFFFFFll && 128 * ldb * 2 < 0x7FFFFFFFll, "mico_gemm: leading dimension too large");
@@ -258,6 +282,17 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else {
         g.e = mico_gemm_epilogue{};
         g.e.alpha = 1.f;
+    }
+    g.ka_rows = g.kb_rows = K;
+    if (g.e.nseg > 0) {
+        MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % BK == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
+                   "mico_gemm: k-segments need nseg <= 3, kseg %% 64 == 0 and nseg * kseg == K");
+        g.ka_rows = g.kb_rows = 0;
+        for (int i = 0; i < g.e.nseg; ++i) {
+            MICO_CHECK(g.e.a_seg_off[i] % 8 == 0 && g.e.b_seg_off[i] % 8 == 0 && g.e.a_seg_off[i] >= 0 && g.e.b_seg_off[i] >= 0, "mico_gemm: bad segment offset");
+            if (g.e.a_seg_off[i] + g.e.kseg > g.ka_rows) g.ka_rows = g.e.a_seg_off[i] + g.e.kseg;
+            if (g.e.b_seg_off[i] + g.e.kseg > g.kb_rows) g.kb_rows = g.e.b_seg_off[i] + g.e.kseg;
+        }
     }
     if (g.split_k > 1) MICO_CHECK(c_dtype == MICO_F32 && g.e.accumulate, "mico_gemm: split_k > 1 needs fp32 accumulate output");
     if (g.e.act == MICO_ACT_GELU_GRAD) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD needs aux_in");

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            float* __restrict__ y32, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, int64_t rows, int cols, float eps,
                                                            const float* __restrict__ post_add, int post_rpg,
-                                                           int post_groups) {
+                                                           int post_groups, int split16) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
@@ -69,7 +69,16 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 f32x4 o = (v[i] - mean) * rstd * g + b;
                 if (pa) o += *(const f32x4*)(pa + c * 4);
                 if (y32) *(f32x4*)(y32 + row * cols + c * 4) = o;
-                if (y16) *(s16x4*)(y16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+                if (y16) {
+                    if (!split16) {
+                        *(s16x4*)(y16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+                    } else {   // [rows, 2*cols]: hi | lo halves (split-precision GEMM operand)
+                        const s16x4 hi = pack4<T>(o[0], o[1], o[2], o[3]);
+                        const f32x4 hf = unpack4<T>(hi);
+                        *(s16x4*)(y16 + row * 2 * cols + c * 4) = hi;
+                        *(s16x4*)(y16 + row * 2 * cols + cols + c * 4) = pack4<T>(o[0] - hf[0], o[1] - hf[1], o[2] - hf[2], o[3] - hf[3]);
+                    }
+                }
             }
         }
     }
@@ -183,8 +192,8 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
 
 template <typename T, typename XT>
 void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
-                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups) {
-#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups)
+                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16) {
+#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16)
     if (cols <= 1024) LNF(4);
     else if (cols <= 1536) LNF(6);
     else if (cols <= 2048) LNF(8);
@@ -209,7 +218,7 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows) { return ln_grid(rows); }
 
 extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* y32,
                                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add,
-                                  int post_rows_per_group, int post_groups, int dtype, void* stream) {
+                                  int post_rows_per_group, int post_groups, int y16_split, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
     MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
@@ -219,8 +228,8 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_grid(rows));
     DISPATCH_T16(dtype, {
-        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups);
-        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups);
+        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split);
+        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split);
     });
     MICO_LAUNCH_CHECK();
     return MICO_OK;

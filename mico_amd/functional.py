@@ -64,6 +64,31 @@ class TowerSpec:
         self.kpad1 = (self.P * self.P + 63) // 64 * 64
 
 
+def _ln16(x, g, b, eps, rows, cols, dt, dev):
+    """LayerNorm -> 16-bit GEMM operand.  Returns (buf, view, mean, rstd); in the split-precision (fp16 parity) mode buf is
+    [rows, 2*cols] = [hi | lo] and view its hi half."""
+    split = runtime.split_precision() and cols % 64 == 0
+    buf = _empty((rows, 2 * cols if split else cols), dt, dev)
+    mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+    ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt)
+    return buf, (buf[:, :cols] if split else buf), mean, rstd
+
+
+def _gemm_fwd(a_buf, a_cols, plist, tag, out, **epi):
+    """Forward GEMM out = a W^T: plain in the bf16 configuration; in the fp16 parity configuration the weight is hi|lo split
+    (and the activation too when its producer emitted [hi | lo]) and the products are summed by one k-segmented launch."""
+    w, ks = runtime.gemm_weight(plist, tag)
+    if ks is not None and a_buf.shape[1] == 2 * a_cols and a_cols == ks[0]:
+        ks = (ks[0], [0, a_cols, 0], [0, 0, ks[0]])
+    return ops.gemm(a_buf[:, :a_cols], w, out, ksegs=ks, **epi)
+
+
+def _qkv_params(P, b, arch):
+    if arch["subln"]:
+        return [P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")]
+    return [P(b + "attn.qkv.weight")]
+
+
 class EvaTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, groups, dp_scale, *params):
@@ -84,14 +109,11 @@ class EvaTowerFn(torch.autograd.Function):
         for g in groups:
             C = g.shape[1]
             kpad = spec.kpad3 if C == 3 else spec.kpad1
-            if C == 3:
-                w16 = runtime.w16(("pe3", id(pe_w)), [pe_w], lambda d: runtime.cast_weight(pe_w, d, k_pad=kpad))
-            else:
-                w16 = runtime.w16(("pe1", id(pe_w)), [pe_w], lambda d: runtime.cast_weight(pe_w.detach().sum(1), d, k_pad=kpad))
+            w16, ks = runtime.gemm_weight([pe_w], "pe3" if C == 3 else "pe1", k_pad=kpad, channel_sum=(C != 3))
             rows16 = _empty((g.shape[0] * np_, kpad), dt, dev)
             ops.im2row(g.contiguous().float(), rows16, spec.P, kpad)
             ops.gemm(rows16, w16, x[f0 * N:], M=g.shape[0] * np_, N=D, K=kpad, bias=pe_b, pos=pos2, pos_rows=N,
-                     remap=(np_, 1, 1))
+                     remap=(np_, 1, 1), ksegs=ks)
             saved_rows.append(rows16)
             f0 += g.shape[0]
         ops.cls_rows(x, Bf, N, P("cls_token").detach().reshape(D), pos2[0])
@@ -105,20 +127,11 @@ class EvaTowerFn(torch.autograd.Function):
             dp1 = dp_scale[i, 0].contiguous() if dp_scale is not None else None
             dp2 = dp_scale[i, 1].contiguous() if dp_scale is not None else None
             # --- attention branch ---
-            ln1 = _empty((M, D), dt, dev)
-            mean1, rstd1 = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
-            ops.layernorm_fwd(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, out16=ln1, mean=mean1, rstd=rstd1, dtype=dt)
-            if arch["subln"]:
-                wq, wk, wv = P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")
-                wqkv = runtime.w16(("qkv", id(wq)), [wq, wk, wv],
-                                   lambda d: runtime.cast_weight(torch.cat((wq.detach(), wk.detach(), wv.detach()), 0), d))
-            else:
-                wq = P(b + "attn.qkv.weight")
-                wqkv = runtime.w16(("qkv", id(wq)), [wq], lambda d: runtime.cast_weight(wq, d))
+            ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M, D, dt, dev)
             qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
             qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
             qkv = _empty((M, 3 * D), dt, dev)
-            ops.gemm(ln1, wqkv, qkv, bias=qkv_bias)
+            _gemm_fwd(ln1b, D, _qkv_params(P, b, arch), "qkv", qkv, bias=qkv_bias)
             if spec.rope is not None:
                 ops.rope(qkv, N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1])
                 ops.rope(qkv[:, D:], N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1])
@@ -127,46 +140,32 @@ class EvaTowerFn(torch.autograd.Function):
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
             proj_in = ao
             if arch["subln"]:
-                aln = _empty((M, D), dt, dev)
-                mean_a, rstd_a = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
-                ops.layernorm_fwd(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"), spec.eps,
-                                  out16=aln, mean=mean_a, rstd=rstd_a, dtype=dt)
+                proj_in, aln, mean_a, rstd_a = _ln16(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"),
+                                                     spec.eps, M, D, dt, dev)
                 a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
-                proj_in = aln
-            wp = P(b + "attn.proj.weight")
-            wp16 = runtime.w16(("w", id(wp)), [wp], lambda d: runtime.cast_weight(wp, d))
             x_mid = _empty((M, D), torch.float32, dev)
-            ops.gemm(proj_in, wp16, x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=dp1, rows_per_scale=N)
+            _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=dp1,
+                      rows_per_scale=N)
             # --- MLP branch ---
-            ln2 = _empty((M, D), dt, dev)
-            mean2, rstd2 = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
-            ops.layernorm_fwd(x_mid, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, out16=ln2, mean=mean2, rstd=rstd2, dtype=dt)
+            ln2b, ln2, mean2, rstd2 = _ln16(x_mid, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M, D, dt, dev)
             x_out = _empty((M, D), torch.float32, dev)
             Hd = spec.hidden
             if arch["swiglu"]:
-                w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
-                w1_16 = runtime.w16(("w", id(w1)), [w1], lambda d: runtime.cast_weight(w1, d))
-                w2_16 = runtime.w16(("w", id(w2)), [w2], lambda d: runtime.cast_weight(w2, d))
-                w3_16 = runtime.w16(("w", id(w3)), [w3], lambda d: runtime.cast_weight(w3, d))
                 x1, x2 = _empty((M, Hd), dt, dev), _empty((M, Hd), dt, dev)
-                ops.gemm(ln2, w1_16, x1, bias=P(b + "mlp.w1.bias"))
-                ops.gemm(ln2, w2_16, x2, bias=P(b + "mlp.w2.bias"))
+                _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1, bias=P(b + "mlp.w1.bias"))
+                _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2, bias=P(b + "mlp.w2.bias"))
                 hsw = _empty((M, Hd), dt, dev)
                 ops.swiglu_fwd(x1, x2, hsw)
-                hln = _empty((M, Hd), dt, dev)
-                mean_f, rstd_f = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
-                ops.layernorm_fwd(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, out16=hln,
-                                  mean=mean_f, rstd=rstd_f, dtype=dt)
-                ops.gemm(hln, w3_16, x_out, bias=P(b + "mlp.w3.bias"), resid=x_mid, row_scale=dp2, rows_per_scale=N)
+                hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M, Hd, dt, dev)
+                _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), resid=x_mid, row_scale=dp2,
+                          rows_per_scale=N)
                 a.update(x1=x1, x2=x2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
             else:
-                w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
-                w1_16 = runtime.w16(("w", id(w1)), [w1], lambda d: runtime.cast_weight(w1, d))
-                w2_16 = runtime.w16(("w", id(w2)), [w2], lambda d: runtime.cast_weight(w2, d))
                 h = _empty((M, Hd), dt, dev)
                 act = _empty((M, Hd), dt, dev)
-                ops.gemm(ln2, w1_16, act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
-                ops.gemm(act, w2_16, x_out, bias=P(b + "mlp.fc2.bias"), resid=x_mid, row_scale=dp2, rows_per_scale=N)
+                _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
+                _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), resid=x_mid, row_scale=dp2,
+                          rows_per_scale=N)
                 a.update(h=h, act=act)
             a.update(x_in=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, mean2=mean2,
                      rstd2=rstd2, ln2=ln2, dp1=dp1, dp2=dp2)
@@ -201,7 +200,7 @@ class EvaTowerFn(torch.autograd.Function):
             return grads[i]
 
         def w16_of(p):
-            return runtime.w16(("w", id(p)), [p], lambda d: runtime.cast_weight(p, d))
+            return runtime.gemm_weight([p])[0]
 
         strides3 = dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D),
                         o_strides=(N * D, D))
@@ -274,17 +273,14 @@ class EvaTowerFn(torch.autograd.Function):
             ops.colsum(dqkv, dbias, scale=inv_s)
             G(b + "attn.q_bias").add_(dbias[:D])
             G(b + "attn.v_bias").add_(dbias[2 * D:])
+            wqkv = runtime.gemm_weight(_qkv_params(P, b, arch), "qkv")[0]
             if arch["subln"]:
-                wq, wk, wv = P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")
-                wqkv = runtime.w16(("qkv", id(wq)), [wq, wk, wv], None)
                 dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
                 linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
                 G(b + "attn.q_proj.weight").add_(dwf[:D])
                 G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
                 G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
             else:
-                wq = P(b + "attn.qkv.weight")
-                wqkv = runtime.w16(("qkv", id(wq)), [wq], None)
                 linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
             dln1 = dln2
             ops.gemm(dqkv, wqkv, dln1, tb=True, M=M, N=D, K=3 * D)
@@ -487,9 +483,9 @@ class _CondPack(torch.autograd.Function):
         Dm = w.shape[0]
         x16 = _empty((rows, Dv), dt, dev)
         ops.cast_f32_to_16(feats.contiguous(), x16)
-        w16 = runtime.w16(("w", id(w)), [w], lambda d: runtime.cast_weight(w, d))
+        w16, ks = runtime.gemm_weight([w])
         u = _empty((rows, Dm), torch.float32, dev)
-        ops.gemm(x16, w16, u, bias=b.detach())
+        ops.gemm(x16, w16, u, bias=b.detach(), ksegs=ks)
         y = _empty((rows, Dm), torch.float32, dev)
         mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
         ops.layernorm_fwd(u, g.detach(), beta.detach(), 1e-12, out32=y, mean=mean, rstd=rstd, post_add=table.detach().contiguous(),
@@ -514,7 +510,7 @@ class _CondPack(torch.autograd.Function):
         linear_wgrad(du16, x16, dw, inv_s)
         db = torch.zeros(Dm, dtype=torch.float32, device=dev)
         ops.colsum(du16, db, scale=inv_s)
-        w16 = runtime.w16(("w", id(w)), [w], lambda d: runtime.cast_weight(w, d))
+        w16 = runtime.gemm_weight([w])[0]
         dx = _empty((rows, x16.shape[1]), torch.float32, dev)
         ops.gemm(du16, w16, dx, tb=True, M=rows, N=x16.shape[1], K=Dm, alpha=inv_s)
         # table gradient: rows are ordered (sample, frame slot, token): sum over samples, then over the tokens of a slot
@@ -544,8 +540,12 @@ class BertSpec:
 
 
 def _fused_w(key, plist, dt_unused=None):
-    return runtime.w16((key, id(plist[0])), plist,
-                       lambda d: runtime.cast_weight(torch.cat([p.detach() for p in plist], 0), d))
+    return runtime.gemm_weight(plist, key)[0]
+
+
+def _fwd_gemm(x, key, plist, out, **kw):
+    kin = plist[0].shape[1]
+    return _gemm_fwd(x, kin, plist, key, out, **kw)
 
 
 class BertFn(torch.autograd.Function):
@@ -562,10 +562,11 @@ class BertFn(torch.autograd.Function):
         emb = _empty((rows, D), torch.float32, dev)
         ops.bert_embed_fwd(ids, P("embeddings.word_embeddings.weight").detach(), P("embeddings.position_embeddings.weight").detach(),
                            P("embeddings.token_type_embeddings.weight").detach()[0].contiguous(), emb, S)
-        x32, x16 = _empty((rows, D), torch.float32, dev), _empty((rows, D), dt, dev)
+        split0 = runtime.split_precision()
+        x32, x16 = _empty((rows, D), torch.float32, dev), _empty((rows, 2 * D if split0 else D), dt, dev)
         mean_e, rstd_e = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
         ops.layernorm_fwd(emb, P("embeddings.LayerNorm.weight"), P("embeddings.LayerNorm.bias"), spec.eps, out16=x16, out32=x32,
-                          mean=mean_e, rstd=rstd_e, dtype=dt)
+                          mean=mean_e, rstd=rstd_e, split16=split0, dtype=dt)
         cond16 = None
         E = 0
         if cond is not None:
@@ -576,54 +577,56 @@ class BertFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(hd)
         acts = []
 
+        split = runtime.split_precision()
+
         def ln_out(u, pre):
-            o32, o16 = _empty((rows, D), torch.float32, dev), _empty((rows, D), dt, dev)
+            o32 = _empty((rows, D), torch.float32, dev)
+            o16 = _empty((rows, 2 * D if split else D), dt, dev)
             m_, r_ = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
-            ops.layernorm_fwd(u, P(pre + "LayerNorm.weight"), P(pre + "LayerNorm.bias"), spec.eps, out16=o16, out32=o32, mean=m_, rstd=r_, dtype=dt)
+            ops.layernorm_fwd(u, P(pre + "LayerNorm.weight"), P(pre + "LayerNorm.bias"), spec.eps, out16=o16, out32=o32, mean=m_, rstd=r_,
+                              split16=split, dtype=dt)
             return o32, o16, m_, r_
 
         for li in range(spec.L):
             p = f"encoder.layer.{li}."
-            a = dict(x16=x16)
+            a = dict(x16=x16[:, :D])
             sa = p + "attention.self."
-            wqkv = _fused_w("bqkv", [P(sa + "query.weight"), P(sa + "key.weight"), P(sa + "value.weight")])
             bqkv = torch.cat((P(sa + "query.bias").detach(), P(sa + "key.bias").detach(), P(sa + "value.bias").detach()))
             qkv = _empty((rows, 3 * D), dt, dev)
-            ops.gemm(x16, wqkv, qkv, bias=bqkv)
+            _fwd_gemm(x16, "bqkv", [P(sa + "query.weight"), P(sa + "key.weight"), P(sa + "value.weight")], qkv, bias=bqkv)
             co = _empty((rows, D), dt, dev)
             lse = _empty((b, H, S), torch.float32, dev)
             st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], co, lse, B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, **st)
             wo = P(p + "attention.output.dense.weight")
             u = _empty((rows, D), torch.float32, dev)
-            ops.gemm(co, _fused_w("w1", [wo]), u, bias=P(p + "attention.output.dense.bias"), resid=x32)
+            _fwd_gemm(co, "w1", [wo], u, bias=P(p + "attention.output.dense.bias"), resid=x32)
             x32, x16, m1, r1 = ln_out(u, p + "attention.output.")
             a.update(qkv=qkv, co=co, lse=lse, u=u, m1=m1, r1=r1)
             if cond16 is not None:
                 ca = p + "crossattention.self."
-                a["x16a"] = x16
+                a["x16a"] = x16[:, :D]
                 q = _empty((rows, D), dt, dev)
-                ops.gemm(x16, _fused_w("w1", [P(ca + "query.weight")]), q, bias=P(ca + "query.bias"))
-                wkv = _fused_w("bkv", [P(ca + "key.weight"), P(ca + "value.weight")])
+                _fwd_gemm(x16, "w1", [P(ca + "query.weight")], q, bias=P(ca + "query.bias"))
                 bkv = torch.cat((P(ca + "key.bias").detach(), P(ca + "value.bias").detach()))
                 kv = _empty((b * E, 2 * D), dt, dev)
-                ops.gemm(cond16, wkv, kv, bias=bkv)
+                _fwd_gemm(cond16, "bkv", [P(ca + "key.weight"), P(ca + "value.weight")], kv, bias=bkv)
                 cc = _empty((rows, D), dt, dev)
                 lse_c = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 ops.attn_fwd(q, kv, kv[:, D:], cc, lse_c, B=b, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None, **stc)
                 u2 = _empty((rows, D), torch.float32, dev)
-                ops.gemm(cc, _fused_w("w1", [P(p + "crossattention.output.dense.weight")]), u2,
-                         bias=P(p + "crossattention.output.dense.bias"), resid=x32)
+                _fwd_gemm(cc, "w1", [P(p + "crossattention.output.dense.weight")], u2,
+                          bias=P(p + "crossattention.output.dense.bias"), resid=x32)
                 x32, x16, m2, r2 = ln_out(u2, p + "crossattention.output.")
                 a.update(q=q, kv=kv, cc=cc, lse_c=lse_c, u2=u2, m2=m2, r2=r2)
-            a["x16b"] = x16
+            a["x16b"] = x16[:, :D]
             h = _empty((rows, I), dt, dev)
             act = _empty((rows, I), dt, dev)
-            ops.gemm(x16, _fused_w("w1", [P(p + "intermediate.dense.weight")]), act, bias=P(p + "intermediate.dense.bias"),
-                     aux_out=h, act=ops.ACT_GELU)
+            _fwd_gemm(x16, "w1", [P(p + "intermediate.dense.weight")], act, bias=P(p + "intermediate.dense.bias"),
+                      aux_out=h, act=ops.ACT_GELU)
             u3 = _empty((rows, D), torch.float32, dev)
-            ops.gemm(act, _fused_w("w1", [P(p + "output.dense.weight")]), u3, bias=P(p + "output.dense.bias"), resid=x32)
+            _fwd_gemm(act, "w1", [P(p + "output.dense.weight")], u3, bias=P(p + "output.dense.bias"), resid=x32)
             x32, x16, m3, r3 = ln_out(u3, p + "output.")
             a.update(h=h, act=act, u3=u3, m3=m3, r3=r3)
             acts.append(a)
@@ -764,15 +767,15 @@ class LMHeadLossFn(torch.autograd.Function):
         ops.cast_f32_to_16(x, x16)
         pre = _empty((rows, D), dt, dev)
         act = _empty((rows, D), dt, dev)
-        ops.gemm(x16, _fused_w("w1", [wt]), act, bias=bt.detach(), aux_out=pre, act=ops.ACT_GELU)
+        _fwd_gemm(x16, "w1", [wt], act, bias=bt.detach(), aux_out=pre, act=ops.ACT_GELU)
         hl = _empty((rows, D), dt, dev)
         mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
         ops.layernorm_fwd(act, g.detach(), beta.detach(), 1e-12, out16=hl, mean=mean, rstd=rstd, dtype=dt)
-        wd16 = runtime.w16(("wdec", id(wdec)), [wdec], lambda d: runtime.cast_weight(wdec, d, n_pad=Vp))
+        wd16, ksd = runtime.gemm_weight([wdec], "wdec", n_pad=Vp)
         bpad = torch.zeros(Vp, dtype=torch.float32, device=dev)
         bpad[:V] = bdec.detach()
         logits = _empty((rows, Vp), dt, dev)
-        ops.gemm(hl, wd16, logits, bias=bpad)
+        ops.gemm(hl, wd16, logits, bias=bpad, ksegs=ksd)
         row_loss = _empty((rows,), torch.float32, dev)
         ops.ce_fwd_bwd(logits, lab, cols=V, row_loss=row_loss)
         n_valid = (lab != -100).sum().clamp_min(1).float()
@@ -798,7 +801,7 @@ class LMHeadLossFn(torch.autograd.Function):
         linear_wgrad(dlog, hl, dwdec, inv_s, n_out=V, n_in=D)
         dbdec = torch.zeros(V, dtype=torch.float32, device=dev)
         ops.colsum(dlog, dbdec, cols=V, scale=inv_s)
-        wd16 = runtime.w16(("wdec", id(wdec)), [wdec], lambda d: runtime.cast_weight(wdec, d, n_pad=Vp))
+        wd16 = runtime.gemm_weight([wdec], "wdec", n_pad=Vp)[0]
         dhl = _empty((rows, D), dt, dev)
         ops.gemm(dlog, wd16, dhl, tb=True, M=rows, N=D, K=Vp)
         dact = _empty((rows, D), dt, dev)
@@ -830,14 +833,14 @@ class LMLogitsFn(torch.autograd.Function):
         x16 = _empty((rows, D), dt, dev)
         ops.cast_f32_to_16(x, x16)
         act = _empty((rows, D), dt, dev)
-        ops.gemm(x16, _fused_w("w1", [wt]), act, bias=bt.detach(), act=ops.ACT_GELU)
+        _fwd_gemm(x16, "w1", [wt], act, bias=bt.detach(), act=ops.ACT_GELU)
         hl = _empty((rows, D), dt, dev)
         ops.layernorm_fwd(act, g.detach(), beta.detach(), 1e-12, out16=hl, dtype=dt)
-        wd16 = runtime.w16(("wdec", id(wdec)), [wdec], lambda d: runtime.cast_weight(wdec, d, n_pad=Vp))
+        wd16, ksd = runtime.gemm_weight([wdec], "wdec", n_pad=Vp)
         bpad = torch.zeros(Vp, dtype=torch.float32, device=dev)
         bpad[:V] = bdec.detach()
         logits = _empty((rows, Vp), torch.float32, dev)
-        ops.gemm(hl, wd16, logits, bias=bpad)
+        ops.gemm(hl, wd16, logits, bias=bpad, ksegs=ksd)
         ctx.mark_non_differentiable(logits)
         return logits[:, :V].reshape(*seq.shape[:-1], V)
 

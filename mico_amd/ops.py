@@ -56,7 +56,7 @@ def pad8(n):
 
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
          row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
-         accumulate=False, split_k=1, dtype=None):
+         accumulate=False, split_k=1, dtype=None, ksegs=None):
     """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
     leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
     dtype = dtype or A.dtype
@@ -81,6 +81,11 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.remap_group, e.remap_skip, e.remap_offset = remap
     e.alpha = alpha
     e.accumulate = 1 if accumulate else 0
+    if ksegs is not None:   # (kseg, a_offsets, b_offsets)
+        e.kseg, e.nseg = ksegs[0], len(ksegs[1])
+        for i, (ao, bo) in enumerate(zip(ksegs[1], ksegs[2])):
+            e.a_seg_off[i], e.b_seg_off[i] = ao, bo
+        K = e.kseg * e.nseg
     timer = GEMM_TIMER
     timed = timer is not None and (int(ta), int(tb)) in timer.variants
     if timed:
@@ -96,11 +101,12 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
 
 
 def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
-                  post_rows_per_group=0, post_groups=0, dtype=torch.float16):
+                  post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16):
+    """split16: out16 is [rows, 2*cols] and receives [hi | lo] (split-precision GEMM operand)."""
     rows, cols = x.shape[0], x.shape[1]
     rc = _lib.lib().mico_layernorm_fwd(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(out32), _p(mean),
                                        _p(rstd), rows, cols, eps, _p(post_add), post_rows_per_group, post_groups,
-                                       dt_code(dtype), _st())
+                                       int(split16), dt_code(dtype), _st())
     check(rc, "mico_layernorm_fwd")
 
 

@@ -17,6 +17,9 @@ class _Cfg:
     # internal 16-bit gradients are carried multiplied by grad_scale (fp16 only: guards against underflow); every
     # function de-scales what it hands back, so autograd sees true-scale fp32 gradients.
     grad_scale = {torch.float16: 4096.0, torch.bfloat16: 1.0}
+    # fp16 parity configuration: forward GEMMs use hi/lo split weights (x W_hi + x W_lo in one launch through the kernel's
+    # k-segments), which removes the weight-rounding half of the fp16 GEMM error.  Off for bf16 (throughput configuration).
+    split_fp16 = True
 
 
 CFG = _Cfg()
@@ -74,3 +77,40 @@ def cast_weight(w, dt, k_pad=None, n_pad=None):
         (N, kp), dtype=dt, device=w.device)
     ops.cast_f32_to_16(w2.contiguous(), out[:N], cols=K, cols_pad=kp)
     return out
+
+
+def split_precision():
+    return CFG.compute_dtype == torch.float16 and CFG.split_fp16
+
+
+def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False):
+    """16-bit GEMM weight for nn.Linear-style parameters (rows of all `plist` entries concatenated).
+    Returns (w16, ksegs): w16 is the [N(_pad), Kp] operand (a strided view of the [N, 2 Kp] hi|lo buffer in split-precision
+    mode), ksegs the k-segment descriptor for *forward* launches (None in plain mode)."""
+    split = split_precision()
+
+    def build(dt):
+        w = plist[0].detach() if len(plist) == 1 else torch.cat([p.detach() for p in plist], 0)
+        if channel_sum:
+            w = w.sum(1)
+        w2 = w.reshape(w.shape[0], -1).float().contiguous()
+        N, K = w2.shape
+        kp = k_pad or ops.pad8(K)
+        do_split = split and kp % 64 == 0   # k-segments need 64-element segments; every GEMM weight on the path has that
+        rows = n_pad or N
+        out = torch.zeros((rows, 2 * kp if do_split else kp), dtype=dt, device=w.device)
+        ops.cast_f32_to_16(w2, out[:N], cols=K, cols_pad=kp)
+        out._mico_split = do_split
+        if do_split:
+            hi32 = torch.zeros((N, kp), dtype=torch.float32, device=w.device)
+            ops.cast_16_to_f32(out[:N, :kp], hi32)
+            resid = torch.zeros((N, kp), dtype=torch.float32, device=w.device)
+            resid[:, :K] = w2 - hi32[:, :K]
+            ops.cast_f32_to_16(resid, out[:N, kp:], cols=kp, cols_pad=kp)
+        return out
+
+    buf = w16((tag, id(plist[0]), k_pad, n_pad, split), plist, build)
+    if getattr(buf, "_mico_split", False):
+        kp = buf.shape[1] // 2
+        return buf[:, :kp], (kp, [0, 0], [0, kp])
+    return buf, None
