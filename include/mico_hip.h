@@ -39,6 +39,8 @@ const char* mico_last_error_string(void);
  *    its input gradient  dx = dy W        is (ta=0,tb=1, A=dy, B=W);
  *    its weight gradient dW = dy^T x      is (ta=1,tb=1, A=dy, B=x) with M=out_features, N=in_features.
  * All leading dimensions and K-contiguous extents must be multiples of 8 elements (16-byte rows).
+ * split_k: 1 = none; > 1 = explicit (fp32 accumulate output only, partial tiles combined with atomics); <= 0 = automatic
+ * (sized so the resident workgroups are filled in whole waves).
  *
  * Epilogue (applied per element v = alpha * acc, in this order):
  *   v += bias[n]                              (bias  != NULL, fp32 [N])

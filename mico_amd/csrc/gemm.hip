@@ -1,25 +1,38 @@
 // MFMA GEMM for gfx950 with fused epilogues (see include/mico_hip.h: mico_gemm).
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA 16x16x32 tiles),
-// BK = 64.  Operand tiles are brought HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B/lane, no VGPR round trip)
-// into a 2-stage ring; the buffer descriptor's bounds check zero-fills rows past the end of the matrix, so M/N/K
-// tails need no masking code in the main loop.  LDS images are lane-linear (DMA constraint); bank conflicts are
-// removed by XOR-swizzling the 16-byte chunk index on the *source* address and applying the same involution on the
-// read side.  K-contiguous operands are read with ds_read_b128, reduction-major operands (dX / dW GEMMs) with the
-// gfx950 transposing read ds_read_b64_tr_b16, so the backward GEMMs need no transposed copies of weights or
-// activations in HBM.  MFMA operands are swapped (D^T = B A^T) so every lane owns 4 consecutive columns of one
-// output row: 8/16-byte epilogue accesses.  Workgroup ids are remapped XCD-contiguously (8 private L2s) and walk the
-// tile grid in groups of 8 row-panels so concurrently resident tiles share A and B panels in L2.
+// Two tile configurations of one kernel template:
+//   * BIG   256x128x64, 8 waves (4x2, 64x64 per wave), 3-stage LDS ring (144 KiB, one workgroup per CU).  Operand tiles for
+//           K-tile t+2 are in flight while tile t is multiplied: the LDS-DMA queue is never drained inside the main loop -
+//           counted `s_waitcnt vmcnt(6)` (the 6 DMA instructions of the newest tile stay outstanding) + raw `s_barrier`.
+//           This is the path of every large GEMM (M = frames x tokens rows).
+//   * SMALL 128x128x64, 4 waves (2x2), 2-stage ring, two workgroups per CU: short-M problems (BERT text GEMMs, heads).
+// Common to both: operand tiles go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B/lane, no VGPR round trip);
+// the buffer descriptor's bounds check zero-fills rows past the end of the matrix, so M/N/K tails need no masking in the
+// main loop.  LDS images are lane-linear (DMA constraint); bank conflicts are removed by XOR-swizzling the 16-byte chunk
+// index on the *source* address and applying the same involution on the read side (measured: SQ_LDS_BANK_CONFLICT = 0).
+// K-contiguous operands are read with ds_read_b128, reduction-major operands (dX / dW GEMMs) with the gfx950 transposing
+// read ds_read_b64_tr_b16, so the backward GEMMs need no transposed copies of weights or activations in HBM.  MFMA
+// operands are swapped (D^T = B A^T) so every lane owns 4 consecutive columns of one output row: 8/16-byte epilogue
+// accesses.  Workgroup ids are remapped XCD-contiguously (8 private L2s) and walk the tile grid in groups of row-panels so
+// concurrently resident tiles share A and B panels in L2.  Long-reduction weight-gradient GEMMs are split along K in whole
+// waves of resident workgroups and combined with fp32 atomics.
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;   // 16 KiB per operand tile, either orientation
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
+
+template <int BM_, int STAGES_> struct TileCfg {
+    static constexpr int BM = BM_, BN = 128, STAGES = STAGES_;
+    static constexpr int WAVES = BM / 64 * 2, THREADS = WAVES * 64;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_DMA = A_BYTES / 16 / THREADS, B_DMA = B_BYTES / 16 / THREADS;   // DMA instructions per thread per tile
+};
+using Big = TileCfg<256, 3>;
+using Small = TileCfg<128, 2>;
 
 struct GemmArgs {
     const char* A;
@@ -33,16 +46,17 @@ struct GemmArgs {
 };
 
 // swizzle keys (16-byte chunk index XOR) - see file header
-__device__ __forceinline__ int key_kc(int row) { return (row >> 1) & 7; }                               // [128][64] k-contiguous
-__device__ __forceinline__ int key_tr(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }   // [64][128] reduction-major
+__device__ __forceinline__ int key_kc(int row) { return (row >> 1) & 7; }                               // [rows][64] k-contiguous
+__device__ __forceinline__ int key_tr(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }   // [64][cols] reduction-major
 
-template <bool TR>
+// one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim (BM or BN).
+template <bool TR, int ROWS, int THREADS>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, int lane,
                                            int64_t ld_bytes, int k0, int64_t kdim, int64_t cdim_rem) {
-    // one tile = 1024 chunks of 16 B; 4 DMA instructions per thread
+    constexpr int NDMA = ROWS * BK * 2 / 16 / THREADS;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int c = it * 256 + wave * 64 + lane;
+    for (int it = 0; it < NDMA; ++it) {
+        const int c = it * THREADS + wave * 64 + lane;
         unsigned voff;
         if (!TR) {
             const int row = c >> 3, cpos = c & 7;
@@ -51,29 +65,31 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS cha
             voff = (unsigned)(row * ld_bytes + (int64_t)k * 2);
             if (k >= kdim) voff = 0xFFFFFFF0u;   // K tail: force out-of-bounds -> zero fill
         } else {
-            const int row = c >> 4, cpos = c & 15;
+            constexpr int CPR = ROWS / 8;       // 16-byte chunks per tile row
+            const int row = c / CPR, cpos = c % CPR;
             const int cg = cpos ^ key_tr(row);
             voff = (unsigned)((int64_t)(k0 + row) * ld_bytes + cg * 16);
             if (cg * 8 >= cdim_rem || (k0 + row) >= kdim) voff = 0xFFFFFFF0u;
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * 256 + wave * 64) * 16), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), 16, voff, 0, 0, 0);
     }
 }
 
 // MFMA fragment (8 x 16-bit along the reduction dim) for 16 tile rows starting at `r0`, k-step kk (0/1)
-template <bool TR>
+template <bool TR, int ROWS>
 __device__ __forceinline__ s16x8 read_frag(LDS_AS const char* tile, int r0, int kk, int lane) {
     if (!TR) {
         const int row = r0 + (lane & 15);
         const int cg = kk * 4 + (lane >> 4);
         return *(LDS_AS const s16x8*)(tile + row * 128 + ((cg ^ key_kc(row)) << 4));
     } else {
+        constexpr int RB = ROWS * 2;   // bytes per k-row
         const int kb = kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2);
         const int chunk = (r0 >> 3) + ((lane >> 1) & 1);
         const int half = (lane & 1) * 8;
         const int k0r = kb, k1r = kb + 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + k0r * 256 + ((chunk ^ key_tr(k0r)) << 4) + half));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + k1r * 256 + ((chunk ^ key_tr(k1r)) << 4) + half));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + k0r * RB + ((chunk ^ key_tr(k0r)) << 4) + half));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + k1r * RB + ((chunk ^ key_tr(k1r)) << 4) + half));
         s16x8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -81,9 +97,187 @@ __device__ __forceinline__ s16x8 read_frag(LDS_AS const char* tile, int r0, int 
     }
 }
 
-template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+// ---- register-lean addressing for the ping-pong (BIG) path --------------------------------------------------------------
+// Per lane and operand only two LDS byte offsets (k-step 0 / 1) are kept; the four 16-row tiles of a wave are reached by an
+// immediate (+i*2048, k-contiguous image) or an XOR (^(i<<5), reduction-major image) and the second transposing read by a
+// constant (+4 rows).  These identities follow from the swizzle keys: key_kc depends on (row>>1)&7 only, hence not on the
+// 16-row tile index; key_tr is identical for rows r and r+4 inside an 8-row group and only touches chunk bits 1-3.
+struct FragBase { int b0, b1; };
+
+template <bool TR, int ROWS>
+__device__ __forceinline__ FragBase frag_base(int wbase, int lane) {
+    FragBase f;
+    const int g = lane >> 4, p = lane & 15;
+    if (!TR) {
+        const int keyl = (p >> 1) & 7;
+        const int base = (wbase + p) * 128;
+        f.b0 = base + ((g ^ keyl) << 4);
+        f.b1 = base + (((4 + g) ^ keyl) << 4);
+    } else {
+        constexpr int RB = ROWS * 2;
+        const int key0 = ((p >> 2) | ((g & 1) << 2)) << 1;
+        const int col = ((((wbase >> 3) + ((lane >> 1) & 1)) ^ key0) << 4) + (lane & 1) * 8;
+        f.b0 = (g * 8 + (p >> 2)) * RB + col;
+        f.b1 = (32 + g * 8 + (p >> 2)) * RB + col;
+    }
+    return f;
+}
+
+template <bool TR, int ROWS>
+__device__ __forceinline__ s16x8 read_frag_b(LDS_AS const char* tile, int base, int i) {
+    if (!TR) {
+        return *(LDS_AS const s16x8*)(tile + base + i * 2048);
+    } else {
+        constexpr int RB = ROWS * 2;
+        LDS_AS const char* a = tile + (base ^ (i << 5));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(a + 4 * RB));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+// loop-invariant per-lane DMA offsets of one operand tile (k0 = 0); 0xFFFFFFF0 marks a chunk past the matrix edge
+template <bool TR, int ROWS, int THREADS, int NDMA>
+__device__ __forceinline__ void dma_offsets(unsigned (&vo)[NDMA], int wave, int lane, int64_t ld_bytes, int64_t cdim_rem) {
+#pragma unroll
+    for (int it = 0; it < NDMA; ++it) {
+        const int c = it * THREADS + wave * 64 + lane;
+        if (!TR) {
+            const int row = c >> 3, cpos = c & 7;
+            vo[it] = (unsigned)(row * ld_bytes + ((cpos ^ key_kc(row)) << 4));
+        } else {
+            constexpr int CPR = ROWS / 8;
+            const int row = c / CPR, cpos = c % CPR;
+            const int cg = cpos ^ key_tr(row);
+            vo[it] = (cg * 8 >= cdim_rem) ? 0xFFFFFFF0u : (unsigned)(row * ld_bytes + cg * 16);
+        }
+    }
+}
+
+template <int THREADS, int NDMA>
+__device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, const unsigned (&vo)[NDMA],
+                                          unsigned koff) {
+#pragma unroll
+    for (int it = 0; it < NDMA; ++it) {
+        const unsigned v = (vo[it] == 0xFFFFFFF0u) ? 0xFFFFFFF0u : vo[it] + koff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), 16, v, 0, 0, 0);
+    }
+}
+
+// Epilogue through LDS: the MFMA layout gives a lane 4 consecutive columns of 16 different rows (32-byte row segments per
+// store instruction - measured as ~14 us of fixed cost per 256x128 tile, i.e. a write-bandwidth-bound tail at ~1.2 TB/s).
+// Each wave therefore parks its 64x64 fp32 accumulator tile in LDS (16 KiB, XOR-swizzled 16-byte chunks, conflict free both
+// ways) and re-reads it so that a lane owns 16 consecutive columns of one row: bias / residual / auxiliary loads and the
+// stores are then 32-64 contiguous bytes per lane and 128-256 contiguous bytes per row - whole cache lines.
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], LDS_AS char* lds, int64_t m0, int64_t n0,
+                                              int wave, int wm, int wn, int lane) {
+    const mico_gemm_epilogue& e = g.e;
+    LDS_AS char* wbuf = lds + wave * 16384;
+    __syncthreads();   // every wave is done with the operand tiles (and the DMA queue is empty) before LDS is reused
+    {
+        const int p = lane & 15, gq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = i * 16 + p, cc = j * 4 + gq;
+                *(LDS_AS f32x4*)(wbuf + row * 256 + ((cc ^ p) << 4)) = acc[i][j] * e.alpha;
+            }
+    }
+    const int q = lane & 3;
+    const int64_t n = n0 + wn * 64 + q * 16;
+    if (n >= g.N) return;
+    const int nvec = (int)min((int64_t)4, (g.N - n) >> 2);   // valid 4-column groups of this lane (N % 4 == 0)
+    f32x4 bias4[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && v < nvec) ? *(const f32x4*)(e.bias + n + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 16 + (lane >> 2);
+        const int64_t m = m0 + wm * 64 + row;
+        if (m >= g.M) continue;
+        int64_t mo = m;
+        if (e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
+        float rscale = 1.f;
+        if (e.row_scale) rscale = e.row_scale[m / e.rows_per_scale];
+        f32x4 v4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + (((q * 4 + v) ^ (row & 15)) << 4)) + bias4[v];
+        if (e.aux_out) {
+            T* ap = (T*)e.aux_out + m * e.ldaux + n;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (v < nvec) *(s16x4*)(ap + v * 4) = pack4<T>(v4[v][0], v4[v][1], v4[v][2], v4[v][3]);
+        }
+        if (e.act == MICO_ACT_GELU) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { v4[v][0] = gelu_f(v4[v][0]); v4[v][1] = gelu_f(v4[v][1]); v4[v][2] = gelu_f(v4[v][2]); v4[v][3] = gelu_f(v4[v][3]); }
+        } else if (e.act == MICO_ACT_GELU_GRAD) {
+            const T* hp = (const T*)e.aux_in + m * e.ldaux + n;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (v < nvec) {
+                    const f32x4 h = unpack4<T>(*(const s16x4*)(hp + v * 4));
+                    v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (v >= nvec) continue;
+            f32x4 x = v4[v] * rscale;
+            if (e.pos) x += *(const f32x4*)(e.pos + (mo % e.pos_rows) * g.N + n + v * 4);
+            if (e.resid) x += *(const f32x4*)(e.resid + mo * g.ldc + n + v * 4);
+            if (g.c_dtype == MICO_F32) {
+                float* cp = (float*)g.C + mo * g.ldc + n + v * 4;
+                if (e.accumulate) {
+                    if (g.split_k > 1) {
+                        unsafeAtomicAdd(cp + 0, x[0]); unsafeAtomicAdd(cp + 1, x[1]);
+                        unsafeAtomicAdd(cp + 2, x[2]); unsafeAtomicAdd(cp + 3, x[3]);
+                    } else {
+                        *(f32x4*)cp += x;
+                    }
+                } else {
+                    *(f32x4*)cp = x;
+                }
+            } else {
+                *(s16x4*)((T*)g.C + mo * g.ldc + n + v * 4) = pack4<T>(x[0], x[1], x[2], x[3]);
+            }
+        }
+    }
+}
+
+// Direct (register-layout) epilogue for split-K partial tiles: alpha-scaled fp32 atomics straight from the MFMA layout
+// (4 consecutive columns per lane).  Measured 2x faster for atomics than the LDS-transposed 16-column form.
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& g, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn,
+                                                     int lane) {
+    const mico_gemm_epilogue& e = g.e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            const f32x4 v = acc[i][j] * e.alpha;
+            float* cp = (float*)g.C + m * g.ldc + n;
+            unsafeAtomicAdd(cp + 0, v[0]); unsafeAtomicAdd(cp + 1, v[1]);
+            unsafeAtomicAdd(cp + 2, v[2]); unsafeAtomicAdd(cp + 3, v[3]);
+        }
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, bool TA, bool TB, typename CFG>
+__global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, STAGES = CFG::STAGES, THREADS = CFG::THREADS;
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * CFG::STAGE_BYTES];
     LDS_AS char* lds = (LDS_AS char*)smem;
 
     const int lane = threadIdx.x & 63;
@@ -133,107 +327,163 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // logical k-tile -> physical k offsets of A and B.  With k-segments (split-precision GEMMs) the logical reduction is
     // the concatenation of nseg segments of kseg elements, each mapped to its own physical column offset per operand.
     const int nseg = g.e.nseg, kseg = g.e.kseg;
-    auto kmap = [&](int kt, int& ka, int& kb, int64_t& kda, int64_t& kdb) {
+    auto stage = [&](int kt, int buf) {
         const int k0 = kt * BK;
+        int ka = k0, kb = k0;
+        int64_t kda = g.K, kdb = g.K;
         if (nseg > 0) {
             const int sg = k0 / kseg, kin = k0 - sg * kseg;
             ka = g.e.a_seg_off[sg] + kin;
             kb = g.e.b_seg_off[sg] + kin;
             kda = g.e.a_seg_off[sg] + kseg;
             kdb = g.e.b_seg_off[sg] + kseg;
-        } else {
-            ka = kb = k0;
-            kda = kdb = g.K;
         }
+        LDS_AS char* dst = lds + buf * CFG::STAGE_BYTES;
+        stage_tile<TA, BM, THREADS>(rsa, dst, wave, lane, lda_b, ka, kda, a_crem);
+        stage_tile<TB, BN, THREADS>(rsb, dst + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
     };
-    int cur = 0;
-    if (kt0 < kt1) {
-        int ka, kb;
-        int64_t kda, kdb;
-        kmap(kt0, ka, kb, kda, kdb);
-        stage_tile<TA>(rsa, lds, wave, lane, lda_b, ka, kda, a_crem);
-        stage_tile<TB>(rsb, lds + TILE_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
-    }
-    for (int kt = kt0; kt < kt1; ++kt) {
-        __syncthreads();   // stage `cur` landed (vmcnt(0) precedes the barrier); stage cur^1 no longer being read
-        if (kt + 1 < kt1) {
-            LDS_AS char* nxt = lds + (cur ^ 1) * STAGE_BYTES;
-            int ka, kb;
-            int64_t kda, kdb;
-            kmap(kt + 1, ka, kb, kda, kdb);
-            stage_tile<TA>(rsa, nxt, wave, lane, lda_b, ka, kda, a_crem);
-            stage_tile<TB>(rsb, nxt + TILE_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
-        }
-        LDS_AS const char* ta = lds + cur * STAGE_BYTES;
-        LDS_AS const char* tb = ta + TILE_BYTES;
+    s16x8 fa[2][4], fb[2][4];   // all fragments of one K-tile (2 k-steps x 4 row tiles per operand)
+    auto read_frags = [&](int buf) {
+        LDS_AS const char* ta = lds + buf * CFG::STAGE_BYTES;
+        LDS_AS const char* tb = ta + CFG::A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            s16x8 fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag<TA>(ta, wm * 64 + i * 16, kk, lane);
+            for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag<TA, BM>(ta, wm * 64 + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = read_frag<TB>(tb, wn * 64 + j * 16, kk, lane);
+            for (int j = 0; j < 4; ++j) fb[kk][j] = read_frag<TB, BN>(tb, wn * 64 + j * 16, kk, lane);
+        }
+    };
+    auto mma_frags = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[j], fa[i], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[kk][j], fa[kk][i], acc[i][j]);
+    };
+
+    if constexpr (STAGES == 2) {
+        int cur = 0;
+        if (kt0 < kt1) stage(kt0, 0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            __syncthreads();   // stage `cur` landed (vmcnt(0) precedes the barrier); stage cur^1 no longer being read
+            if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+            read_frags(cur);
+            mma_frags();
+            cur ^= 1;
         }
-        cur ^= 1;
+    } else {
+        // 3-stage ring (prefetch distance 2: the LDS-DMA queue is never drained in steady state - counted vmcnt + raw
+        // s_barrier) with a PING-PONG schedule: the 8 waves form two groups of 4 (waves w and w+4 share a SIMD).  Each
+        // K-tile takes two barrier-separated phases; in every phase one group issues its 16 LDS fragment reads for the tile
+        // while the other group runs its 32 MFMAs on fragments read one phase earlier, so the matrix pipe of every SIMD is
+        // always fed by one wave while its partner's LDS latency is hidden behind it:
+        //     phase 2t   : group0 reads tile t      | group1 MFMAs tile t-1
+        //     phase 2t+1 : group0 MFMAs tile t      | group1 reads tile t
+        // Tile t+2's DMA is issued at the start of phase 2t into the buffer whose last reader (group1, tile t-1) finished
+        // before that phase's barrier.
+        constexpr int PER_TILE = CFG::A_DMA + CFG::B_DMA;
+        const int grp = wave >> 2;
+        const int T_ = kt1 - kt0;
+        const FragBase ab = frag_base<TA, BM>(wm * 64, lane), bb = frag_base<TB, BN>(wn * 64, lane);
+        unsigned voa[CFG::A_DMA], vob[CFG::B_DMA];
+        dma_offsets<TA, BM, THREADS, CFG::A_DMA>(voa, wave, lane, lda_b, a_crem);
+        dma_offsets<TB, BN, THREADS, CFG::B_DMA>(vob, wave, lane, ldb_b, b_crem);
+        const bool ktail = (g.K % BK) != 0;   // only then can a k-contiguous operand need per-chunk K masking
+        auto stage_fast = [&](int kt, int bo) {
+            const int k0 = kt * BK;
+            int ka = k0, kb = k0;
+            if (nseg > 0) {
+                const int sg = k0 / kseg, kin = k0 - sg * kseg;
+                ka = g.e.a_seg_off[sg] + kin;
+                kb = g.e.b_seg_off[sg] + kin;
+            }
+            if (ktail && kt == g.ktiles - 1) {
+                stage(kt, bo / CFG::STAGE_BYTES);
+                return;
+            }
+            const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
+            const unsigned kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
+            dma_issue<THREADS, CFG::A_DMA>(rsa, lds + bo, wave, voa, koa);
+            dma_issue<THREADS, CFG::B_DMA>(rsb, lds + bo + CFG::A_BYTES, wave, vob, kob);
+        };
+        auto read_pp = [&](int bo) {
+            LDS_AS const char* ta = lds + bo;
+            LDS_AS const char* tb = ta + CFG::A_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[0][i] = read_frag_b<TA, BM>(ta, ab.b0, i); fa[1][i] = read_frag_b<TA, BM>(ta, ab.b1, i); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { fb[0][j] = read_frag_b<TB, BN>(tb, bb.b0, j); fb[1][j] = read_frag_b<TB, BN>(tb, bb.b1, j); }
+        };
+        if (T_ > 0) stage_fast(kt0, 0);
+        if (T_ > 1) stage_fast(kt0 + 1, CFG::STAGE_BYTES);
+        // The two groups run separate, straight-line loops (same barrier count per iteration) so the fragment registers have
+        // one unambiguous live range each - a shared loop with per-phase role branches made the allocator keep two copies.
+        auto head = [&](int t, int bo) {   // top of K-tile t: tile t landed everywhere, then queue tile t+2
+            if (t + 1 < T_) wait_vmcnt<PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < T_) stage_fast(kt0 + t + 2, bo >= CFG::STAGE_BYTES ? bo - CFG::STAGE_BYTES : 2 * CFG::STAGE_BYTES);
+        };
+        auto mid = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int bo = 0;   // byte offset of the buffer holding tile t (kept opaque so LDS addresses are not hoisted x3)
+        if (grp == 0) {
+            for (int t = 0; t < T_; ++t) {
+                asm volatile("" : "+s"(bo));
+                head(t, bo);
+                read_pp(bo);
+                mid();
+                mma_frags();
+                __builtin_amdgcn_sched_barrier(0);
+                bo = bo == 2 * CFG::STAGE_BYTES ? 0 : bo + CFG::STAGE_BYTES;
+            }
+        } else {
+            for (int t = 0; t < T_; ++t) {
+                asm volatile("" : "+s"(bo));
+                head(t, bo);
+                if (t > 0) mma_frags();
+                mid();
+                read_pp(bo);
+                __builtin_amdgcn_sched_barrier(0);
+                bo = bo == 2 * CFG::STAGE_BYTES ? 0 : bo + CFG::STAGE_BYTES;
+            }
+            if (T_ > 0) mma_frags();
+        }
     }
 
-    // ---- epilogue: lane owns C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
-    const mico_gemm_epilogue& e = g.e;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
-        int64_t mo = m;
-        if (e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
-        float rscale = 1.f;
-        if (e.row_scale) rscale = e.row_scale[m / e.rows_per_scale];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
-            f32x4 v = acc[i][j] * e.alpha;
-            if (e.bias) v += *(const f32x4*)(e.bias + n);
-            if (e.aux_out) *(s16x4*)((T*)e.aux_out + m * e.ldaux + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-            if (e.act == MICO_ACT_GELU) {
-                v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
-            } else if (e.act == MICO_ACT_GELU_GRAD) {
-                f32x4 h = unpack4<T>(*(const s16x4*)((const T*)e.aux_in + m * e.ldaux + n));
-                v[0] *= gelu_grad_f(h[0]); v[1] *= gelu_grad_f(h[1]); v[2] *= gelu_grad_f(h[2]); v[3] *= gelu_grad_f(h[3]);
-            }
-            v *= rscale;
-            if (e.pos) v += *(const f32x4*)(e.pos + (mo % e.pos_rows) * g.N + n);
-            if (e.resid) v += *(const f32x4*)(e.resid + mo * g.ldc + n);
-            if (g.c_dtype == MICO_F32) {
-                float* cp = (float*)g.C + mo * g.ldc + n;
-                if (e.accumulate) {
-                    if (g.split_k > 1) {
-                        unsafeAtomicAdd(cp + 0, v[0]); unsafeAtomicAdd(cp + 1, v[1]);
-                        unsafeAtomicAdd(cp + 2, v[2]); unsafeAtomicAdd(cp + 3, v[3]);
-                    } else {
-                        *(f32x4*)cp += v;
-                    }
-                } else {
-                    *(f32x4*)cp = v;
-                }
-            } else {
-                *(s16x4*)((T*)g.C + mo * g.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
+    // split-K partials carry no bias / activation / residual (checked on the host side): plain atomics
+    if (g.split_k > 1) gemm_epilogue_atomic<T>(g, acc, m0, n0, wm, wn, lane);
+    else gemm_epilogue<T>(g, acc, lds, m0, n0, wave, wm, wn, lane);
 }
 
-template <typename T>
-int launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
-    const dim3 grid(g.ntiles * g.split_k), block(256);
-    if (!ta && !tb) MICO_LAUNCH((gemm_kernel<T, false, false>), grid, block, 0, st, g);
-    else if (!ta && tb) MICO_LAUNCH((gemm_kernel<T, false, true>), grid, block, 0, st, g);
-    else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true>), grid, block, 0, st, g);
-    else MICO_LAUNCH((gemm_kernel<T, true, false>), grid, block, 0, st, g);
-    return 0;
+template <typename T, typename CFG>
+void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
+    const dim3 grid(g.ntiles * g.split_k), block(CFG::THREADS);
+    if (!ta && !tb) MICO_LAUNCH((gemm_kernel<T, false, false, CFG>), grid, block, 0, st, g);
+    else if (!ta && tb) MICO_LAUNCH((gemm_kernel<T, false, true, CFG>), grid, block, 0, st, g);
+    else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true, CFG>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_kernel<T, true, false, CFG>), grid, block, 0, st, g);
+}
+
+// split factor for fp32-accumulating (weight-gradient) GEMMs: fill `slots` resident workgroups in whole waves.
+// cost(s) = waves(s) * (k-tiles per split + fixed prologue / atomic-epilogue cost in k-tile units)
+int auto_split(int tiles, int ktiles, int slots) {
+    int best = 1;
+    long best_cost = -1;
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && ktiles / s < 16) break;
+        const long waves = ((long)tiles * s + slots - 1) / slots;
+        const long cost = waves * ((ktiles + s - 1) / s + 12);
+        if (best_cost < 0 || cost < best_cost) { best = s; best_cost = cost; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -248,7 +498,7 @@ int mico_set_err(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int mico_version(void) { return 100; }
+extern "C" int mico_version(void) { return 101; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
@@ -265,24 +515,29 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (!tb) MICO_CHECK(K % 8 == 0 && (segs || ldb >= K), "mico_gemm: B[N,K] needs K %% 8 == 0 and ldb >= K");
     else MICO_CHECK(ldb >= N, "mico_gemm: B^T[K,N] needs ldb >= N");
     MICO_CHECK(c_dtype == MICO_F32 || c_dtype == dtype, "mico_gemm: c_dtype must be MICO_F32 or dtype");
-    MICO_CHECK(128 * lda * 2 < 0x7FFFFFFFll && 128 * ldb * 2 < 0x7FFFFFFFll, "mico_gemm: leading dimension too large");
-    if (split_k < 1) split_k = 1;
+    MICO_CHECK(256 * lda * 2 < 0x7FFFFFFFll && 256 * ldb * 2 < 0x7FFFFFFFll, "mico_gemm: leading dimension too large");
     GemmArgs g;
     g.A = (const char*)A; g.B = (const char*)B; g.C = (char*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
-    g.ntiles = g.ntm * g.ntn;
-    g.ktiles = (int)((K + BK - 1) / BK);
-    if (split_k > g.ktiles) split_k = g.ktiles;
-    g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
-    split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
-    g.split_k = split_k;
     g.c_dtype = c_dtype;
     if (epi) g.e = *epi;
     else {
         g.e = mico_gemm_epilogue{};
         g.e.alpha = 1.f;
     }
+    // tile configuration: the 256x128 3-stage kernel whenever it yields at least ~one workgroup per CU
+    const int64_t big_tiles = ((M + 255) / 256) * ((N + 127) / 128);
+    const bool big = big_tiles >= 192;
+    const int BM = big ? 256 : 128, BN = 128;
+    const int slots = big ? 256 : 512;
+    g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
+    g.ntiles = g.ntm * g.ntn;
+    g.ktiles = (int)((K + BK - 1) / BK);
+    if (split_k <= 0) split_k = (c_dtype == MICO_F32 && g.e.accumulate) ? auto_split(g.ntiles, g.ktiles, slots) : 1;
+    if (split_k > g.ktiles) split_k = g.ktiles;
+    g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
+    split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
+    g.split_k = split_k;
     g.ka_rows = g.kb_rows = K;
     if (g.e.nseg > 0) {
         MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % BK == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
@@ -294,12 +549,17 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
             if (g.e.b_seg_off[i] + g.e.kseg > g.kb_rows) g.kb_rows = g.e.b_seg_off[i] + g.e.kseg;
         }
     }
-    if (g.split_k > 1) MICO_CHECK(c_dtype == MICO_F32 && g.e.accumulate, "mico_gemm: split_k > 1 needs fp32 accumulate output");
+    if (g.split_k > 1) {
+        MICO_CHECK(c_dtype == MICO_F32 && g.e.accumulate, "mico_gemm: split_k > 1 needs fp32 accumulate output");
+        MICO_CHECK(!g.e.bias && !g.e.aux_out && g.e.act == MICO_ACT_NONE && !g.e.row_scale && !g.e.resid && !g.e.pos && !g.e.remap_group,
+                   "mico_gemm: split_k > 1 supports only the alpha-scaled accumulate epilogue");
+    }
     if (g.e.act == MICO_ACT_GELU_GRAD) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD needs aux_in");
     if (g.e.row_scale) MICO_CHECK(g.e.rows_per_scale > 0, "mico_gemm: rows_per_scale must be > 0");
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T16(dtype, launch<T>(ta, tb, g, st));
+    if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
+    else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -38,7 +38,7 @@ def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None):
     n_out = n_out or dw.shape[0]
     n_in = n_in or dw.shape[1]
     ops.gemm(dy16, x16, dw, ta=True, tb=True, M=n_out, N=n_in, K=dy16.shape[0], accumulate=True, alpha=inv_s,
-             split_k=_split_k(n_out, n_in, dy16.shape[0]))
+             split_k=0)   # 0 = let the library size the K split in whole waves of resident workgroups
 
 
 # ======================================================================================================================

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of mico_gemm at the ViT-g/14 shapes of BASELINE config 3 (M = 82240 token rows), all three orientations.
+    python tools/gemm_bench.py [--iters 20] [--only fwd|dx|dw] [--m 82240]
+Prints TFLOP/s per shape from HIP events on the launch stream (random bf16 data, not zero-filled)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mico_amd import ops  # noqa: E402
+from mico_amd.functional import _split_k  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--m", type=int, default=82240)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    dev = torch.device("cuda:0")
+    M = a.m
+    shapes = [("qkv", 1408, 4224), ("proj", 1408, 1408), ("fc1", 1408, 6144), ("fc2", 6144, 1408)]
+    res = []
+    for name, K, N in shapes:
+        x = torch.randn(M, K, device=dev).to(dt)
+        w = (0.02 * torch.randn(N, K, device=dev)).to(dt)
+        dy = torch.randn(M, N, device=dev).to(dt)
+        y = torch.empty(M, N, device=dev, dtype=dt)
+        dx = torch.empty(M, K, device=dev, dtype=dt)
+        dw = torch.zeros(N, K, device=dev)
+        bias = torch.randn(N, device=dev)
+        sk = 0
+        cases = {
+            "fwd": lambda: ops.gemm(x, w, y, bias=bias),
+            "dx": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N),
+            "dw": lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=sk),
+        }
+        for cname, fn in cases.items():
+            if a.only and cname != a.only:
+                continue
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            tf = 2.0 * M * N * K / ms / 1e9
+            res.append((name, cname, ms, tf))
+            print(f"{name:5s} {cname:3s} M={M} N={N} K={K} split_k={sk if cname == 'dw' else 1}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s", flush=True)
+    tot_f = sum(2.0 * M * (4224 + 1408 + 6144 + 6144) * 1408 for _ in range(1))
+    for c in ("fwd", "dx", "dw"):
+        ms = sum(r[2] for r in res if r[1] == c)
+        if ms:
+            print(f"layer {c}: {ms:.3f} ms  -> {tot_f / ms / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
