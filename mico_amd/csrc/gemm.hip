@@ -1,21 +1,28 @@
 // MFMA GEMM for gfx950 with fused epilogues (see include/mico_hip.h: mico_gemm).
 //
-// Two tile configurations of one kernel template:
-//   * BIG   256x128x64, 8 waves (4x2, 64x64 per wave), 3-stage LDS ring (144 KiB, one workgroup per CU).  Operand tiles for
-//           K-tile t+2 are in flight while tile t is multiplied: the LDS-DMA queue is never drained inside the main loop -
-//           counted `s_waitcnt vmcnt(6)` (the 6 DMA instructions of the newest tile stay outstanding) + raw `s_barrier`.
-//           This is the path of every large GEMM (M = frames x tokens rows).
-//   * SMALL 128x128x64, 4 waves (2x2), 2-stage ring, two workgroups per CU: short-M problems (BERT text GEMMs, heads).
-// Common to both: operand tiles go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B/lane, no VGPR round trip);
-// the buffer descriptor's bounds check zero-fills rows past the end of the matrix, so M/N/K tails need no masking in the
-// main loop.  LDS images are lane-linear (DMA constraint); bank conflicts are removed by XOR-swizzling the 16-byte chunk
-// index on the *source* address and applying the same involution on the read side (measured: SQ_LDS_BANK_CONFLICT = 0).
-// K-contiguous operands are read with ds_read_b128, reduction-major operands (dX / dW GEMMs) with the gfx950 transposing
-// read ds_read_b64_tr_b16, so the backward GEMMs need no transposed copies of weights or activations in HBM.  MFMA
-// operands are swapped (D^T = B A^T) so every lane owns 4 consecutive columns of one output row: 8/16-byte epilogue
-// accesses.  Workgroup ids are remapped XCD-contiguously (8 private L2s) and walk the tile grid in groups of row-panels so
-// concurrently resident tiles share A and B panels in L2.  Long-reduction weight-gradient GEMMs are split along K in whole
-// waves of resident workgroups and combined with fp32 atomics.
+// Measured on MI355X these GEMMs are bound by the per-CU HBM/L2 -> LDS fill rate (~45 GB/s per CU, ~11 TB/s chip) long
+// before the matrix pipe: 128x128 tiles (64 flop per staged byte) plateau near 750 TFLOP/s, 256x128 near 930.  Hence two
+// configurations:
+//   * BIG   256x256x64, 8 waves (2x4, 128x64 per wave), 2-stage LDS ring (128 KiB, one workgroup per CU): 128 flop per
+//           staged byte.  Schedule = 4-phase PING-PONG: waves w and w+4 share a SIMD and form two groups; every K-tile is
+//           four barrier-separated phases and in each phase one group issues the 12 LDS fragment reads of one 32-deep
+//           k-step while the other group runs its 32 MFMAs on fragments fetched one phase earlier -
+//               group0:  R0  M0  R1  M1            (Rk = read k-step k, Mk = multiply it)
+//               group1:  M1' R0  M0  R1            (M1' belongs to the previous K-tile)
+//           so a SIMD's matrix pipe always has one wave feeding it while its partner's LDS latency hides behind it, with
+//           single-buffered fragments (48 VGPRs next to the 128 accumulator VGPRs).  The next K-tile's DMA is issued at the
+//           head of the current one and has all four phases to land.
+//   * SMALL 128x128x64, 4 waves (2x2), 2-stage ring, two workgroups per CU: short-M / narrow problems (BERT text, heads).
+// Common: operand tiles go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B/lane, no VGPR round trip); the buffer
+// descriptor's bounds check zero-fills rows past the end of the matrix, so M/N/K tails need no masking in the main loop.
+// LDS images are lane-linear (DMA constraint); bank conflicts are removed by XOR-swizzling the 16-byte chunk index on the
+// *source* address and applying the same involution on the read side (measured: SQ_LDS_BANK_CONFLICT = 0).  K-contiguous
+// operands are read with ds_read_b128, reduction-major operands (dX / dW GEMMs) with the gfx950 transposing read
+// ds_read_b64_tr_b16, so the backward GEMMs need no transposed copies of weights or activations in HBM.  MFMA operands are
+// swapped (D^T = B A^T) so a lane owns 4 consecutive output columns; the epilogue then transposes through LDS so that global
+// accesses are whole cache lines.  Workgroup ids are remapped XCD-contiguously (8 private L2s) and walk the tile grid in
+// groups of row-panels so concurrently resident tiles share A and B panels in L2.  Long-reduction weight-gradient GEMMs are
+// split along K in whole waves of resident workgroups and combined with fp32 atomics.
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -25,14 +32,17 @@ namespace {
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
-template <int BM_, int STAGES_> struct TileCfg {
-    static constexpr int BM = BM_, BN = 128, STAGES = STAGES_;
-    static constexpr int WAVES = BM / 64 * 2, THREADS = WAVES * 64;
+template <int BM_, int BN_, int WM_, int WN_> struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int WAVES = WM * WN, THREADS = WAVES * 64;
+    static constexpr int MT = BM / WM / 16, NT = BN / WN / 16;   // 16x16 MFMA tiles per wave
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int A_DMA = A_BYTES / 16 / THREADS, B_DMA = B_BYTES / 16 / THREADS;   // DMA instructions per thread per tile
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static_assert(NT == 4, "wave tiles are 64 columns wide");
 };
-using Big = TileCfg<256, 3>;
-using Small = TileCfg<128, 2>;
+using Big = TileCfg<256, 256, 2, 4>;
+using Small = TileCfg<128, 128, 2, 2>;
 
 struct GemmArgs {
     const char* A;
@@ -49,7 +59,7 @@ struct GemmArgs {
 __device__ __forceinline__ int key_kc(int row) { return (row >> 1) & 7; }                               // [rows][64] k-contiguous
 __device__ __forceinline__ int key_tr(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }   // [64][cols] reduction-major
 
-// one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim (BM or BN).
+// generic (masked) staging of one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim.
 template <bool TR, int ROWS, int THREADS>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, int lane,
                                            int64_t ld_bytes, int k0, int64_t kdim, int64_t cdim_rem) {
@@ -75,33 +85,12 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS cha
     }
 }
 
-// MFMA fragment (8 x 16-bit along the reduction dim) for 16 tile rows starting at `r0`, k-step kk (0/1)
-template <bool TR, int ROWS>
-__device__ __forceinline__ s16x8 read_frag(LDS_AS const char* tile, int r0, int kk, int lane) {
-    if (!TR) {
-        const int row = r0 + (lane & 15);
-        const int cg = kk * 4 + (lane >> 4);
-        return *(LDS_AS const s16x8*)(tile + row * 128 + ((cg ^ key_kc(row)) << 4));
-    } else {
-        constexpr int RB = ROWS * 2;   // bytes per k-row
-        const int kb = kk * 32 + (lane >> 4) * 8 + ((lane & 15) >> 2);
-        const int chunk = (r0 >> 3) + ((lane >> 1) & 1);
-        const int half = (lane & 1) * 8;
-        const int k0r = kb, k1r = kb + 4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + k0r * RB + ((chunk ^ key_tr(k0r)) << 4) + half));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + k1r * RB + ((chunk ^ key_tr(k1r)) << 4) + half));
-        s16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
-    }
-}
-
-// ---- register-lean addressing for the ping-pong (BIG) path --------------------------------------------------------------
-// Per lane and operand only two LDS byte offsets (k-step 0 / 1) are kept; the four 16-row tiles of a wave are reached by an
+// ---- register-lean fragment addressing ----------------------------------------------------------------------------------
+// Per lane and operand only two LDS byte offsets (k-step 0 / 1) are kept; the 16-row tiles of a wave are reached by an
 // immediate (+i*2048, k-contiguous image) or an XOR (^(i<<5), reduction-major image) and the second transposing read by a
 // constant (+4 rows).  These identities follow from the swizzle keys: key_kc depends on (row>>1)&7 only, hence not on the
-// 16-row tile index; key_tr is identical for rows r and r+4 inside an 8-row group and only touches chunk bits 1-3.
+// 16-row tile index; key_tr is identical for rows r and r+4 inside an 8-row group and only touches chunk bits 1-3, which the
+// tile index occupies exclusively because wave column bases are multiples of 64 (and of 128 when a wave owns 8 tiles).
 struct FragBase { int b0, b1; };
 
 template <bool TR, int ROWS>
@@ -167,17 +156,16 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char
     }
 }
 
-// Epilogue through LDS: the MFMA layout gives a lane 4 consecutive columns of 16 different rows (32-byte row segments per
-// store instruction - measured as ~14 us of fixed cost per 256x128 tile, i.e. a write-bandwidth-bound tail at ~1.2 TB/s).
-// Each wave therefore parks its 64x64 fp32 accumulator tile in LDS (16 KiB, XOR-swizzled 16-byte chunks, conflict free both
-// ways) and re-reads it so that a lane owns 16 consecutive columns of one row: bias / residual / auxiliary loads and the
-// stores are then 32-64 contiguous bytes per lane and 128-256 contiguous bytes per row - whole cache lines.
+// ---- epilogues ------------------------------------------------------------------------------------------------------------
+// Through LDS: the MFMA layout gives a lane 4 consecutive columns of 16 different rows (32-byte row segments per store
+// instruction - measured as ~14 us of fixed cost per 256x128 tile, a write-bound tail at ~1.2 TB/s).  Each wave therefore
+// parks a 64x64 fp32 block of its accumulators in LDS (16 KiB, XOR-swizzled 16-byte chunks, conflict free both ways) and
+// re-reads it so that a lane owns 16 consecutive columns of one row: bias / residual / auxiliary loads and the stores are
+// then 32-64 contiguous bytes per lane, 128-256 per row - whole cache lines.  acc[0..3] is the block for 64 rows at mrow0.
 template <typename T>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], LDS_AS char* lds, int64_t m0, int64_t n0,
-                                              int wave, int wm, int wn, int lane) {
+__device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
+                                                    int64_t ncol0, int lane) {
     const mico_gemm_epilogue& e = g.e;
-    LDS_AS char* wbuf = lds + wave * 16384;
-    __syncthreads();   // every wave is done with the operand tiles (and the DMA queue is empty) before LDS is reused
     {
         const int p = lane & 15, gq = lane >> 4;
 #pragma unroll
@@ -189,7 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
             }
     }
     const int q = lane & 3;
-    const int64_t n = n0 + wn * 64 + q * 16;
+    const int64_t n = ncol0 + q * 16;
     if (n >= g.N) return;
     const int nvec = (int)min((int64_t)4, (g.N - n) >> 2);   // valid 4-column groups of this lane (N % 4 == 0)
     f32x4 bias4[4];
@@ -198,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int row = pass * 16 + (lane >> 2);
-        const int64_t m = m0 + wm * 64 + row;
+        const int64_t m = mrow0 + row;
         if (m >= g.M) continue;
         int64_t mo = m;
         if (e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
@@ -233,16 +221,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
             if (e.resid) x += *(const f32x4*)(e.resid + mo * g.ldc + n + v * 4);
             if (g.c_dtype == MICO_F32) {
                 float* cp = (float*)g.C + mo * g.ldc + n + v * 4;
-                if (e.accumulate) {
-                    if (g.split_k > 1) {
-                        unsafeAtomicAdd(cp + 0, x[0]); unsafeAtomicAdd(cp + 1, x[1]);
-                        unsafeAtomicAdd(cp + 2, x[2]); unsafeAtomicAdd(cp + 3, x[3]);
-                    } else {
-                        *(f32x4*)cp += x;
-                    }
-                } else {
-                    *(f32x4*)cp = x;
-                }
+                if (e.accumulate) *(f32x4*)cp += x;
+                else *(f32x4*)cp = x;
             } else {
                 *(s16x4*)((T*)g.C + mo * g.ldc + n + v * 4) = pack4<T>(x[0], x[1], x[2], x[3]);
             }
@@ -251,20 +231,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 }
 
 // Direct (register-layout) epilogue for split-K partial tiles: alpha-scaled fp32 atomics straight from the MFMA layout
-// (4 consecutive columns per lane).  Measured 2x faster for atomics than the LDS-transposed 16-column form.
-template <typename T>
-__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& g, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn,
+// (4 consecutive columns per lane); measured 2x faster for atomics than the LDS-transposed 16-column form.
+__device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& g, const f32x4 (*acc)[4], int64_t mrow0, int64_t ncol0,
                                                      int lane) {
-    const mico_gemm_epilogue& e = g.e;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+        const int64_t m = mrow0 + i * 16 + (lane & 15);
         if (m >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            const int64_t n = ncol0 + j * 16 + (lane >> 4) * 4;
             if (n >= g.N) continue;
-            const f32x4 v = acc[i][j] * e.alpha;
+            const f32x4 v = acc[i][j] * g.e.alpha;
             float* cp = (float*)g.C + m * g.ldc + n;
             unsafeAtomicAdd(cp + 0, v[0]); unsafeAtomicAdd(cp + 1, v[1]);
             unsafeAtomicAdd(cp + 2, v[2]); unsafeAtomicAdd(cp + 3, v[3]);
@@ -276,13 +254,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <typename T, bool TA, bool TB, typename CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
-    constexpr int BM = CFG::BM, BN = CFG::BN, STAGES = CFG::STAGES, THREADS = CFG::THREADS;
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * CFG::STAGE_BYTES];
+    constexpr int BM = CFG::BM, BN = CFG::BN, THREADS = CFG::THREADS, MT = CFG::MT;
+    constexpr bool PINGPONG = CFG::WAVES == 8;
+    __shared__ __attribute__((aligned(16))) char smem[CFG::LDS_BYTES];
     LDS_AS char* lds = (LDS_AS char*)smem;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+    const int wrow = wm * (BM / CFG::WM), wcol = wn * 64;
 
     // ---- workgroup -> (k-split, tile) : XCD-contiguous remap (bijective), then grouped row-panel order ----
     int bid = blockIdx.x;
@@ -305,6 +285,7 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const int kt0 = ks * g.ktiles_per_split;
     const int kt1 = min(g.ktiles, kt0 + g.ktiles_per_split);
+    const int T_ = kt1 - kt0;
 
     // ---- buffer descriptors (block-relative base so 32-bit offsets never overflow) ----
     const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
@@ -318,16 +299,21 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
     const int64_t a_crem = g.M - m0, b_crem = g.N - n0;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // logical k-tile -> physical k offsets of A and B.  With k-segments (split-precision GEMMs) the logical reduction is
-    // the concatenation of nseg segments of kseg elements, each mapped to its own physical column offset per operand.
+    // ---- staging: fast path = precomputed per-lane offsets + one scalar k offset; masked generic path for a ragged last
+    // K-tile.  k-segments (split-precision GEMMs) map the logical k-tile to per-operand physical column offsets.
     const int nseg = g.e.nseg, kseg = g.e.kseg;
-    auto stage = [&](int kt, int buf) {
+    const FragBase ab = frag_base<TA, BM>(wrow, lane), bb = frag_base<TB, BN>(wcol, lane);
+    unsigned voa[CFG::A_DMA], vob[CFG::B_DMA];
+    dma_offsets<TA, BM, THREADS, CFG::A_DMA>(voa, wave, lane, lda_b, a_crem);
+    dma_offsets<TB, BN, THREADS, CFG::B_DMA>(vob, wave, lane, ldb_b, b_crem);
+    const bool ktail = (g.K % BK) != 0;
+    auto stage = [&](int kt, int bo) {
         const int k0 = kt * BK;
         int ka = k0, kb = k0;
         int64_t kda = g.K, kdb = g.K;
@@ -338,129 +324,108 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
             kda = g.e.a_seg_off[sg] + kseg;
             kdb = g.e.b_seg_off[sg] + kseg;
         }
-        LDS_AS char* dst = lds + buf * CFG::STAGE_BYTES;
-        stage_tile<TA, BM, THREADS>(rsa, dst, wave, lane, lda_b, ka, kda, a_crem);
-        stage_tile<TB, BN, THREADS>(rsb, dst + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
-    };
-    s16x8 fa[2][4], fb[2][4];   // all fragments of one K-tile (2 k-steps x 4 row tiles per operand)
-    auto read_frags = [&](int buf) {
-        LDS_AS const char* ta = lds + buf * CFG::STAGE_BYTES;
-        LDS_AS const char* tb = ta + CFG::A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag<TA, BM>(ta, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[kk][j] = read_frag<TB, BN>(tb, wn * 64 + j * 16, kk, lane);
+        if (ktail && kt == g.ktiles - 1) {
+            stage_tile<TA, BM, THREADS>(rsa, lds + bo, wave, lane, lda_b, ka, kda, a_crem);
+            stage_tile<TB, BN, THREADS>(rsb, lds + bo + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
+            return;
         }
-    };
-    auto mma_frags = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[kk][j], fa[kk][i], acc[i][j]);
+        const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
+        const unsigned kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
+        dma_issue<THREADS, CFG::A_DMA>(rsa, lds + bo, wave, voa, koa);
+        dma_issue<THREADS, CFG::B_DMA>(rsb, lds + bo + CFG::A_BYTES, wave, vob, kob);
     };
 
-    if constexpr (STAGES == 2) {
-        int cur = 0;
-        if (kt0 < kt1) stage(kt0, 0);
-        for (int kt = kt0; kt < kt1; ++kt) {
-            __syncthreads();   // stage `cur` landed (vmcnt(0) precedes the barrier); stage cur^1 no longer being read
-            if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
-            read_frags(cur);
-            mma_frags();
-            cur ^= 1;
+    s16x8 fa[MT], fb[4];   // fragments of ONE 32-deep k-step
+    auto read_k = [&](int bo, int kk) {
+        LDS_AS const char* ta = lds + bo;
+        LDS_AS const char* tb = ta + CFG::A_BYTES;
+        const int abase = kk ? ab.b1 : ab.b0, bbase = kk ? bb.b1 : bb.b0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = read_frag_b<TA, BM>(ta, abase, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag_b<TB, BN>(tb, bbase, j);
+    };
+    auto mma_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[j], fa[i], acc[i][j]);
+    };
+
+    if constexpr (!PINGPONG) {
+        int bo = 0;
+        if (T_ > 0) stage(kt0, 0);
+        for (int t = 0; t < T_; ++t) {
+            __syncthreads();   // stage `bo` landed (vmcnt(0) precedes the barrier); the other stage is no longer being read
+            if (t + 1 < T_) stage(kt0 + t + 1, bo ^ CFG::STAGE_BYTES);
+            read_k(bo, 0);
+            mma_k();
+            read_k(bo, 1);
+            mma_k();
+            bo ^= CFG::STAGE_BYTES;
         }
     } else {
-        // 3-stage ring (prefetch distance 2: the LDS-DMA queue is never drained in steady state - counted vmcnt + raw
-        // s_barrier) with a PING-PONG schedule: the 8 waves form two groups of 4 (waves w and w+4 share a SIMD).  Each
-        // K-tile takes two barrier-separated phases; in every phase one group issues its 16 LDS fragment reads for the tile
-        // while the other group runs its 32 MFMAs on fragments read one phase earlier, so the matrix pipe of every SIMD is
-        // always fed by one wave while its partner's LDS latency is hidden behind it:
-        //     phase 2t   : group0 reads tile t      | group1 MFMAs tile t-1
-        //     phase 2t+1 : group0 MFMAs tile t      | group1 reads tile t
-        // Tile t+2's DMA is issued at the start of phase 2t into the buffer whose last reader (group1, tile t-1) finished
-        // before that phase's barrier.
-        constexpr int PER_TILE = CFG::A_DMA + CFG::B_DMA;
+        // see the file header for the schedule.  The two groups run separate straight-line loops with the same number of
+        // barriers per K-tile, so the fragment registers have one unambiguous live range in each.
         const int grp = wave >> 2;
-        const int T_ = kt1 - kt0;
-        const FragBase ab = frag_base<TA, BM>(wm * 64, lane), bb = frag_base<TB, BN>(wn * 64, lane);
-        unsigned voa[CFG::A_DMA], vob[CFG::B_DMA];
-        dma_offsets<TA, BM, THREADS, CFG::A_DMA>(voa, wave, lane, lda_b, a_crem);
-        dma_offsets<TB, BN, THREADS, CFG::B_DMA>(vob, wave, lane, ldb_b, b_crem);
-        const bool ktail = (g.K % BK) != 0;   // only then can a k-contiguous operand need per-chunk K masking
-        auto stage_fast = [&](int kt, int bo) {
-            const int k0 = kt * BK;
-            int ka = k0, kb = k0;
-            if (nseg > 0) {
-                const int sg = k0 / kseg, kin = k0 - sg * kseg;
-                ka = g.e.a_seg_off[sg] + kin;
-                kb = g.e.b_seg_off[sg] + kin;
-            }
-            if (ktail && kt == g.ktiles - 1) {
-                stage(kt, bo / CFG::STAGE_BYTES);
-                return;
-            }
-            const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
-            const unsigned kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
-            dma_issue<THREADS, CFG::A_DMA>(rsa, lds + bo, wave, voa, koa);
-            dma_issue<THREADS, CFG::B_DMA>(rsb, lds + bo + CFG::A_BYTES, wave, vob, kob);
-        };
-        auto read_pp = [&](int bo) {
-            LDS_AS const char* ta = lds + bo;
-            LDS_AS const char* tb = ta + CFG::A_BYTES;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { fa[0][i] = read_frag_b<TA, BM>(ta, ab.b0, i); fa[1][i] = read_frag_b<TA, BM>(ta, ab.b1, i); }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { fb[0][j] = read_frag_b<TB, BN>(tb, bb.b0, j); fb[1][j] = read_frag_b<TB, BN>(tb, bb.b1, j); }
-        };
-        if (T_ > 0) stage_fast(kt0, 0);
-        if (T_ > 1) stage_fast(kt0 + 1, CFG::STAGE_BYTES);
-        // The two groups run separate, straight-line loops (same barrier count per iteration) so the fragment registers have
-        // one unambiguous live range each - a shared loop with per-phase role branches made the allocator keep two copies.
-        auto head = [&](int t, int bo) {   // top of K-tile t: tile t landed everywhere, then queue tile t+2
-            if (t + 1 < T_) wait_vmcnt<PER_TILE>();
-            else wait_vmcnt<0>();
+        auto head = [&](int t, int bo) {   // tile t landed everywhere; its partner buffer is free: queue tile t+1 into it
+            // lgkmcnt(0): this wave's own LDS reads of the buffer about to be refilled have returned (group1 issued the last
+            // ones of the previous tile just before arriving here); vmcnt(0): its share of tile t has landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < T_) stage_fast(kt0 + t + 2, bo >= CFG::STAGE_BYTES ? bo - CFG::STAGE_BYTES : 2 * CFG::STAGE_BYTES);
+            if (t + 1 < T_) stage(kt0 + t + 1, bo ^ CFG::STAGE_BYTES);
         };
-        auto mid = [&]() {
+        auto bar = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        int bo = 0;   // byte offset of the buffer holding tile t (kept opaque so LDS addresses are not hoisted x3)
+        int bo = 0;   // byte offset of the buffer holding tile t (kept opaque so LDS addresses are not hoisted per buffer)
+        if (T_ > 0) stage(kt0, 0);
         if (grp == 0) {
             for (int t = 0; t < T_; ++t) {
                 asm volatile("" : "+s"(bo));
                 head(t, bo);
-                read_pp(bo);
-                mid();
-                mma_frags();
+                read_k(bo, 0);
+                bar();
+                mma_k();
+                bar();
+                read_k(bo, 1);
+                bar();
+                mma_k();
                 __builtin_amdgcn_sched_barrier(0);
-                bo = bo == 2 * CFG::STAGE_BYTES ? 0 : bo + CFG::STAGE_BYTES;
+                bo ^= CFG::STAGE_BYTES;
             }
         } else {
             for (int t = 0; t < T_; ++t) {
                 asm volatile("" : "+s"(bo));
                 head(t, bo);
-                if (t > 0) mma_frags();
-                mid();
-                read_pp(bo);
+                if (t > 0) mma_k();      // k-step 1 of the previous tile (fragments read in the last phase of that tile)
+                bar();
+                read_k(bo, 0);
+                bar();
+                mma_k();
+                bar();
+                read_k(bo, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                bo = bo == 2 * CFG::STAGE_BYTES ? 0 : bo + CFG::STAGE_BYTES;
+                bo ^= CFG::STAGE_BYTES;
             }
-            if (T_ > 0) mma_frags();
+            if (T_ > 0) mma_k();
         }
     }
 
-    // split-K partials carry no bias / activation / residual (checked on the host side): plain atomics
-    if (g.split_k > 1) gemm_epilogue_atomic<T>(g, acc, m0, n0, wm, wn, lane);
-    else gemm_epilogue<T>(g, acc, lds, m0, n0, wave, wm, wn, lane);
+    // ---- epilogue ----
+    if (g.split_k > 1) {   // split-K partials carry no bias / activation / residual (checked on the host side)
+#pragma unroll
+        for (int h = 0; h < MT / 4; ++h) gemm_epilogue_atomic(g, &acc[h * 4], m0 + wrow + h * 64, n0 + wcol, lane);
+    } else {
+        __syncthreads();   // every wave is done with the operand tiles (and the DMA queue is empty) before LDS is reused
+#pragma unroll
+        for (int h = 0; h < MT / 4; ++h)
+            gemm_epilogue_block<T>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
+    }
 }
 
 template <typename T, typename CFG>
@@ -498,7 +463,7 @@ int mico_set_err(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int mico_version(void) { return 101; }
+extern "C" int mico_version(void) { return 102; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
@@ -525,10 +490,10 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         g.e = mico_gemm_epilogue{};
         g.e.alpha = 1.f;
     }
-    // tile configuration: the 256x128 3-stage kernel whenever it yields at least ~one workgroup per CU
-    const int64_t big_tiles = ((M + 255) / 256) * ((N + 127) / 128);
-    const bool big = big_tiles >= 192;
-    const int BM = big ? 256 : 128, BN = 128;
+    // tile configuration: the 256x256 ping-pong kernel whenever it yields enough workgroups to occupy most CUs
+    const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = big_tiles >= 128 && N >= 192;
+    const int BM = big ? 256 : 128, BN = big ? 256 : 128;
     const int slots = big ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
     g.ntiles = g.ntm * g.ntn;
