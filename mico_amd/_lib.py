@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (import order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmico_hip.so")
+LIB_PATH = os.environ.get("MICO_HIP_LIB") or os.path.join(_HERE, "libmico_hip.so")   # env override: kernel ablation builds
 
 F16, BF16, F32 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2

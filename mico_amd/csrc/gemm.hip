@@ -3,15 +3,15 @@
 // Measured on MI355X these GEMMs are bound by the per-CU HBM/L2 -> LDS fill rate (~45 GB/s per CU, ~11 TB/s chip) long
 // before the matrix pipe: 128x128 tiles (64 flop per staged byte) plateau near 750 TFLOP/s, 256x128 near 930.  Hence two
 // configurations:
-//   * BIG   256x256x64, 8 waves (2x4, 128x64 per wave), 2-stage LDS ring (128 KiB, one workgroup per CU): 128 flop per
-//           staged byte.  Schedule = 4-phase PING-PONG: waves w and w+4 share a SIMD and form two groups; every K-tile is
-//           four barrier-separated phases and in each phase one group issues the 12 LDS fragment reads of one 32-deep
-//           k-step while the other group runs its 32 MFMAs on fragments fetched one phase earlier -
-//               group0:  R0  M0  R1  M1            (Rk = read k-step k, Mk = multiply it)
-//               group1:  M1' R0  M0  R1            (M1' belongs to the previous K-tile)
-//           so a SIMD's matrix pipe always has one wave feeding it while its partner's LDS latency hides behind it, with
-//           single-buffered fragments (48 VGPRs next to the 128 accumulator VGPRs).  The next K-tile's DMA is issued at the
-//           head of the current one and has all four phases to land.
+//   * BIG   256x256x32, 8 waves (2x4, 128x64 per wave), 4-stage LDS ring of 32 KiB K-tiles (128 KiB, one workgroup per CU):
+//           128 flop per staged byte, prefetch distance 3 tiles.  Schedule = 2-phase PING-PONG: waves w and w+4 share a
+//           SIMD (measured: wave->SIMD order 0,2,1,3,0,2,1,3) and form two groups; every K-tile (one 32-deep MFMA k-step) is
+//           two barrier-separated phases and in each phase one group issues its 12 LDS fragment reads AND its 4 DMA
+//           instructions for tile t+3, while the other group runs its 32 MFMAs on fragments fetched one phase earlier -
+//               group0:  R(t)   | M(t)          group1:  M(t-1) | R(t)
+//           so a SIMD's matrix pipe always has one wave feeding it, the partner's LDS latency and the (expensive: ~100-200
+//           issue cycles each) DMA instructions hide behind it, fragments are single-buffered (48 VGPRs next to 128
+//           accumulator VGPRs), and the DMA queue is never drained: counted `s_waitcnt vmcnt(8)` + raw `s_barrier`.
 //   * SMALL 128x128x64, 4 waves (2x2), 2-stage ring, two workgroups per CU: short-M / narrow problems (BERT text, heads).
 // Common: operand tiles go HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B/lane, no VGPR round trip); the buffer
 // descriptor's bounds check zero-fills rows past the end of the matrix, so M/N/K tails need no masking in the main loop.
@@ -27,22 +27,26 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA
+#define MICO_GEMM_ABLATE 0
+#endif
+
 namespace {
 
-constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
-template <int BM_, int BN_, int WM_, int WN_> struct TileCfg {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+template <int BM_, int BN_, int WM_, int WN_, int BK_, int STAGES_> struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
     static constexpr int WAVES = WM * WN, THREADS = WAVES * 64;
     static constexpr int MT = BM / WM / 16, NT = BN / WN / 16;   // 16x16 MFMA tiles per wave
+    static constexpr int KSTEPS = BK / 32;                       // MFMA k-steps per K-tile
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int A_DMA = A_BYTES / 16 / THREADS, B_DMA = B_BYTES / 16 / THREADS;   // DMA instructions per thread per tile
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     static_assert(NT == 4, "wave tiles are 64 columns wide");
 };
-using Big = TileCfg<256, 256, 2, 4>;
-using Small = TileCfg<128, 128, 2, 2>;
+using Big = TileCfg<256, 256, 2, 4, 32, 4>;
+using Small = TileCfg<128, 128, 2, 2, 64, 2>;
 
 struct GemmArgs {
     const char* A;
@@ -57,10 +61,11 @@ struct GemmArgs {
 
 // swizzle keys (16-byte chunk index XOR) - see file header
 __device__ __forceinline__ int key_kc(int row) { return (row >> 1) & 7; }                               // [rows][64] k-contiguous
+__device__ __forceinline__ int key_k32(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }      // [rows][32]: {0,3,2,1}[(row>>2)&3]
 __device__ __forceinline__ int key_tr(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }   // [64][cols] reduction-major
 
 // generic (masked) staging of one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim.
-template <bool TR, int ROWS, int THREADS>
+template <bool TR, int ROWS, int THREADS, int BK>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, int lane,
                                            int64_t ld_bytes, int k0, int64_t kdim, int64_t cdim_rem) {
     constexpr int NDMA = ROWS * BK * 2 / 16 / THREADS;
@@ -69,8 +74,9 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS cha
         const int c = it * THREADS + wave * 64 + lane;
         unsigned voff;
         if (!TR) {
-            const int row = c >> 3, cpos = c & 7;
-            const int cg = cpos ^ key_kc(row);
+            constexpr int CPRK = BK / 8;        // 16-byte chunks per k-contiguous row (8 or 4)
+            const int row = c / CPRK, cpos = c % CPRK;
+            const int cg = cpos ^ (BK == 64 ? key_kc(row) : key_k32(row));
             const int k = k0 + cg * 8;
             voff = (unsigned)(row * ld_bytes + (int64_t)k * 2);
             if (k >= kdim) voff = 0xFFFFFFF0u;   // K tail: force out-of-bounds -> zero fill
@@ -93,15 +99,18 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS cha
 // tile index occupies exclusively because wave column bases are multiples of 64 (and of 128 when a wave owns 8 tiles).
 struct FragBase { int b0, b1; };
 
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int BK>
 __device__ __forceinline__ FragBase frag_base(int wbase, int lane) {
     FragBase f;
     const int g = lane >> 4, p = lane & 15;
-    if (!TR) {
+    if (!TR && BK == 64) {
         const int keyl = (p >> 1) & 7;
         const int base = (wbase + p) * 128;
         f.b0 = base + ((g ^ keyl) << 4);
         f.b1 = base + (((4 + g) ^ keyl) << 4);
+    } else if (!TR) {   // 64-byte rows, one k-step per tile
+        f.b0 = (wbase + p) * 64 + ((g ^ key_k32(p)) << 4);
+        f.b1 = f.b0;
     } else {
         constexpr int RB = ROWS * 2;
         const int key0 = ((p >> 2) | ((g & 1) << 2)) << 1;
@@ -112,10 +121,10 @@ __device__ __forceinline__ FragBase frag_base(int wbase, int lane) {
     return f;
 }
 
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int BK>
 __device__ __forceinline__ s16x8 read_frag_b(LDS_AS const char* tile, int base, int i) {
     if (!TR) {
-        return *(LDS_AS const s16x8*)(tile + base + i * 2048);
+        return *(LDS_AS const s16x8*)(tile + base + i * (BK * 2 * 16));
     } else {
         constexpr int RB = ROWS * 2;
         LDS_AS const char* a = tile + (base ^ (i << 5));
@@ -129,14 +138,15 @@ __device__ __forceinline__ s16x8 read_frag_b(LDS_AS const char* tile, int base, 
 }
 
 // loop-invariant per-lane DMA offsets of one operand tile (k0 = 0); 0xFFFFFFF0 marks a chunk past the matrix edge
-template <bool TR, int ROWS, int THREADS, int NDMA>
+template <bool TR, int ROWS, int THREADS, int BK, int NDMA>
 __device__ __forceinline__ void dma_offsets(unsigned (&vo)[NDMA], int wave, int lane, int64_t ld_bytes, int64_t cdim_rem) {
 #pragma unroll
     for (int it = 0; it < NDMA; ++it) {
         const int c = it * THREADS + wave * 64 + lane;
         if (!TR) {
-            const int row = c >> 3, cpos = c & 7;
-            vo[it] = (unsigned)(row * ld_bytes + ((cpos ^ key_kc(row)) << 4));
+            constexpr int CPRK = BK / 8;
+            const int row = c / CPRK, cpos = c % CPRK;
+            vo[it] = (unsigned)(row * ld_bytes + ((cpos ^ (BK == 64 ? key_kc(row) : key_k32(row))) << 4));
         } else {
             constexpr int CPR = ROWS / 8;
             const int row = c / CPR, cpos = c % CPR;
@@ -254,7 +264,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <typename T, bool TA, bool TB, typename CFG>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
-    constexpr int BM = CFG::BM, BN = CFG::BN, THREADS = CFG::THREADS, MT = CFG::MT;
+    constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, THREADS = CFG::THREADS, MT = CFG::MT;
     constexpr bool PINGPONG = CFG::WAVES == 8;
     __shared__ __attribute__((aligned(16))) char smem[CFG::LDS_BYTES];
     LDS_AS char* lds = (LDS_AS char*)smem;
@@ -308,10 +318,10 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     // ---- staging: fast path = precomputed per-lane offsets + one scalar k offset; masked generic path for a ragged last
     // K-tile.  k-segments (split-precision GEMMs) map the logical k-tile to per-operand physical column offsets.
     const int nseg = g.e.nseg, kseg = g.e.kseg;
-    const FragBase ab = frag_base<TA, BM>(wrow, lane), bb = frag_base<TB, BN>(wcol, lane);
+    const FragBase ab = frag_base<TA, BM, BK>(wrow, lane), bb = frag_base<TB, BN, BK>(wcol, lane);
     unsigned voa[CFG::A_DMA], vob[CFG::B_DMA];
-    dma_offsets<TA, BM, THREADS, CFG::A_DMA>(voa, wave, lane, lda_b, a_crem);
-    dma_offsets<TB, BN, THREADS, CFG::B_DMA>(vob, wave, lane, ldb_b, b_crem);
+    dma_offsets<TA, BM, THREADS, BK, CFG::A_DMA>(voa, wave, lane, lda_b, a_crem);
+    dma_offsets<TB, BN, THREADS, BK, CFG::B_DMA>(vob, wave, lane, ldb_b, b_crem);
     const bool ktail = (g.K % BK) != 0;
     auto stage = [&](int kt, int bo) {
         const int k0 = kt * BK;
@@ -324,9 +334,10 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
             kda = g.e.a_seg_off[sg] + kseg;
             kdb = g.e.b_seg_off[sg] + kseg;
         }
+        if (MICO_GEMM_ABLATE == 1 && kt >= kt0 + 3) return;   // ablation: no DMA in the steady state
         if (ktail && kt == g.ktiles - 1) {
-            stage_tile<TA, BM, THREADS>(rsa, lds + bo, wave, lane, lda_b, ka, kda, a_crem);
-            stage_tile<TB, BN, THREADS>(rsb, lds + bo + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
+            stage_tile<TA, BM, THREADS, BK>(rsa, lds + bo, wave, lane, lda_b, ka, kda, a_crem);
+            stage_tile<TB, BN, THREADS, BK>(rsb, lds + bo + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
             return;
         }
         const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
@@ -337,15 +348,29 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
 
     s16x8 fa[MT], fb[4];   // fragments of ONE 32-deep k-step
     auto read_k = [&](int bo, int kk) {
+        if (MICO_GEMM_ABLATE == 2 && g.K > 0) {   // ablation: no LDS reads (keep fragments opaque)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fb[j]));
+            return;
+        }
         LDS_AS const char* ta = lds + bo;
         LDS_AS const char* tb = ta + CFG::A_BYTES;
         const int abase = kk ? ab.b1 : ab.b0, bbase = kk ? bb.b1 : bb.b0;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = read_frag_b<TA, BM>(ta, abase, i);
+        for (int i = 0; i < MT; ++i) fa[i] = read_frag_b<TA, BM, BK>(ta, abase, i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = read_frag_b<TB, BN>(tb, bbase, j);
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag_b<TB, BN, BK>(tb, bbase, j);
     };
     auto mma_k = [&]() {
+        if (MICO_GEMM_ABLATE == 3 && g.K > 0) {   // ablation: no MFMA (keep operands live)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[j]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -358,23 +383,29 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
         for (int t = 0; t < T_; ++t) {
             __syncthreads();   // stage `bo` landed (vmcnt(0) precedes the barrier); the other stage is no longer being read
             if (t + 1 < T_) stage(kt0 + t + 1, bo ^ CFG::STAGE_BYTES);
-            read_k(bo, 0);
-            mma_k();
-            read_k(bo, 1);
-            mma_k();
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                read_k(bo, kk);
+                mma_k();
+            }
             bo ^= CFG::STAGE_BYTES;
         }
     } else {
         // see the file header for the schedule.  The two groups run separate straight-line loops with the same number of
         // barriers per K-tile, so the fragment registers have one unambiguous live range in each.
+        static_assert(CFG::KSTEPS == 1 && CFG::STAGES == 4, "ping-pong path: one k-step per tile, 4-stage ring");
+        constexpr int PT = CFG::A_DMA + CFG::B_DMA;           // DMA instructions per thread per tile
+        constexpr int RING = CFG::STAGES * CFG::STAGE_BYTES;   // power of two
         const int grp = wave >> 2;
-        auto head = [&](int t, int bo) {   // tile t landed everywhere; its partner buffer is free: queue tile t+1 into it
-            // lgkmcnt(0): this wave's own LDS reads of the buffer about to be refilled have returned (group1 issued the last
-            // ones of the previous tile just before arriving here); vmcnt(0): its share of tile t has landed
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        auto head = [&](int t) {
+            // this wave's share of tile t has landed (tiles t+1, t+2 may stay in flight) and its own LDS reads of the buffer
+            // that is about to be refilled have returned; the barrier then publishes tile t to every wave
+            const int ahead = T_ - 1 - t;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < T_) stage(kt0 + t + 1, bo ^ CFG::STAGE_BYTES);
         };
         auto bar = [&]() {
             __builtin_amdgcn_sched_barrier(0);
@@ -382,35 +413,29 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        int bo = 0;   // byte offset of the buffer holding tile t (kept opaque so LDS addresses are not hoisted per buffer)
-        if (T_ > 0) stage(kt0, 0);
+        for (int i = 0; i < 3 && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
+        int bo = 0;   // ring offset of tile t (kept opaque so LDS addresses are not hoisted per buffer)
         if (grp == 0) {
             for (int t = 0; t < T_; ++t) {
                 asm volatile("" : "+s"(bo));
-                head(t, bo);
+                head(t);
                 read_k(bo, 0);
-                bar();
-                mma_k();
-                bar();
-                read_k(bo, 1);
+                if (t + 3 < T_) stage(kt0 + t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));   // buffer of tile t-1: free
                 bar();
                 mma_k();
                 __builtin_amdgcn_sched_barrier(0);
-                bo ^= CFG::STAGE_BYTES;
+                bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
             }
         } else {
             for (int t = 0; t < T_; ++t) {
                 asm volatile("" : "+s"(bo));
-                head(t, bo);
-                if (t > 0) mma_k();      // k-step 1 of the previous tile (fragments read in the last phase of that tile)
+                head(t);
+                if (t > 0) mma_k();      // tile t-1 (fragments read in the second phase of that tile)
                 bar();
                 read_k(bo, 0);
-                bar();
-                mma_k();
-                bar();
-                read_k(bo, 1);
+                if (t + 3 < T_) stage(kt0 + t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                bo ^= CFG::STAGE_BYTES;
+                bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
             }
             if (T_ > 0) mma_k();
         }
@@ -439,13 +464,13 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
 
 // split factor for fp32-accumulating (weight-gradient) GEMMs: fill `slots` resident workgroups in whole waves.
 // cost(s) = waves(s) * (k-tiles per split + fixed prologue / atomic-epilogue cost in k-tile units)
-int auto_split(int tiles, int ktiles, int slots) {
+int auto_split(int tiles, int ktiles, int slots, int min_tiles, int fixed) {
     int best = 1;
     long best_cost = -1;
     for (int s = 1; s <= 32; ++s) {
-        if (s > 1 && ktiles / s < 16) break;
+        if (s > 1 && ktiles / s < min_tiles) break;
         const long waves = ((long)tiles * s + slots - 1) / slots;
-        const long cost = waves * ((ktiles + s - 1) / s + 12);
+        const long cost = waves * ((ktiles + s - 1) / s + fixed);
         if (best_cost < 0 || cost < best_cost) { best = s; best_cost = cost; }
     }
     return best;
@@ -497,15 +522,16 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     const int slots = big ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
     g.ntiles = g.ntm * g.ntn;
-    g.ktiles = (int)((K + BK - 1) / BK);
-    if (split_k <= 0) split_k = (c_dtype == MICO_F32 && g.e.accumulate) ? auto_split(g.ntiles, g.ktiles, slots) : 1;
+    const int BKc = big ? Big::BK : Small::BK;
+    g.ktiles = (int)((K + BKc - 1) / BKc);
+    if (split_k <= 0) split_k = (c_dtype == MICO_F32 && g.e.accumulate) ? auto_split(g.ntiles, g.ktiles, slots, big ? 32 : 16, big ? 24 : 12) : 1;
     if (split_k > g.ktiles) split_k = g.ktiles;
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
     g.split_k = split_k;
     g.ka_rows = g.kb_rows = K;
     if (g.e.nseg > 0) {
-        MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % BK == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
+        MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % 64 == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
                    "mico_gemm: k-segments need nseg <= 3, kseg %% 64 == 0 and nseg * kseg == K");
         g.ka_rows = g.kb_rows = 0;
         for (int i = 0; i < g.e.nseg; ++i) {
