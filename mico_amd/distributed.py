@@ -15,6 +15,10 @@ import torch
 import torch.distributed as dist
 
 
+def _nccl():
+    return dist.get_backend() == "nccl"
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -69,7 +73,10 @@ def packed_all_gather(tensors):
     buf = torch.cat(flat, dim=1).contiguous()
     W = dist.get_world_size()
     out = torch.empty((W * b, buf.shape[1]), dtype=torch.uint8, device=buf.device)
-    dist.all_gather_into_tensor(out, buf) if buf.is_cuda else dist.all_gather(list(out.chunk(W, 0)), buf)
+    if _nccl():
+        dist.all_gather_into_tensor(out, buf)
+    else:
+        dist.all_gather(list(out.chunk(W, 0)), buf)
     res, o = [], 0
     for t, w in zip(tensors, widths):
         piece = out[:, o:o + w].contiguous().view(t.dtype).view(W * b, *t.shape[1:])
@@ -82,9 +89,9 @@ def _exchange(send, send_counts, recv_counts):
     """Variable-size row exchange: send[sum(send_counts), ...] split by destination rank -> received rows by source rank."""
     W = dist.get_world_size()
     recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-    if send.is_cuda:
+    if _nccl():
         dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts)
-    else:   # gloo: emulate with padded all_gather (test path only)
+    else:   # gloo (tests): emulate with a padded all_gather
         mx = torch.tensor([max(send_counts + [1])], device=send.device)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         m = int(mx.item())
@@ -181,6 +188,7 @@ class GradBucketReducer:
 
     def reset(self):
         self._pending = {bi: len(b) for bi, b in enumerate(self.buckets)}
+        self._launched = set()
         self._handles = []
 
     def _hook(self, p):
@@ -190,6 +198,7 @@ class GradBucketReducer:
             self._launch(bi)
 
     def _launch(self, bi):
+        self._launched.add(bi)
         grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
         if not grads:
             return
@@ -200,6 +209,12 @@ class GradBucketReducer:
     def finish(self):
         """Waits for the outstanding all-reduces, writes the averaged gradients back, re-arms the hooks."""
         W = world_size()
+        # buckets holding parameters the step did not touch (unused heads: every rank runs the same task, so the same set)
+        # never complete through the hooks - reduce whatever gradients they do hold now
+        if is_dist():
+            for bi in range(len(self.buckets)):
+                if bi not in self._launched:
+                    self._launch(bi)
         for h, flat, grads in self._handles:
             h.wait()
             flat.div_(W)
