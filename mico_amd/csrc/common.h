@@ -84,11 +84,29 @@ template <typename T> __device__ __forceinline__ s16x8 pack8(const float* o) {
 }
 
 // exact (erf) GELU and its derivative - matches nn.GELU / mico.py:22-28
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erfc(|z|) * via Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7): y = poly(t) * exp(-z^2), t = 1 / (1 + p |z|).  libm's erff costs
+// ~3x more VALU and sits un-overlapped in the GEMM epilogues (measured +40% on the fc1 GEMM).  Returning 1 + erf(z) as 2 - y
+// (z >= 0) or y (z < 0) avoids the cancellation of 1 + erf for negative arguments; e2 = exp(-z^2) is shared with the Gaussian
+// density of the GELU derivative.
+__device__ __forceinline__ float one_plus_erf(float z, float& e2) {
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    e2 = __expf(-az * az);
+    const float y = poly * t * e2;
+    return z >= 0.f ? 2.0f - y : y;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e2;
+    return 0.5f * x * one_plus_erf(x * 0.70710678118654752f, e2);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e2;   // = exp(-x^2 / 2)
+    const float cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
+    return fmaf(x * 0.39894228040143268f, e2, cdf);
 }
 
 // wave64 reductions

@@ -517,7 +517,10 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     }
     // tile configuration: the 256x256 ping-pong kernel whenever it yields enough workgroups to occupy most CUs
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    const bool big = big_tiles >= 128 && N >= 192;
+    // weight-gradient GEMMs (fp32 accumulate, auto split) have few output tiles but a very long reduction: split-K supplies
+    // the parallelism, so the big tile pays as soon as K is long
+    const bool long_k_acc = split_k <= 0 && c_dtype == MICO_F32 && g.e.accumulate && K >= 8192 && big_tiles >= 8;
+    const bool big = (big_tiles >= 128 || long_k_acc) && N >= 192;
     const int BM = big ? 256 : 128, BN = big ? 256 : 128;
     const int slots = big ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);

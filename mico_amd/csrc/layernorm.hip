@@ -157,15 +157,18 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
     }
 }
 
-// folds the per-block partials: 32 columns per workgroup, 8 threads per column stride the partial rows, LDS tree
+// folds the per-block partials: 32 columns x 8 partial-row lanes per workgroup, grid.y splits the partial rows further and
+// the few resulting partial sums are combined with atomics (dgamma/dbeta are accumulated into anyway)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int cols,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float scale) {
     __shared__ float ra[8][33], rb[8][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int k0 = blockIdx.y * per, k1 = min(nblk, k0 + per);
     float a = 0.f, b = 0.f;
     if (c < cols) {
-        for (int k = ry; k < nblk; k += 8) {
+        for (int k = k0 + ry; k < k1; k += 8) {
             a += ws[(int64_t)k * cols + c];
             b += ws[((int64_t)nblk + k) * cols + c];
         }
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     if (ry == 0 && c < cols) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) { a += ra[k][cx]; b += rb[k][cx]; }
-        if (dgamma) dgamma[c] += a * scale;
-        if (dbeta) dbeta[c] += b * scale;
+        if (dgamma) unsafeAtomicAdd(dgamma + c, a * scale);
+        if (dbeta) unsafeAtomicAdd(dbeta + c, b * scale);
     }
 }
 
@@ -257,7 +260,7 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {
-        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
+        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 31) / 32, nblk >= 64 ? 16 : 1), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
         MICO_LAUNCH_CHECK();
     }
     return MICO_OK;
