@@ -179,6 +179,7 @@ int mico_cls_pool_bwd(const float* dpooled, float* dtokens, int b, int n, int64_
 
 /* SwiGLU gate (eva_vit_model.py:217-220): h = silu(x1) * x2, 16-bit in/out, and its backward. */
 int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t n, int dtype, void* stream);
+int mico_swiglu_fwd_f32(const float* x1, const float* x2, float* h, int64_t n, void* stream);   /* fp32 (parity configuration) */
 int mico_swiglu_bwd(const void* x1, const void* x2, const void* dh, void* dx1, void* dx2, int64_t n, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "mico_cls_rows": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp],
     "mico_add_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_int, c_vp],
     "mico_swiglu_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_swiglu_fwd_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "mico_swiglu_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_bert_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp],
     "mico_embed_scatter_add": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_f, c_vp],

@@ -126,6 +126,16 @@ __global__ void swiglu_fwd_kernel(const T* __restrict__ x1, const T* __restrict_
     }
 }
 
+__global__ void swiglu_fwd_f32_kernel(const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ h, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+        const f32x4 a = ((const f32x4*)x1)[i], b = ((const f32x4*)x2)[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = a[k] * sigmoid_f(a[k]) * b[k];
+        ((f32x4*)h)[i] = o;
+    }
+}
+
 template <typename T>
 __global__ void swiglu_bwd_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const T* __restrict__ dh,
                                   T* __restrict__ dx1, T* __restrict__ dx2, int64_t n8) {
@@ -354,6 +364,14 @@ extern "C" int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t 
     MICO_CHECK(dtype_ok(dtype) && x1 && x2 && h && n % 8 == 0, "mico_swiglu_fwd: bad args (n must be a multiple of 8)");
     if (n <= 0) return MICO_OK;
     DISPATCH_T16(dtype, MICO_LAUNCH(swiglu_fwd_kernel<T>, dim3(egrid(n / 8)), dim3(EB), 0, ST, (const T*)x1, (const T*)x2, (T*)h, n / 8));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_swiglu_fwd_f32(const float* x1, const float* x2, float* h, int64_t n, void* stream) {
+    MICO_CHECK(x1 && x2 && h && n % 4 == 0, "mico_swiglu_fwd_f32: bad args (n must be a multiple of 4)");
+    if (n <= 0) return MICO_OK;
+    MICO_LAUNCH(swiglu_fwd_f32_kernel, dim3(egrid(n / 4)), dim3(EB), 0, ST, x1, x2, h, n / 4);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -152,10 +152,22 @@ class EvaTowerFn(torch.autograd.Function):
             Hd = spec.hidden
             if arch["swiglu"]:
                 x1, x2 = _empty((M, Hd), dt, dev), _empty((M, Hd), dt, dev)
-                _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1, bias=P(b + "mlp.w1.bias"))
-                _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2, bias=P(b + "mlp.w2.bias"))
-                hsw = _empty((M, Hd), dt, dev)
-                ops.swiglu_fwd(x1, x2, hsw)
+                if runtime.split_precision():
+                    # parity configuration: the gate runs in fp32 (x1, x2 and the gated product never round to fp16 on the
+                    # forward path); 16-bit copies of x1 / x2 are kept for the backward kernels only
+                    x1f, x2f = _empty((M, Hd), torch.float32, dev), _empty((M, Hd), torch.float32, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=P(b + "mlp.w1.bias"))
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=P(b + "mlp.w2.bias"))
+                    hsw = _empty((M, Hd), torch.float32, dev)
+                    ops.swiglu_fwd_f32(x1f, x2f, hsw)
+                    ops.cast_f32_to_16(x1f, x1)
+                    ops.cast_f32_to_16(x2f, x2)
+                    del x1f, x2f
+                else:
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1, bias=P(b + "mlp.w1.bias"))
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2, bias=P(b + "mlp.w2.bias"))
+                    hsw = _empty((M, Hd), dt, dev)
+                    ops.swiglu_fwd(x1, x2, hsw)
                 hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M, Hd, dt, dev)
                 _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), resid=x_mid, row_scale=dp2,
                           rows_per_scale=N)

@@ -213,6 +213,10 @@ def swiglu_fwd(x1, x2, h):
     check(_lib.lib().mico_swiglu_fwd(_p(x1), _p(x2), _p(h), x1.numel(), dt_code(x1.dtype), _st()), "mico_swiglu_fwd")
 
 
+def swiglu_fwd_f32(x1, x2, h):
+    check(_lib.lib().mico_swiglu_fwd_f32(_p(x1), _p(x2), _p(h), x1.numel(), _st()), "mico_swiglu_fwd_f32")
+
+
 def swiglu_bwd(x1, x2, dh, dx1, dx2):
     check(_lib.lib().mico_swiglu_bwd(_p(x1), _p(x2), _p(dh), _p(dx1), _p(dx2), x1.numel(), dt_code(x1.dtype), _st()),
           "mico_swiglu_bwd")

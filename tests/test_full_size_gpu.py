@@ -1,0 +1,79 @@
+"""BASELINE.json configs at FULL size on the GPU, checked through size-independent properties:
+  * per-sample independence: the features of the first samples inside the full batch equal those of the same samples run
+    alone, and those match the CPU oracle (fp32) within the parity gate;
+  * unit-norm contrastive features; ITC loss recomputed on the host from the product's own features;
+  * one full forward+backward finishes with finite losses and gradients for every parameter the task touches.
+configs[1]: ViT-B/16 image+text contrastive, bs=256, 224^2 + 77 tokens.   configs[2]: ViT-g/14 image+audio+text, bs=64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from common import build_model, rel_err
+from mico_amd import runtime
+from mico_amd.weights import synth_inputs
+from oracle import mico_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_feats(sd, vtype, inp, conds):
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    with torch.no_grad():
+        enc = O.encode_batch(sdo, O.ARCHS[vtype], inp)
+        return enc["feat_t"], {c: O.feat_cond(sdo, enc, c) for c in conds}
+
+
+@pytest.mark.parametrize("name,vtype,cfg,task,conds,nsub", [
+    ("config2", "evaclip02_base", dict(b=256, vision=1, S=77), "ret%tv", ("v",), 4),
+    ("config3", "evaclip01_giant", dict(b=64, vision=1, audio=4, S=77), "ret%tva_cap%tva", ("va",), 1),
+])
+def test_full_size_config(cuda, name, vtype, cfg, task, conds, nsub):
+    torch.set_num_threads(32)
+    m, sd = build_model(vtype, None, device=cuda)
+    inp = synth_inputs(cfg, seed=4321)
+    dev_inp = {k: v.to(cuda) for k, v in inp.items()}
+    sub = {k: v[:nsub] for k, v in inp.items()}
+    ref_t, ref_c = _oracle_feats(sd, vtype, sub, conds)
+    with runtime.precision(torch.float16), torch.no_grad():
+        enc_full = m.encode_batch(dict(dev_inp))
+        enc_sub = m.encode_batch({k: v[:nsub].contiguous() for k, v in dev_inp.items()})
+        for c in conds:
+            f_full, f_sub = m._feat_cond(enc_full, c), m._feat_cond(enc_sub, c)
+            assert rel_err(f_full[:nsub], f_sub) < 2e-4, "samples are not independent of their batch"
+            assert rel_err(f_sub, ref_c[c]) < 1e-3
+            assert (f_full.norm(dim=-1) - 1).abs().max() < 1e-5
+        assert rel_err(enc_full["feat_t"][:nsub], enc_sub["feat_t"]) < 2e-4
+        assert rel_err(enc_sub["feat_t"], ref_t) < 1e-3
+    # throughput configuration: one full training step, losses against a host recomputation from the product's features
+    m.train()
+    with runtime.precision(torch.bfloat16):
+        m.zero_grad(set_to_none=True)
+        out = m(dict(dev_inp), task)
+        sum(out.values()).backward()
+        with torch.no_grad():
+            enc = m.encode_batch(dict(dev_inp))   # DropPath draws differ -> compare in eval mode below
+    for k, v in out.items():
+        assert torch.isfinite(v), k
+    used = [n for n, p in m.named_parameters() if p.grad is not None]
+    assert len(used) > 300
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    m.eval()
+    with runtime.precision(torch.bfloat16), torch.no_grad():
+        out_e = m(dict(dev_inp), "ret%" + task.split("_")[0].split("%", 1)[1] if False else task.split("_")[0], compute_loss=False)
+        ft = out_e["feat_t"].float().cpu()
+        st = task.split("_")[0].split("%")[1]
+        fc = out_e[f"feat_cond_{st}"].float().cpu()
+        temp = float(m.contra_temp)
+        tgt = torch.arange(ft.shape[0])
+        itc_host = (F.cross_entropy(fc @ ft.t() / temp, tgt, label_smoothing=0.1)
+                    + F.cross_entropy(ft @ fc.t() / temp, tgt, label_smoothing=0.1)) / 2
+    m2 = m
+    with runtime.precision(torch.bfloat16), torch.no_grad():
+        b2 = dict(dev_inp)
+        b2["_injected"] = {st: dict(neg_cond_idx=torch.arange(ft.shape[0]).roll(1), neg_text_idx=torch.arange(ft.shape[0]).roll(1))}
+        loss_e = m2(b2, "ret%" + st)["loss_itc"]
+    assert abs(float(loss_e) - float(itc_host)) < 2e-3 * float(itc_host)
+    print(name, {k: float(v) for k, v in out.items()}, "itc(eval)", float(loss_e), float(itc_host))
