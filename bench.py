@@ -154,8 +154,19 @@ def main():
     tot_ms = sum(v["ms"] for v in summ.values())
     dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
     achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from the separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01_gemm_hbm_traffic.json, FETCH_SIZE
+    # doubled as MI355X_MICROARCH.md prescribes for gfx950).  null when that profile is not present.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+    if os.path.exists(tpath) and world == 1:
+        tj = json.load(open(tpath))
+        key = {(0, 0): "NN_big", (0, 1): "dX_big", (1, 1): "dW_big"}[dom[0]]
+        if key in tj:
+            traffic = tj[key]["hbm_bytes_per_launch"]
     roofline = dict(bound="mfma", kernel=names[dom[0]], achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / MFMA_PEAK_TFLOPS, traffic=None, launches=dom[1]["launches"],
+                    frac=achieved / MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
+                    launches=dom[1]["launches"],
                     avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
                     all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
     workload = "vitg_img1_aud4_txt77_stepB"
