@@ -15,34 +15,53 @@ namespace {
 constexpr float NEG_BIG = -1.0e30f;
 
 template <int HDP> struct Cfg {
-    static constexpr int RS = HDP * 2 + 16;        // LDS row stride in bytes (pad one 16-B chunk: de-phases the banks)
+    // LDS row stride: 256 B = 16 chunk slots (<= 12 used) with the 16-byte chunk index XOR-ed by 2*(row & 7).  With that key
+    // both access modes of a tile are bank-conflict free: ds_read_b128 row fragments (16 rows x 2 adjacent chunk columns per
+    // lane group) and ds_read_b64_tr_b16 (8 consecutive rows x one chunk pair per half-wave) - the +16-byte padding used
+    // before measured 0.4 conflict cycles per LDS-active cycle.
+    static constexpr int RS = 256;
     static constexpr int TILE = 64 * RS;           // one [64][HDP] tile
     static constexpr int KS = HDP / 32;            // k-steps over the head dim
     static constexpr int TD = HDP / 16;            // 16-wide tiles over the head dim
     static constexpr int NCH = 64 * (HDP / 8) / 256;   // 16-B chunks per thread per tile
 };
 
-// global -> registers for a [64][HDP] tile (zero beyond nrows / hd)
-template <typename T, int HDP>
-__device__ __forceinline__ void tile_fetch(s16x8 (&reg)[Cfg<HDP>::NCH], const T* base, int64_t rs, int row0, int nrows,
-                                           int hd, int tid) {
+// Per-thread, loop-invariant addressing of a [64][HDP] tile (16-byte chunk c = it*256 + tid -> tile row, head-dim chunk):
+// global element offset, tile row (1<<20 when the chunk lies beyond the real head dim -> always fetched as zero) and swizzled
+// LDS byte offset.  Computed once per kernel: the divisions by HDP/8 = 12 and the swizzle would otherwise be redone for every
+// tile (the forward kernel was VALU-bound at ~13 VALU instructions per MFMA).
+template <int HDP> struct TileMap {
+    int goff[Cfg<HDP>::NCH], row[Cfg<HDP>::NCH], loff[Cfg<HDP>::NCH];
+};
+template <int HDP>
+__device__ __forceinline__ TileMap<HDP> tile_map(int64_t rs, int hd, int tid) {
+    TileMap<HDP> m;
 #pragma unroll
     for (int it = 0; it < Cfg<HDP>::NCH; ++it) {
         const int c = it * 256 + tid;
         const int row = c / (HDP / 8), ch = c % (HDP / 8);
+        m.goff[it] = (int)(row * rs + ch * 8);
+        m.row[it] = (ch * 8 < hd) ? row : (1 << 20);
+        m.loff[it] = row * Cfg<HDP>::RS + ((ch ^ ((row & 7) << 1)) << 4);
+    }
+    return m;
+}
+// global -> registers for a [64][HDP] tile (zero beyond nrows / hd)
+template <typename T, int HDP>
+__device__ __forceinline__ void tile_fetch(s16x8 (&reg)[Cfg<HDP>::NCH], const T* base, int64_t rs, int row0, int nrows,
+                                           const TileMap<HDP>& m) {
+    const T* b0 = base + (int64_t)row0 * rs;
+#pragma unroll
+    for (int it = 0; it < Cfg<HDP>::NCH; ++it) {
         s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + row < nrows && ch * 8 < hd) v = *(const s16x8*)(base + (int64_t)(row0 + row) * rs + ch * 8);
+        if (row0 + m.row[it] < nrows) v = *(const s16x8*)(b0 + m.goff[it]);
         reg[it] = v;
     }
 }
 template <int HDP>
-__device__ __forceinline__ void tile_commit(const s16x8 (&reg)[Cfg<HDP>::NCH], LDS_AS char* tile, int tid) {
+__device__ __forceinline__ void tile_commit(const s16x8 (&reg)[Cfg<HDP>::NCH], LDS_AS char* tile, const TileMap<HDP>& m) {
 #pragma unroll
-    for (int it = 0; it < Cfg<HDP>::NCH; ++it) {
-        const int c = it * 256 + tid;
-        const int row = c / (HDP / 8), ch = c % (HDP / 8);
-        *(LDS_AS s16x8*)(tile + row * Cfg<HDP>::RS + ch * 16) = reg[it];
-    }
+    for (int it = 0; it < Cfg<HDP>::NCH; ++it) *(LDS_AS s16x8*)(tile + m.loff[it]) = reg[it];
 }
 
 // row-operand fragment straight from global: X[row][ks*32 + (lane>>4)*8 .. +8]
@@ -61,15 +80,17 @@ __device__ __forceinline__ void row_frags(s16x8 (&f)[Cfg<HDP>::KS], const T* bas
 // A-operand fragment of a row-major LDS tile: rows r0 + (lane&15), head-dim chunk ks
 template <int HDP>
 __device__ __forceinline__ s16x8 lds_row_frag(LDS_AS const char* tile, int r0, int ks, int lane) {
-    return *(LDS_AS const s16x8*)(tile + (r0 + (lane & 15)) * Cfg<HDP>::RS + (ks * 32 + (lane >> 4) * 8) * 2);
+    const int row = r0 + (lane & 15), ch = ks * 4 + (lane >> 4);
+    return *(LDS_AS const s16x8*)(tile + row * Cfg<HDP>::RS + ((ch ^ ((row & 7) << 1)) << 4));
 }
 // A-operand fragment of the TRANSPOSED tile: output rows d = td*16 + (lane&15), reduction slots over tile rows
 // (2*s2 + r2)*16 + (lane>>4)*4 + {0..3}
 template <int HDP>
 __device__ __forceinline__ s16x8 lds_tr_frag(LDS_AS const char* tile, int td, int s2, int lane) {
     const int g = lane >> 4, p = lane & 15;
-    const int col_b = (td * 16 + (p & 3) * 4) * 2;
-    const int r_lo = (2 * s2) * 16 + g * 4 + (p >> 2);
+    const int ch = td * 2 + ((p >> 1) & 1), half = (p & 1) * 8;
+    const int r_lo = (2 * s2) * 16 + g * 4 + (p >> 2);   // rows r_lo and r_lo + 16 share (row & 7), hence the swizzle key
+    const int col_b = ((ch ^ ((r_lo & 7) << 1)) << 4) + half;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + r_lo * Cfg<HDP>::RS + col_b));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + (r_lo + 16) * Cfg<HDP>::RS + col_b));
     s16x8 r;
@@ -126,20 +147,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     f32x4 oacc[C::TD];
 #pragma unroll
     for (int t = 0; t < C::TD; ++t) oacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = NEG_BIG, l_run = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;   // running max (log2 domain) and sum
+    const float sc2 = p.scale * 1.4426950408889634f;
 
     const int nt = (p.Sk + 63) / 64;
+    const TileMap<HDP> tm_a = tile_map<HDP>(p.k_rs, p.hd, tid), tm_b = tile_map<HDP>(p.v_rs, p.hd, tid);
     s16x8 kr[C::NCH], vr[C::NCH];
-    tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, p.hd, tid);
-    tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, p.hd, tid);
+    tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, tm_a);
+    tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, tm_b);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
-        tile_commit<HDP>(kr, kt, tid);
-        tile_commit<HDP>(vr, vt, tid);
+        tile_commit<HDP>(kr, kt, tm_a);
+        tile_commit<HDP>(vr, vt, tm_b);
         __syncthreads();
         if (t + 1 < nt) {
-            tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, p.hd, tid);
-            tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, p.hd, tid);
+            tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, tm_a);
+            tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, tm_b);
         }
         // S^T = K Q^T
         f32x4 s[4];
@@ -149,29 +172,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) s[tn] = T16<T>::mfma(lds_row_frag<HDP>(kt, tn * 16, ks, lane), qf[ks], s[tn]);
         }
+        // online softmax in the exp2 domain (v_exp_f32 is 2^x): scores are pre-multiplied by scale * log2(e)
         float mloc = NEG_BIG;
+        const bool edge = (t == nt - 1) && (p.Sk & 63);   // workgroup-uniform: only the ragged last key tile needs bounds
+        if (!p.mask_mode && !edge) {
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = t * 64 + tn * 16 + g * 4 + r;
-                float x = s[tn][r] * p.scale;
-                if (j < p.Sk) {
-                    if (p.mask_mode && i < p.Sq) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk);
-                } else {
-                    x = NEG_BIG;
-                }
-                s[tn][r] = x;
-                mloc = fmaxf(mloc, x);
+            for (int tn = 0; tn < 4; ++tn) {
+                s[tn] *= sc2;
+                mloc = fmaxf(fmaxf(mloc, fmaxf(s[tn][0], s[tn][1])), fmaxf(s[tn][2], s[tn][3]));
             }
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = t * 64 + tn * 16 + g * 4 + r;
+                    float x = s[tn][r] * sc2;
+                    if (j < p.Sk) {
+                        if (p.mask_mode && i < p.Sq) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk) * 1.4426950408889634f;
+                    } else {
+                        x = NEG_BIG;
+                    }
+                    s[tn][r] = x;
+                    mloc = fmaxf(mloc, x);
+                }
+        }
         const float m_new = fmaxf(m_run, group_max(mloc));
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float lloc = 0.f;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[tn][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(s[tn][r] - m_new);
                 s[tn][r] = e;
                 lloc += e;
             }
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
             const int d = td * 16 + g * 4;
             if (d < p.hd) *(s16x4*)(ob + d) = pack4<T>(oacc[td][0] * inv, oacc[td][1] * inv, oacc[td][2] * inv, oacc[td][3] * inv);
         }
-        if (g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = m_run + __logf(l_run);
+        if (g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (m_run + __log2f(l_run)) * 0.6931471805599453f;
     }
 }
 
@@ -251,17 +284,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
     for (int t = 0; t < C::TD; ++t) dqacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = (p.Sk + 63) / 64;
+    const TileMap<HDP> tm_a = tile_map<HDP>(p.k_rs, p.hd, tid), tm_b = tile_map<HDP>(p.v_rs, p.hd, tid);
     s16x8 kr[C::NCH], vr[C::NCH];
-    tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, p.hd, tid);
-    tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, p.hd, tid);
+    tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, tm_a);
+    tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, tm_b);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
-        tile_commit<HDP>(kr, kt, tid);
-        tile_commit<HDP>(vr, vt, tid);
+        tile_commit<HDP>(kr, kt, tm_a);
+        tile_commit<HDP>(vr, vt, tm_b);
         __syncthreads();
         if (t + 1 < nt) {
-            tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, p.hd, tid);
-            tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, p.hd, tid);
+            tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, tm_a);
+            tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, tm_b);
         }
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -341,20 +375,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
         dvacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int nt = (p.Sq + 63) / 64;
+    const TileMap<HDP> tm_a = tile_map<HDP>(p.q_rs, p.hd, tid), tm_b = tile_map<HDP>(p.o_rs, p.hd, tid);
     s16x8 qr[C::NCH], dor[C::NCH];
     float st_l = 0.f, st_d = 0.f;
-    tile_fetch<T, HDP>(qr, qb, p.q_rs, 0, p.Sq, p.hd, tid);
-    tile_fetch<T, HDP>(dor, dob, p.o_rs, 0, p.Sq, p.hd, tid);
+    tile_fetch<T, HDP>(qr, qb, p.q_rs, 0, p.Sq, tm_a);
+    tile_fetch<T, HDP>(dor, dob, p.o_rs, 0, p.Sq, tm_b);
     if (tid < 64 && tid < p.Sq) { st_l = lse[stat_base + tid]; st_d = delta[stat_base + tid]; }
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
-        tile_commit<HDP>(qr, qt, tid);
-        tile_commit<HDP>(dor, dot, tid);
+        tile_commit<HDP>(qr, qt, tm_a);
+        tile_commit<HDP>(dor, dot, tm_b);
         if (tid < 64) { lse_t[tid] = st_l; del_t[tid] = st_d; }
         __syncthreads();
         if (t + 1 < nt) {
-            tile_fetch<T, HDP>(qr, qb, p.q_rs, (t + 1) * 64, p.Sq, p.hd, tid);
-            tile_fetch<T, HDP>(dor, dob, p.o_rs, (t + 1) * 64, p.Sq, p.hd, tid);
+            tile_fetch<T, HDP>(qr, qb, p.q_rs, (t + 1) * 64, p.Sq, tm_a);
+            tile_fetch<T, HDP>(dor, dob, p.o_rs, (t + 1) * 64, p.Sq, tm_b);
             st_l = 0.f; st_d = 0.f;
             const int ii = (t + 1) * 64 + tid;
             if (tid < 64 && ii < p.Sq) { st_l = lse[stat_base + ii]; st_d = delta[stat_base + ii]; }
