@@ -41,23 +41,29 @@ def load_from_pretrained_dir(pretrain_dir, video_resolution=224, return_modal="f
             new_ckpt[k] = v.float()
     checkpoint = new_ckpt
     if model_cfg.frame_embedding_type == "adaptive":
-        for key, n in (("vision_frame_embedding", model_cfg.max_vision_sample_num),
-                       ("audio_frame_embedding", model_cfg.max_audio_sample_num)):
-            alt = "vision_perceiver." + key
-            kk = key if key in checkpoint else (alt if alt in checkpoint else None)
-            if kk is not None and checkpoint[kk].shape[1] != n:
-                checkpoint[kk] = F.interpolate(checkpoint[kk].float().permute(0, 2, 1), n, mode="nearest").permute(0, 2, 1)
-    if model_cfg.vision_encoder_type.startswith("evaclip"):
-        pk = "vision_encoder.visual.pos_embed"
-        src = checkpoint[pk][0].float()
-        width = src.shape[-1]
-        patch = checkpoint["vision_encoder.visual.patch_embed.proj.weight"].shape[-1]
-        grid = round((src.shape[0] - 1) ** 0.5)
+        vkey = "vision_frame_embedding" if "vision_frame_embedding" in checkpoint else "vision_perceiver.vision_frame_embedding"
+        wanted = [(vkey, model_cfg.max_vision_sample_num)]      # a checkpoint with neither vision key is a KeyError, as upstream
+        if "audio_frame_embedding" in checkpoint:
+            wanted.append(("audio_frame_embedding", model_cfg.max_audio_sample_num))
+        for key, n in wanted:
+            emb = checkpoint[key]
+            if emb.shape[1] != n:
+                checkpoint[key] = F.interpolate(emb.permute(0, 2, 1), n, mode="nearest").permute(0, 2, 1)
+    vtype = model_cfg.vision_encoder_type
+    if vtype.startswith("clip") or vtype.startswith("evaclip"):
+        # OpenAI-CLIP towers keep a 2-D table, EVA towers a [1, 1+g*g, D] one; both resize the patch part bilinearly
+        eva = vtype.startswith("evaclip")
+        pk = "vision_encoder.visual.pos_embed" if eva else "vision_encoder.visual.positional_embedding"
+        wk = "vision_encoder.visual.patch_embed.proj.weight" if eva else "vision_encoder.visual.conv1.weight"
+        table = checkpoint[pk][0] if eva else checkpoint[pk]
+        width, patch = table.shape[-1], checkpoint[wk].shape[-1]
+        grid = round((table.shape[0] - 1) ** 0.5)
         new_grid = model_cfg.vision_resolution // patch
         if new_grid != grid:
-            oth = F.interpolate(src[1:].reshape(grid, grid, width).permute(2, 0, 1).unsqueeze(0), (new_grid, new_grid), mode="bilinear")
-            oth = oth[0].permute(1, 2, 0).reshape(-1, width)
-            checkpoint[pk] = torch.cat((src[0:1], oth), dim=0).unsqueeze(0)
+            oth = table[1:].reshape(grid, grid, width).permute(2, 0, 1).unsqueeze(0)
+            oth = F.interpolate(oth, (new_grid, new_grid), mode="bilinear")[0].permute(1, 2, 0).reshape(-1, width)
+            table = torch.cat((table[0:1], oth), dim=0)
+            checkpoint[pk] = table.unsqueeze(0) if eva else table
     if return_modal == "uni":
         out = defaultdict()
         for k in checkpoint:

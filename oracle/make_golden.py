@@ -292,6 +292,46 @@ def vit_full_fixture():
     print("wrote vit_g14_full.pt")
 
 
+def ckpt_fixture():
+    """Reference load_from_pretrained_dir (inference_demo.py:14-116) on tiny synthetic pretrain dirs: stored (pre-rename) state
+    dict + hps.json in, remapped/interpolated state dict out, for the evaclip and clip table layouts and return_modal variants."""
+    import json
+    import tempfile
+    ref = ref_import.load()
+    with ref.cwd():
+        import inference_demo as ref_demo
+    g = torch.Generator().manual_seed(7)
+    r = lambda *s: torch.randn(*s, generator=g)
+    cases = {}
+    for name, vtype in (("evaclip", "evaclip01_giant"), ("clip", "clip_vit_base_16")):
+        stored = {
+            "video_frame_embedding": r(1, 4, 8), "audio_frame_embedding": r(1, 2, 8), "video_type_embeddings": r(1, 1, 8),
+            "multimodal_encoder.bert.embeddings.word_embeddings.weight": r(6, 8).half(),
+            "multimodal_encoder.cls.predictions.bias": r(6),
+            "video_encoder.blocks.0.w": r(3, 3), "contra_head_t.linear.weight": r(4, 8).double(),
+        }
+        if name == "evaclip":
+            stored["evaclip_model.visual.pos_embed"] = r(1, 1 + 9, 8)
+            stored["evaclip_model.visual.patch_embed.proj.weight"] = r(8, 3, 2, 2).half()
+        else:
+            stored["clip_model.visual.positional_embedding"] = r(1 + 9, 8)
+            stored["clip_model.visual.conv1.weight"] = r(8, 3, 2, 2)
+        hps = dict(model_cfg=dict(frame_embedding_type="adaptive", max_vision_sample_num=8, max_audio_sample_num=3,
+                                  vision_encoder_type=vtype, vision_resolution=10))
+        d = tempfile.mkdtemp()
+        os.makedirs(os.path.join(d, "ckpt")); os.makedirs(os.path.join(d, "log"))
+        json.dump(hps, open(os.path.join(d, "log", "hps.json"), "w"))
+        torch.save({"stale": torch.zeros(1)}, os.path.join(d, "ckpt", "model_step_9.pt"))
+        torch.save(stored, os.path.join(d, "ckpt", "model_step_10.pt"))
+        outs = {}
+        for modal in ("full", "uni", "text"):
+            ck, cfg = ref_demo.load_from_pretrained_dir(d, return_modal=modal)
+            outs[modal] = {k: v.clone() for k, v in ck.items()}
+        cases[name] = dict(stored=stored, hps=hps, outs=outs)
+    torch.save(cases, os.path.join(OUT, "ckpt_remap.pt"))
+    print("wrote ckpt_remap.pt")
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -322,6 +362,8 @@ def main(which):
         del mg
     if want("full"):
         vit_full_fixture()
+    if want("ckpt"):
+        ckpt_fixture()
 
 
 if __name__ == "__main__":

@@ -47,3 +47,23 @@ def test_loader_and_processor(tmp_path):
     assert p(str(tmp_path / "missing.jpg")) is None
     open(str(tmp_path / "bad.jpg"), "w").write("x")
     assert p(str(tmp_path / "bad.jpg")) is None
+
+
+def test_loader_against_reference_golden(tmp_path):
+    """tests/golden/ckpt_remap.pt holds outputs of the reference's own load_from_pretrained_dir (oracle/make_golden.py ckpt):
+    same keys, dtypes and values, bit-exact, for the EVA and OpenAI-CLIP table layouts and every return_modal."""
+    import inference_demo as demo
+    cases = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ckpt_remap.pt"))
+    for name, c in cases.items():
+        d = str(tmp_path / name)
+        os.makedirs(os.path.join(d, "ckpt"))
+        os.makedirs(os.path.join(d, "log"))
+        json.dump(c["hps"], open(os.path.join(d, "log", "hps.json"), "w"))
+        torch.save({"stale": torch.zeros(1)}, os.path.join(d, "ckpt", "model_step_9.pt"))
+        torch.save(c["stored"], os.path.join(d, "ckpt", "model_step_10.pt"))
+        for modal, want in c["outs"].items():
+            got, cfg = demo.load_from_pretrained_dir(d, return_modal=modal)
+            assert set(got) == set(want), (name, modal)
+            for k in want:
+                assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (name, modal, k)
+            assert cfg.max_vision_sample_num == 8 and cfg["vision_resolution"] == 10
