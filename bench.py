@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
+    ap.add_argument("--dense-droppath", action="store_true",
+                    help="evaluate dropped residual branches too and multiply them by 0 (the reference's schedule) instead of skipping them")
     return ap.parse_args()
 
 
@@ -97,7 +99,9 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     runtime.set_compute_dtype(dtype)
-    torch.manual_seed(0)
+    torch.manual_seed(rank)     # host RNG: stochastic-depth draws differ per rank (weights/inputs come from counter hashes)
+    from mico_amd.functional import DropPlan
+    DropPlan.skip_dropped = not args.dense_droppath
     cfg = default_cfg(args.vision, vision_layers=args.layers)
     model = MiCo(cfg)
     sd_cpu = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
@@ -124,6 +128,7 @@ def main():
         dist.barrier()
     timer = ops.KernelTimer()
     ops.GEMM_TIMER = timer
+    DropPlan.stats[:] = [0, 0]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -171,7 +176,13 @@ def main():
                     all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
     workload = "vitg_img1_aud4_txt77_stepB"
     full = args.layers is None and args.vision == "evaclip01_giant" and args.task == "ret%tva_cap%tva"
-    step_tflops = ALG_TFLOP_PER_SAMPLE[workload] * value / world if full else None
+    # stochastic depth: a dropped (block, branch, frame) contributes exactly zero to values and gradients, so the engine does
+    # not evaluate it.  The nominal (dense) FLOP count is what the reference executes; the executed count scales the ViT-block
+    # share (5 frames x 40 blocks x 13.341 GF x 3 = 8.00 of the 8.74 TF/sample) by the kept fraction of this run's draws.
+    kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
+    nominal = ALG_TFLOP_PER_SAMPLE[workload]
+    executed = nominal - 8.00 * (1.0 - kept)
+    step_tflops = executed * value / world if full else None
     res = {
         "metric": "omni-modal samples/sec (ViT-g/14 fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -179,11 +190,15 @@ def main():
         "config": {"workload": f"BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, "
                                f"b={b}/GPU, task {args.task} (ITC+ITM+CAP)", "per_gpu_batch": b, "global_batch": b * world,
                    "vision": args.vision, "vit_layers": args.layers or "full", "parallelism": f"dp{world}",
-                   "droppath": not args.eval_mode, "bert_dropout": False},
+                   "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),
+                   "droppath_schedule": ("dense: every branch evaluated then scaled by 0 | 1/keep" if args.dense_droppath
+                                         else "dropped (block, branch, frame) triples are skipped - exact, zero contribution"),
+                   "kept_branch_fraction": kept, "bert_dropout": False},
         "samples_per_sec_per_gpu": value / world,
-        "step_algorithmic_tflops_per_gpu": step_tflops,
+        "step_executed_tflops_per_gpu": step_tflops,
+        "tflop_per_sample": {"dense_nominal": nominal, "executed": executed},
         "step_mfma_frac": (step_tflops / MFMA_PEAK_TFLOPS) if step_tflops else None,
-        "losses": {k: float(v) for k, v in losses.items()},
+        "losses": {k: float(v.detach()) for k, v in losses.items()},
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
         "roofline": roofline,
     }

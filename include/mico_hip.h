@@ -79,6 +79,11 @@ typedef struct mico_gemm_epilogue {
      * x_hi W_hi + x_lo W_hi + x_hi W_lo  (~22 mantissa bits from fp16 MFMAs).  nseg == 0 disables. */
     int nseg, kseg;
     int a_seg_off[3], b_seg_off[3];
+    /* frame scatter (stochastic-depth frame skipping): the M rows are a compacted list of whole frames; row m is written to
+     * (and resid / pos / row_scale are indexed with) row  row_map[m / rows_per_map] * rows_per_map + m % rows_per_map.
+     * NULL = identity.  Not combinable with remap_group. */
+    const int* row_map;
+    int rows_per_map;
 } mico_gemm_epilogue;
 
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
@@ -93,22 +98,28 @@ int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
  *   post_add (optional, fp32 [post_groups, cols]): y += post_add[(row / post_rows_per_group) % post_groups]
  *   (frame + type embeddings of model/mico.py:201,209).
  *   y16_split != 0: y16 is [rows, 2*cols] = [hi | lo] with lo = T(y - hi) (A operand of a split-precision mico_gemm).
+ *   frame_map (optional, int32 [rows / rows_per_frame]): input row r is read from row
+ *   frame_map[r / rows_per_frame] * rows_per_frame + r % rows_per_frame of x (compacting gather of whole frames; all outputs
+ *   are compact);  x_copy (optional, fp32 [rows, cols]) receives the gathered input rows (saved for the backward).
  * ------------------------------------------------------------------------------------------------------------- */
 int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                        void* y16, float* y32, float* mean, float* rstd,
                        int64_t rows, int cols, float eps,
                        const float* post_add, int post_rows_per_group, int post_groups, int y16_split,
+                       const int* frame_map, int rows_per_frame, float* x_copy,
                        int dtype, void* stream);
 /* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
  * (dx16 = T(dx * scale16)).
  * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced
- * and ACCUMULATED (+=) into dgamma/dbeta (fp32 [cols]) scaled by grad_scale. */
+ * and ACCUMULATED (+=) into dgamma/dbeta (fp32 [cols]) scaled by grad_scale.
+ * frame_map (optional): dx_add and dx32 are indexed with the scattered row
+ * frame_map[r / rows_per_frame] * rows_per_frame + r % rows_per_frame (dy, x, mean, rstd, dx16 stay compact). */
 int mico_layernorm_bwd_nblk(int64_t rows);
 int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        const float* dx_add, float* dx32, void* dx16, float scale16,
                        float* dgamma, float* dbeta, float grad_scale, float* ws,
-                       int64_t rows, int cols, int dtype, void* stream);
+                       int64_t rows, int cols, const int* frame_map, int rows_per_frame, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (flash style: scores never materialised), forward and backward.
@@ -156,10 +167,13 @@ int mico_cast_f32_to_16(const float* src, int64_t ld_src, void* dst, int64_t ld_
 int mico_cast_16_to_f32(const void* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int cols,
                         float scale, int accumulate, int dtype, void* stream);
 /* dst16[m', :] = T(scale * row_scale[m'/rows_per_scale] * src32[m, :]) with the same row remap as the GEMM epilogue
- * (gathers token rows out of the residual-gradient stream, skipping CLS rows).  rows = number of output rows. */
+ * (gathers token rows out of the residual-gradient stream, skipping CLS rows).  rows = number of output rows.
+ * frame_map (optional, int32): source row = frame_map[m' / rows_per_frame] * rows_per_frame + m' % rows_per_frame
+ * (compacting gather of whole frames); row_scale is indexed with the SOURCE row in both remap modes. */
 int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
                           int remap_group, int remap_skip, int remap_offset,
-                          const float* row_scale, int rows_per_scale, float scale, int dtype, void* stream);
+                          const float* row_scale, int rows_per_scale, float scale,
+                          const int* frame_map, int rows_per_frame, int dtype, void* stream);
 /* out[c] (+)= scale * sum_r x[r, c]   (bias gradients, positional-table gradients).  x fp32 or 16-bit. */
 int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows, int cols, float* out, float scale, int accumulate,
                 void* stream);

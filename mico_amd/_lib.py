@@ -26,6 +26,7 @@ class GemmEpilogue(C.Structure):
         ("row_scale", c_vp), ("rows_per_scale", c_int), ("resid", c_vp), ("pos", c_vp), ("pos_rows", c_int),
         ("remap_group", c_int), ("remap_skip", c_int), ("remap_offset", c_int), ("alpha", c_f), ("accumulate", c_int),
         ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
+        ("row_map", c_vp), ("rows_per_map", c_int),
     ]
 
 
@@ -44,17 +45,18 @@ PROTOTYPES = {
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
-                           c_int, c_int, c_vp],
+                           c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
     "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
-                           c_i64, c_int, c_int, c_vp],
+                           c_i64, c_int, c_vp, c_int, c_int, c_vp],
     "mico_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_rope": [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "mico_im2row": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "mico_cast_f32_to_16": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_f, c_int, c_vp],
     "mico_cast_16_to_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f, c_int, c_int, c_vp],
-    "mico_gather_rows_cast": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_int, c_f, c_int, c_vp],
+    "mico_gather_rows_cast": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_int, c_f, c_vp, c_int,
+                              c_int, c_vp],
     "mico_colsum": [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_f, c_int, c_vp],
     "mico_cls_rows": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp],
     "mico_add_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_int, c_vp],

@@ -200,8 +200,9 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         if (m >= g.M) continue;
         int64_t mo = m;
         if (e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
+        else if (e.row_map) { const int64_t f = m / e.rows_per_map; mo = (int64_t)e.row_map[f] * e.rows_per_map + (m - f * e.rows_per_map); }
         float rscale = 1.f;
-        if (e.row_scale) rscale = e.row_scale[m / e.rows_per_scale];
+        if (e.row_scale) rscale = e.row_scale[(e.row_map ? mo : m) / e.rows_per_scale];
         f32x4 v4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + (((q * 4 + v) ^ (row & 15)) << 4)) + bias4[v];
@@ -545,11 +546,12 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     }
     if (g.split_k > 1) {
         MICO_CHECK(c_dtype == MICO_F32 && g.e.accumulate, "mico_gemm: split_k > 1 needs fp32 accumulate output");
-        MICO_CHECK(!g.e.bias && !g.e.aux_out && g.e.act == MICO_ACT_NONE && !g.e.row_scale && !g.e.resid && !g.e.pos && !g.e.remap_group,
+        MICO_CHECK(!g.e.bias && !g.e.aux_out && g.e.act == MICO_ACT_NONE && !g.e.row_scale && !g.e.resid && !g.e.pos && !g.e.remap_group && !g.e.row_map,
                    "mico_gemm: split_k > 1 supports only the alpha-scaled accumulate epilogue");
     }
     if (g.e.act == MICO_ACT_GELU_GRAD) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD needs aux_in");
     if (g.e.row_scale) MICO_CHECK(g.e.rows_per_scale > 0, "mico_gemm: rows_per_scale must be > 0");
+    if (g.e.row_map) MICO_CHECK(g.e.rows_per_map > 0 && !g.e.remap_group, "mico_gemm: row_map needs rows_per_map > 0 and no remap_group");
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
     hipStream_t st = (hipStream_t)stream;
     if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));

@@ -28,13 +28,17 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            float* __restrict__ y32, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, int64_t rows, int cols, float eps,
                                                            const float* __restrict__ post_add, int post_rpg,
-                                                           int post_groups, int split16) {
+                                                           int post_groups, int split16,
+                                                           const int* __restrict__ frame_map, int rpf,
+                                                           float* __restrict__ x_copy) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
     const float inv = 1.0f / (float)cols;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const XT* xr = x + row * cols;
+        int64_t srow = row;
+        if (frame_map) { const int64_t f = row / rpf; srow = (int64_t)frame_map[f] * rpf + (row - f * rpf); }
+        const XT* xr = x + srow * cols;
         f32x4 v[NV];
         float s = 0.f;
 #pragma unroll
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
             const int c = i * 64 + lane;
             if (c < nv) {
                 v[i] = RowIO<XT>::load(xr + c * 4);
+                if (x_copy) *(f32x4*)(x_copy + row * cols + c * 4) = v[i];
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ dx_add,
                                                            float* __restrict__ dx32, T* __restrict__ dx16, float scale16,
-                                                           float* __restrict__ ws, int64_t rows, int cols, float dy_scale) {
+                                                           float* __restrict__ ws, int64_t rows, int cols, float dy_scale,
+                                                           const int* __restrict__ frame_map, int rpf) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -120,13 +126,15 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
             }
         }
         const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
+        int64_t orow = row;   // scattered row of the residual-gradient stream (dx_add / dx32)
+        if (frame_map) { const int64_t f = row / rpf; orow = (int64_t)frame_map[f] * rpf + (row - f * rpf); }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
             if (c < nv) {
                 f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
-                if (dx_add) o += *(const f32x4*)(dx_add + row * cols + c * 4);
-                if (dx32) *(f32x4*)(dx32 + row * cols + c * 4) = o;
+                if (dx_add) o += *(const f32x4*)(dx_add + orow * cols + c * 4);
+                if (dx32) *(f32x4*)(dx32 + orow * cols + c * 4) = o;
                 if (dx16) {
                     o *= scale16;
                     *(s16x4*)(dx16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
@@ -195,8 +203,9 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
 
 template <typename T, typename XT>
 void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
-                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16) {
-#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16)
+                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16,
+                   const int* fmap, int rpf, float* x_copy) {
+#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy)
     if (cols <= 1024) LNF(4);
     else if (cols <= 1536) LNF(6);
     else if (cols <= 2048) LNF(8);
@@ -207,8 +216,8 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
 template <typename T, typename DT, typename XT>
 void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                    const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
-                   int cols, float dy_scale) {
-#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale)
+                   int cols, float dy_scale, const int* fmap, int rpf) {
+#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else LNB(8);
@@ -221,18 +230,20 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows) { return ln_grid(rows); }
 
 extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* y32,
                                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add,
-                                  int post_rows_per_group, int post_groups, int y16_split, int dtype, void* stream) {
+                                  int post_rows_per_group, int post_groups, int y16_split, const int* frame_map,
+                                  int rows_per_frame, float* x_copy, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
     MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
     MICO_CHECK(x_dtype == MICO_F32 || x_dtype == dtype, "mico_layernorm_fwd: x_dtype must be fp32 or dtype");
     if (post_add) MICO_CHECK(post_rows_per_group > 0 && post_groups > 0, "mico_layernorm_fwd: bad post_add grouping");
+    if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_fwd: frame_map needs rows_per_frame > 0");
     if (rows <= 0) return MICO_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_grid(rows));
     DISPATCH_T16(dtype, {
-        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split);
-        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split);
+        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy);
+        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy);
     });
     MICO_LAUNCH_CHECK();
     return MICO_OK;
@@ -241,8 +252,9 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
 extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype, const float* gamma,
                                   const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
                                   float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
-                                  int cols, int dtype, void* stream) {
+                                  int cols, const int* frame_map, int rows_per_frame, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
+    if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_bwd: frame_map needs rows_per_frame > 0");
     MICO_CHECK(dy && x && gamma && mean && rstd, "mico_layernorm_bwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 2048, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 2048 (got %d)", cols);
     MICO_CHECK((dy_dtype == MICO_F32 || dy_dtype == dtype) && (x_dtype == MICO_F32 || x_dtype == dtype), "mico_layernorm_bwd: bad in dtype");
@@ -253,10 +265,10 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     const dim3 grid(nblk);
     float* wsp = (dgamma || dbeta) ? ws : nullptr;
     DISPATCH_T16(dtype, {
-        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
-        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
-        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
-        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale);
+        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
+        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
+        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
+        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {

@@ -64,13 +64,14 @@ class TowerSpec:
         self.kpad1 = (self.P * self.P + 63) // 64 * 64
 
 
-def _ln16(x, g, b, eps, rows, cols, dt, dev):
+def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None):
     """LayerNorm -> 16-bit GEMM operand.  Returns (buf, view, mean, rstd); in the split-precision (fp16 parity) mode buf is
-    [rows, 2*cols] = [hi | lo] and view its hi half."""
+    [rows, 2*cols] = [hi | lo] and view its hi half.  frame_map: compacting gather of whole frames (rows = kept rows)."""
     split = runtime.split_precision() and cols % 64 == 0
     buf = _empty((rows, 2 * cols if split else cols), dt, dev)
     mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
-    ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt)
+    ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt, frame_map=frame_map,
+                      rows_per_frame=rows_per_frame, x_copy=x_copy)
     return buf, (buf[:, :cols] if split else buf), mean, rstd
 
 
@@ -89,6 +90,44 @@ def _qkv_params(P, b, arch):
     return [P(b + "attn.qkv.weight")]
 
 
+class DropPlan:
+    """Host-side plan of one step's stochastic depth (eva_vit_model.py:121-138 drop_path, applied per frame at :409-416).
+    A dropped residual branch contributes exactly zero to the forward value and to every gradient, so the engine does not
+    evaluate it: per (block, branch) the kept frames are compacted (LayerNorm gathers them, the output-projection epilogue
+    scatters them back onto the fp32 residual stream in place) and every GEMM / attention launch in between runs on
+    kept_frames * N rows.  scale [depth, 2, Bf] holds 0 or 1/keep; it is best drawn on the host (no device sync)."""
+
+    skip_dropped = True      # False: evaluate every branch and multiply by the 0 / 1/keep scale (the reference's schedule)
+    stats = [0, 0]           # running (kept, total) branch-frame counts, for bench.py's executed-FLOP accounting
+
+    def __init__(self, scale, n_frames, dev):
+        cpu = scale.detach().to("cpu", torch.float32)
+        assert cpu.shape[1] == 2 and cpu.shape[2] == n_frames, (tuple(cpu.shape), n_frames)
+        self.scale = scale.detach().to(dev, torch.float32).contiguous()
+        keep = (cpu != 0).reshape(-1, n_frames)
+        if not DropPlan.skip_dropped:
+            keep = torch.ones_like(keep)
+        self.counts = keep.sum(-1).tolist()
+        DropPlan.stats[0] += sum(self.counts)
+        DropPlan.stats[1] += keep.numel()
+        frames = keep.nonzero()[:, 1].to(torch.int32)          # row-major: sorted by (block, branch), then frame
+        self.frames = frames.to(dev)
+        self.starts = [0]
+        for c in self.counts:
+            self.starts.append(self.starts[-1] + c)
+        self.n_frames = n_frames
+
+    def branch(self, block, which):
+        """-> (kept frame count, int32 device frame list or None when every frame is kept, [Bf] scale vector)"""
+        j = block * 2 + which
+        cnt = self.counts[j]
+        fmap = None if cnt == self.n_frames else self.frames[self.starts[j]:self.starts[j] + cnt]
+        return cnt, fmap, self.scale[block, which]
+
+    def kept_fraction(self):
+        return sum(self.counts) / float(len(self.counts) * self.n_frames)
+
+
 class EvaTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, groups, dp_scale, *params):
@@ -100,6 +139,7 @@ class EvaTowerFn(torch.autograd.Function):
         depth = arch["depth_built"]
         Bf = sum(g.shape[0] for g in groups)
         M = Bf * N
+        plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
         x = _empty((M, D), torch.float32, dev)
         # ---- patch embedding: im2row + GEMM(+bias +pos, patch rows -> token rows) ; CLS rows ----
         pe_w, pe_b, pos = P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed")
@@ -118,71 +158,88 @@ class EvaTowerFn(torch.autograd.Function):
             f0 += g.shape[0]
         ops.cls_rows(x, Bf, N, P("cls_token").detach().reshape(D), pos2[0])
 
+        def branch_io(i, which):
+            """-> (kept frames, frame list | None, scale vector | None)"""
+            return plan.branch(i, which) if plan is not None else (Bf, None, None)
+
+        def strides3():
+            return dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D), o_strides=(N * D, D))
+
         acts = []
-        strides3 = dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D),
-                        o_strides=(N * D, D))
+        Hd = spec.hidden
         for i in range(depth):
             b = f"blocks.{i}."
             a = {}
-            dp1 = dp_scale[i, 0].contiguous() if dp_scale is not None else None
-            dp2 = dp_scale[i, 1].contiguous() if dp_scale is not None else None
-            # --- attention branch ---
-            ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M, D, dt, dev)
-            qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
-            qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
-            qkv = _empty((M, 3 * D), dt, dev)
-            _gemm_fwd(ln1b, D, _qkv_params(P, b, arch), "qkv", qkv, bias=qkv_bias)
-            if spec.rope is not None:
-                ops.rope(qkv, N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1])
-                ops.rope(qkv[:, D:], N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1])
-            ao = _empty((M, D), dt, dev)
-            lse = _empty((Bf, H, N), torch.float32, dev)
-            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
-            proj_in = ao
-            if arch["subln"]:
-                proj_in, aln, mean_a, rstd_a = _ln16(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"),
-                                                     spec.eps, M, D, dt, dev)
-                a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
-            x_mid = _empty((M, D), torch.float32, dev)
-            _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=dp1,
-                      rows_per_scale=N)
+            # --- attention branch: x <- x + s1 * proj(attn(LN1 x)) on the kept frames ---
+            B1, fmap1, sc1 = branch_io(i, 0)
+            a.update(B1=B1, fmap1=fmap1, sc1=sc1)
+            if B1 > 0:
+                M1 = B1 * N
+                xc1 = _empty((M1, D), torch.float32, dev) if fmap1 is not None else None
+                ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev,
+                                                frame_map=fmap1, rows_per_frame=N, x_copy=xc1)
+                qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
+                qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
+                qkv = _empty((M1, 3 * D), dt, dev)
+                _gemm_fwd(ln1b, D, _qkv_params(P, b, arch), "qkv", qkv, bias=qkv_bias)
+                if spec.rope is not None:
+                    ops.rope(qkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1])
+                    ops.rope(qkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1])
+                ao = _empty((M1, D), dt, dev)
+                lse = _empty((B1, H, N), torch.float32, dev)
+                ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=B1, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3())
+                proj_in = ao
+                if arch["subln"]:
+                    proj_in, aln, mean_a, rstd_a = _ln16(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"),
+                                                         spec.eps, M1, D, dt, dev)
+                    a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
+                # every frame kept: out of place, the input buffer itself is the saved LN input; otherwise the epilogue
+                # scatters the kept frames onto the stream in place and the LN's compact copy (xc1) is what is saved
+                x_mid = _empty((M, D), torch.float32, dev) if fmap1 is None else x
+                _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=sc1,
+                          rows_per_scale=N, row_map=fmap1, rows_per_map=N)
+                a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse)
+                x = x_mid
             # --- MLP branch ---
-            ln2b, ln2, mean2, rstd2 = _ln16(x_mid, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M, D, dt, dev)
-            x_out = _empty((M, D), torch.float32, dev)
-            Hd = spec.hidden
-            if arch["swiglu"]:
-                x1, x2 = _empty((M, Hd), dt, dev), _empty((M, Hd), dt, dev)
-                if runtime.split_precision():
-                    # parity configuration: the gate runs in fp32 (x1, x2 and the gated product never round to fp16 on the
-                    # forward path); 16-bit copies of x1 / x2 are kept for the backward kernels only
-                    x1f, x2f = _empty((M, Hd), torch.float32, dev), _empty((M, Hd), torch.float32, dev)
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=P(b + "mlp.w1.bias"))
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=P(b + "mlp.w2.bias"))
-                    hsw = _empty((M, Hd), torch.float32, dev)
-                    ops.swiglu_fwd_f32(x1f, x2f, hsw)
-                    ops.cast_f32_to_16(x1f, x1)
-                    ops.cast_f32_to_16(x2f, x2)
-                    del x1f, x2f
+            B2, fmap2, sc2 = branch_io(i, 1)
+            a.update(B2=B2, fmap2=fmap2, sc2=sc2)
+            if B2 > 0:
+                M2 = B2 * N
+                xc2 = _empty((M2, D), torch.float32, dev) if fmap2 is not None else None
+                ln2b, ln2, mean2, rstd2 = _ln16(x, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev,
+                                                frame_map=fmap2, rows_per_frame=N, x_copy=xc2)
+                x_out = _empty((M, D), torch.float32, dev) if fmap2 is None else x
+                epi = dict(resid=x, row_scale=sc2, rows_per_scale=N, row_map=fmap2, rows_per_map=N)
+                if arch["swiglu"]:
+                    g1, g2 = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
+                    if runtime.split_precision():
+                        # parity configuration: the gate runs in fp32 (x1, x2 and the gated product never round to fp16 on the
+                        # forward path); 16-bit copies of x1 / x2 are kept for the backward kernels only
+                        x1f, x2f = _empty((M2, Hd), torch.float32, dev), _empty((M2, Hd), torch.float32, dev)
+                        _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=P(b + "mlp.w1.bias"))
+                        _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=P(b + "mlp.w2.bias"))
+                        hsw = _empty((M2, Hd), torch.float32, dev)
+                        ops.swiglu_fwd_f32(x1f, x2f, hsw)
+                        ops.cast_f32_to_16(x1f, g1)
+                        ops.cast_f32_to_16(x2f, g2)
+                        del x1f, x2f
+                    else:
+                        _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", g1, bias=P(b + "mlp.w1.bias"))
+                        _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", g2, bias=P(b + "mlp.w2.bias"))
+                        hsw = _empty((M2, Hd), dt, dev)
+                        ops.swiglu_fwd(g1, g2, hsw)
+                    hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M2, Hd, dt, dev)
+                    _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), **epi)
+                    a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
                 else:
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1, bias=P(b + "mlp.w1.bias"))
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2, bias=P(b + "mlp.w2.bias"))
-                    hsw = _empty((M, Hd), dt, dev)
-                    ops.swiglu_fwd(x1, x2, hsw)
-                hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M, Hd, dt, dev)
-                _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), resid=x_mid, row_scale=dp2,
-                          rows_per_scale=N)
-                a.update(x1=x1, x2=x2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
-            else:
-                h = _empty((M, Hd), dt, dev)
-                act = _empty((M, Hd), dt, dev)
-                _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
-                _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), resid=x_mid, row_scale=dp2,
-                          rows_per_scale=N)
-                a.update(h=h, act=act)
-            a.update(x_in=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, mean2=mean2,
-                     rstd2=rstd2, ln2=ln2, dp1=dp1, dp2=dp2)
+                    h = _empty((M2, Hd), dt, dev)
+                    act = _empty((M2, Hd), dt, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
+                    _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), **epi)
+                    a.update(h=h, act=act)
+                a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=ln2)
+                x = x_out
             acts.append(a)
-            x = x_out
         out = _empty((M, D), torch.float32, dev)
         mean_n, rstd_n = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
         ops.layernorm_fwd(x, P("norm.weight"), P("norm.bias"), spec.eps, out32=out, mean=mean_n, rstd=rstd_n, dtype=dt)
@@ -221,84 +278,95 @@ class EvaTowerFn(torch.autograd.Function):
         ops.layernorm_bwd(dout.contiguous().view(M, D), x_last, P("norm.weight"), mean_n, rstd_n, dx32=g,
                           dgamma=G("norm.weight"), dbeta=G("norm.bias"), dtype=dt)
         ctx.final = None
+        del x_last
         Hd = spec.hidden
         for i in reversed(range(arch["depth_built"])):
             b = f"blocks.{i}."
             a = ctx.acts.pop()
-            # ---------------- MLP branch ----------------
-            g16 = _empty((M, D), dt, dev)
-            ops.gather_rows_cast(g, g16, row_scale=a["dp2"], rows_per_scale=N, scale=S)
-            dln2 = _empty((M, D), torch.float32, dev)
-            if arch["swiglu"]:
-                w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
-                linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
-                ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
-                dhln = _empty((M, Hd), dt, dev)
-                ops.gemm(g16, w16_of(w3), dhln, tb=True, M=M, N=Hd, K=D)
-                dhsw = _empty((M, Hd), dt, dev)
-                ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
-                                  dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
-                dx1, dx2 = dhln, _empty((M, Hd), dt, dev)   # reuse dhln storage for dx1
-                ops.swiglu_bwd(a["x1"], a["x2"], dhsw, dx1, dx2)
-                linear_wgrad(dx1, a["ln2"], G(b + "mlp.w1.weight"), inv_s)
-                linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
-                ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
-                ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
-                ops.gemm(dx1, w16_of(w1), dln2, tb=True, M=M, N=D, K=Hd)
-                ops.gemm(dx2, w16_of(w2), dln2, tb=True, M=M, N=D, K=Hd, accumulate=True)
-                del dhln, dhsw, dx1, dx2
-            else:
-                w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
-                linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
-                ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
-                dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                ops.gemm(g16, w16_of(w2), dh, tb=True, M=M, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
-                linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
-                ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
-                ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M, N=D, K=Hd)
-                del dh
-            ops.layernorm_bwd(dln2, a["x_mid"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
-                              dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt)
+            # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
+            if a["B2"] > 0:
+                M2, fmap2 = a["B2"] * N, a["fmap2"]
+                g16 = _empty((M2, D), dt, dev)
+                ops.gather_rows_cast(g, g16, row_scale=a["sc2"], rows_per_scale=N, scale=S, frame_map=fmap2, rows_per_frame=N)
+                dln2 = _empty((M2, D), torch.float32, dev)
+                if arch["swiglu"]:
+                    w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
+                    linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
+                    ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
+                    dhln = _empty((M2, Hd), dt, dev)
+                    ops.gemm(g16, w16_of(w3), dhln, tb=True, M=M2, N=Hd, K=D)
+                    dhsw = _empty((M2, Hd), dt, dev)
+                    ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
+                                      dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
+                    dx1, dx2 = dhln, _empty((M2, Hd), dt, dev)   # reuse dhln storage for dx1
+                    ops.swiglu_bwd(a["g1"], a["g2"], dhsw, dx1, dx2)
+                    linear_wgrad(dx1, a["ln2"], G(b + "mlp.w1.weight"), inv_s)
+                    linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
+                    ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
+                    ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
+                    ops.gemm(dx1, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
+                    ops.gemm(dx2, w16_of(w2), dln2, tb=True, M=M2, N=D, K=Hd, accumulate=True)
+                    del dhln, dhsw, dx1, dx2
+                else:
+                    w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+                    linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
+                    ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
+                    dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
+                    ops.gemm(g16, w16_of(w2), dh, tb=True, M=M2, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
+                    linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
+                    ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
+                    ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
+                    del dh
+                ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
+                                  dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt, frame_map=fmap2,
+                                  rows_per_frame=N)
+                del dln2, g16
             # ---------------- attention branch ----------------
-            ops.gather_rows_cast(g, g16, row_scale=a["dp1"], rows_per_scale=N, scale=S)
-            wp = P(b + "attn.proj.weight")
-            proj_in = a["aln"] if arch["subln"] else a["ao"]
-            linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
-            ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
-            dao = _empty((M, D), dt, dev)
-            ops.gemm(g16, w16_of(wp), dao, tb=True, M=M, N=D, K=D)
-            if arch["subln"]:
-                dao2 = _empty((M, D), dt, dev)
-                ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,
-                                  dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
-                                  grad_scale=inv_s, dtype=dt)
-                dao = dao2
-            qkv = a["qkv"]
-            dqkv = _empty((M, 3 * D), dt, dev)
-            delta = _empty((Bf, H, N), torch.float32, dev)
-            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["ao"], dao, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
-                         B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
-            if spec.rope is not None:
-                ops.rope(dqkv, N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
-                ops.rope(dqkv[:, D:], N * 3 * D, 3 * D, Bf, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
-            dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
-            ops.colsum(dqkv, dbias, scale=inv_s)
-            G(b + "attn.q_bias").add_(dbias[:D])
-            G(b + "attn.v_bias").add_(dbias[2 * D:])
-            wqkv = runtime.gemm_weight(_qkv_params(P, b, arch), "qkv")[0]
-            if arch["subln"]:
-                dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
-                linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
-                G(b + "attn.q_proj.weight").add_(dwf[:D])
-                G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
-                G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
-            else:
-                linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
-            dln1 = dln2
-            ops.gemm(dqkv, wqkv, dln1, tb=True, M=M, N=D, K=3 * D)
-            ops.layernorm_bwd(dln1, a["x_in"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
-                              dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt)
-            del a, dqkv, dao, dln1, dln2, g16
+            if a["B1"] > 0:
+                B1, fmap1 = a["B1"], a["fmap1"]
+                M1 = B1 * N
+                g16 = _empty((M1, D), dt, dev)
+                ops.gather_rows_cast(g, g16, row_scale=a["sc1"], rows_per_scale=N, scale=S, frame_map=fmap1, rows_per_frame=N)
+                wp = P(b + "attn.proj.weight")
+                proj_in = a["aln"] if arch["subln"] else a["ao"]
+                linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
+                ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
+                dao = _empty((M1, D), dt, dev)
+                ops.gemm(g16, w16_of(wp), dao, tb=True, M=M1, N=D, K=D)
+                if arch["subln"]:
+                    dao2 = _empty((M1, D), dt, dev)
+                    ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,
+                                      dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
+                                      grad_scale=inv_s, dtype=dt)
+                    dao = dao2
+                qkv = a["qkv"]
+                dqkv = _empty((M1, 3 * D), dt, dev)
+                delta = _empty((B1, H, N), torch.float32, dev)
+                ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["ao"], dao, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
+                             B=B1, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
+                if spec.rope is not None:
+                    ops.rope(dqkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
+                    ops.rope(dqkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
+                dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+                ops.colsum(dqkv, dbias, scale=inv_s)
+                G(b + "attn.q_bias").add_(dbias[:D])
+                G(b + "attn.v_bias").add_(dbias[2 * D:])
+                wqkv = runtime.gemm_weight(_qkv_params(P, b, arch), "qkv")[0]
+                if arch["subln"]:
+                    dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
+                    linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
+                    G(b + "attn.q_proj.weight").add_(dwf[:D])
+                    G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
+                    G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
+                else:
+                    linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
+                dln1 = _empty((M1, D), torch.float32, dev)
+                ops.gemm(dqkv, wqkv, dln1, tb=True, M=M1, N=D, K=3 * D)
+                ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
+                                  dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,
+                                  rows_per_frame=N)
+                del dqkv, dao, dln1, g16
+            del a
         # ---------------- patch embedding ----------------
         dpos = torch.zeros(N * D, dtype=torch.float32, device=dev)
         ops.colsum(g, dpos, rows=Bf, cols=N * D, ld=N * D)

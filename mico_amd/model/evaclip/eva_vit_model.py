@@ -143,11 +143,13 @@ class EVAVisionTransformer(nn.Module):
         return self._spec, [p for _, p in named]
 
     def _drop_path_scale(self, n_frames, device):
-        """Per-sample stochastic-depth multipliers (eva_vit_model.py:121-138), drawn on device; None when inactive."""
+        """Per-sample stochastic-depth multipliers (eva_vit_model.py:121-138): 0 or 1/keep per (block, branch, frame); None when
+        inactive.  Drawn on the HOST (torch's CPU generator, so torch.manual_seed governs it): the tower needs the kept-frame
+        lists on the host to size its launches (functional.DropPlan) and a device draw would cost a sync per step."""
         probs = [b.drop_path_prob for b in self.blocks]
         if not self.training or max(probs) == 0.0:
             return None
-        keep = 1.0 - torch.tensor(probs, device=device, dtype=torch.float32).view(-1, 1, 1)
+        keep = 1.0 - torch.tensor(probs, dtype=torch.float32).view(-1, 1, 1)
         mask = torch.bernoulli(keep.expand(len(probs), 2, n_frames))
         return (mask / keep).contiguous()
 

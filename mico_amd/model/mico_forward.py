@@ -47,7 +47,11 @@ def encode_batch(self, batch):
         groups.append(g)
         meta.append((m, b, n))
     if groups:
-        tokens = self.vision_encoder.visual.forward_groups(groups)
+        # injected stochastic-depth multipliers ({modality: [depth, 2, b*n]}; parity tests) are laid out like the frames
+        dps = (batch.get("_injected") or {}).get("drop_path_scale")
+        if dps is not None:
+            dps = torch.cat([dps[m].float().cpu() for m, _, _ in meta], dim=-1)
+        tokens = self.vision_encoder.visual.forward_groups(groups, drop_path_scale=dps)
         f0 = 0
         for m, b, n in meta:
             o = tokens[f0:f0 + b * n].view(b, n, *tokens.shape[-2:])

@@ -56,7 +56,7 @@ def pad8(n):
 
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
          row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
-         accumulate=False, split_k=1, dtype=None, ksegs=None):
+         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0):
     """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
     leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
     dtype = dtype or A.dtype
@@ -81,6 +81,8 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.remap_group, e.remap_skip, e.remap_offset = remap
     e.alpha = alpha
     e.accumulate = 1 if accumulate else 0
+    e.row_map = _p(row_map)
+    e.rows_per_map = rows_per_map
     if ksegs is not None:   # (kseg, a_offsets, b_offsets)
         e.kseg, e.nseg = ksegs[0], len(ksegs[1])
         for i, (ao, bo) in enumerate(zip(ksegs[1], ksegs[2])):
@@ -101,17 +103,22 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
 
 
 def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
-                  post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16):
-    """split16: out16 is [rows, 2*cols] and receives [hi | lo] (split-precision GEMM operand)."""
+                  post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16, frame_map=None,
+                  rows_per_frame=0, x_copy=None):
+    """split16: out16 is [rows, 2*cols] and receives [hi | lo] (split-precision GEMM operand).  frame_map (int32 [frames]):
+    compacting gather of whole frames out of x; the number of rows is then len(frame_map) * rows_per_frame."""
     rows, cols = x.shape[0], x.shape[1]
+    if frame_map is not None:
+        rows = frame_map.shape[0] * rows_per_frame
     rc = _lib.lib().mico_layernorm_fwd(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(out32), _p(mean),
                                        _p(rstd), rows, cols, eps, _p(post_add), post_rows_per_group, post_groups,
-                                       int(split16), dt_code(dtype), _st())
+                                       int(split16), _p(frame_map), rows_per_frame, _p(x_copy), dt_code(dtype), _st())
     check(rc, "mico_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
-                  grad_scale=1.0, dtype=torch.float16):
+                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0):
+    """frame_map: dx_add / dx32 are the full stream, addressed through the frame scatter; dy / x / mean / rstd are compact."""
     rows, cols = x.shape[0], x.shape[1]
     ws = None
     if dgamma is not None or dbeta is not None:
@@ -119,7 +126,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=N
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=x.device)
     rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), dy_scale, _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
                                        _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
-                                       _p(ws), rows, cols, dt_code(dtype), _st())
+                                       _p(ws), rows, cols, _p(frame_map), rows_per_frame, dt_code(dtype), _st())
     check(rc, "mico_layernorm_bwd")
 
 
@@ -183,10 +190,12 @@ def cast_16_to_f32(src, dst, *, scale=1.0, accumulate=False):
     return dst
 
 
-def gather_rows_cast(src, dst, *, remap=(0, 0, 0), row_scale=None, rows_per_scale=0, scale=1.0):
+def gather_rows_cast(src, dst, *, remap=(0, 0, 0), row_scale=None, rows_per_scale=0, scale=1.0, frame_map=None,
+                     rows_per_frame=0):
     rows, cols = dst.shape
     check(_lib.lib().mico_gather_rows_cast(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, remap[0], remap[1],
-                                           remap[2], _p(row_scale), rows_per_scale, scale, dt_code(dst.dtype), _st()),
+                                           remap[2], _p(row_scale), rows_per_scale, scale, _p(frame_map), rows_per_frame,
+                                           dt_code(dst.dtype), _st()),
           "mico_gather_rows_cast")
     return dst
 

@@ -1,0 +1,90 @@
+"""Stochastic depth (train-mode DropPath, eva_vit_model.py:121-138) with INJECTED per-frame masks: the engine skips dropped
+(block, branch, frame) triples entirely (functional.DropPlan: compacting LayerNorm gather, in-place scatter epilogue) while
+the oracle evaluates every branch and multiplies by 0 or 1/keep as the reference does - values and gradients must agree.
+Masks cover: every frame kept in a branch (out-of-place path), a branch with no frame kept, mixed."""
+import pytest
+import torch
+
+from common import build_model, rel_err
+from mico_amd import runtime
+from mico_amd.weights import synth_inputs
+from oracle import mico_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(depth, B, keep, seed):
+    g = torch.Generator().manual_seed(seed)
+    m = (torch.rand(depth, 2, B, generator=g) < keep).float() / keep
+    m[0, 0] = 1.0 / keep          # block 0 attention: all kept  -> out-of-place path with a scale
+    if depth > 1:
+        m[1, 1] = 0.0             # block 1 MLP: nothing kept   -> branch skipped
+        m[1, 0, 0] = 0.0
+        m[1, 0, 1:] = 1.0 / keep
+    return m
+
+
+@pytest.mark.parametrize("vtype", ["evaclip02_base", "evaclip01_giant"])
+def test_tower_frame_skipping(cuda, vtype):
+    torch.set_num_threads(16)
+    depth, B = 3, 5
+    m, sd = build_model(vtype, depth, device=cuda)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    dps = _masks(depth, B, 0.7, 11)
+    pre = "vision_encoder.visual."
+    names = [pre + "blocks.0.norm1.weight", pre + "blocks.1.mlp.%s.weight" % ("w3" if "02" in vtype else "fc2"), pre + "pos_embed",
+             pre + "blocks.2.attn.%s" % ("q_proj.weight" if "02" in vtype else "qkv.weight"), pre + "patch_embed.proj.weight",
+             pre + "blocks.1.norm2.weight", pre + "blocks.2.attn.proj.bias"]
+    sdo = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    ref = O.eva_vit_forward(sdo, x, O.ARCHS[vtype], drop_path_scale=dps)
+    w = torch.randn(ref.shape, generator=g) / ref.numel() ** 0.5
+    (ref * w).sum().backward()
+    vis = m.vision_encoder.visual
+    with runtime.precision(torch.float16):
+        m.zero_grad(set_to_none=True)
+        out = vis.forward_groups([x.to(cuda)], drop_path_scale=dps)
+        (out * w.to(cuda)).sum().backward()
+    e = rel_err(out, ref)
+    print(vtype, "tokens", f"{e:.2e}")
+    assert e < 1e-3
+    named = dict(m.named_parameters())
+    for n in names:
+        if named[n].grad is None:      # parameters of a branch no frame went through get no gradient at all
+            assert sdo[n].grad.abs().max() == 0, n
+            continue
+        ge = rel_err(named[n].grad, sdo[n].grad)
+        print(" ", n, f"{ge:.2e}")
+        assert ge < 2e-2, (n, ge)
+    # the skipped MLP branch of block 1 must leave its parameters without a gradient contribution
+    assert sdo[pre + "blocks.1.norm2.weight"].grad.abs().max() == 0
+    gskip = named[pre + "blocks.1.norm2.weight"].grad
+    assert gskip is None or gskip.abs().max() == 0
+
+
+def test_alignment_step_with_masks(cuda):
+    """Whole alignment step (ITC+ITM+CAP) in train mode with per-modality injected masks, bf16 is the throughput setting but the
+    comparison runs in the fp16 parity configuration."""
+    torch.set_num_threads(16)
+    vtype, depth, b = "evaclip01_giant", 2, 3
+    m, sd = build_model(vtype, depth, device=cuda)
+    inp = synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=77)
+    import random
+    mi, lab = O.token_masker(inp["input_ids"], 0.6, random.Random(0))
+    idx = torch.arange(b).roll(1)
+    dps = {"v": _masks(depth, b * 2, 0.6, 3), "a": _masks(depth, b, 0.6, 4)}
+    inj = {"tva": dict(neg_cond_idx=idx, neg_text_idx=idx), "cap": dict(masked_ids=mi, labels=lab), "drop_path_scale": dps}
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    arch = O.ARCHS[vtype]
+    with torch.no_grad():
+        ref, _ = O.mico_forward(sdo, arch, inp, "ret%tva_cap%tva", dict(itm_ratio=0.1), injected=inj)
+    batch = {k: v.to(cuda) for k, v in inp.items()}
+    batch["_injected"] = inj
+    m.train()
+    with runtime.precision(torch.float16):
+        out = m(batch, "ret%tva_cap%tva", compute_loss=True)
+    for k, v in ref.items():
+        e = abs(out[k].item() - v.item()) / max(abs(v.item()), 1e-6)
+        print(k, out[k].item(), v.item(), f"{e:.2e}")
+        assert e < 2e-3, k
