@@ -27,7 +27,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA
+#ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
+                           // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles
 #define MICO_GEMM_ABLATE 0
 #endif
 
@@ -161,7 +162,8 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char
                                           unsigned koff) {
 #pragma unroll
     for (int it = 0; it < NDMA; ++it) {
-        const unsigned v = (vo[it] == 0xFFFFFFF0u) ? 0xFFFFFFF0u : vo[it] + koff;
+        unsigned v = (vo[it] == 0xFFFFFFF0u) ? 0xFFFFFFF0u : vo[it] + koff;
+        if (MICO_GEMM_ABLATE == 4) v |= 0xFFFFFFF0u;   // ablation: every DMA out of bounds (issue + LDS zero-fill, no memory traffic)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), 16, v, 0, 0, 0);
     }
 }
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     dma_offsets<TB, BN, THREADS, BK, CFG::B_DMA>(vob, wave, lane, ldb_b, b_crem);
     const bool ktail = (g.K % BK) != 0;
     auto stage = [&](int kt, int bo) {
+        if (MICO_GEMM_ABLATE == 5) kt = kt0 + (kt & 1);   // ablation: re-read the first two K-tiles (cache-resident operands)
         const int k0 = kt * BK;
         int ka = k0, kb = k0;
         int64_t kda = g.K, kdb = g.K;
