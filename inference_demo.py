@@ -7,8 +7,8 @@
 `load_from_pretrained_dir(pretrain_dir, video_resolution, return_modal) -> (checkpoint, model_cfg)` keeps the reference's
 contract: reads log/hps.json, picks ckpt/model_step_<max>.pt, renames video->vision / evaclip_model|clip_model->vision_encoder,
 casts to fp32, nearest-interpolates the frame embeddings to max_*_sample_num and bilinearly interpolates the ViT position
-table to the requested resolution.  The demo then encodes the image and the texts, prints the text-to-image similarity and the
-ITM scores.  The caption step (HF beam search over BertForMaskedLM.generate, :161-174) is not built yet.
+table to the requested resolution.  The demo then encodes the image and the texts, prints the text-to-image similarity, the ITM
+scores and a beam-search caption (BertForMaskedLM.generate, :161-174).
 """
 import argparse
 import json
@@ -113,7 +113,17 @@ def run_demo(model, image_input, texts, device="cuda", max_length=30):
     video_input = video_input.expand(input_ids.shape[0], -1, -1).contiguous()
     slice_output = model.forward_multimodal_encoder(input_ids, attention_mask, video_input).sequence_output
     slice_scores = F.softmax(model.itm_head(slice_output[:, 0]), dim=1)[:, 1]
-    return dict(feat_v=feat_v, feat_t=feat_t, sim_t2v=sim_t2v, itm_scores=slice_scores, input_ids=input_ids)
+    # caption generation (inference_demo.py:161-174)
+    cap_input = model.get_multimodal_forward_input_vision(video_output)
+    tk = model.multimodal_encoder.tokenizer
+    init_ids = torch.full((cap_input.size(0), 1), tk.bos_token_id, dtype=torch.long, device=device)
+    outputs = model.multimodal_encoder.generate(input_ids=init_ids, attention_mask=init_ids.new_ones(cap_input.size(0), 1, 1),
+                                                encoder_hidden_states=cap_input, max_new_tokens=model.max_caption_len,
+                                                num_beams=model.beam_size, eos_token_id=tk.sep_token_id,
+                                                pad_token_id=tk.pad_token_id, length_penalty=0.6)
+    captions = tk.batch_decode(outputs[:, 1:], skip_special_tokens=True)
+    return dict(feat_v=feat_v, feat_t=feat_t, sim_t2v=sim_t2v, itm_scores=slice_scores, input_ids=input_ids,
+                caption_ids=outputs, captions=captions)
 
 
 def main():
@@ -141,7 +151,7 @@ def main():
     out = run_demo(model, image_input, args.texts, device)
     print(out["sim_t2v"])
     print(out["itm_scores"])
-    print("caption generation (beam search) is not part of this build yet")
+    print(out["captions"])
 
 
 if __name__ == "__main__":

@@ -200,8 +200,127 @@ class BertForMaskedLM(nn.Module):
         dict.__setitem__(out, "_lazy_logits", _LazyLogits(lambda: Fn.LMLogitsFn.apply(seq.detach(), *[p.detach() for p in hp])))
         return out
 
-    def generate(self, *a, **k):
-        raise NotImplementedError("caption decoding (HF beam search, inference_demo.py:161-174) is SURVEY.md section 8 row f1 - not built yet")
+    # ---- caption decoding (inference_demo.py:161-171; the [MASK]-append protocol of bert.py:1110-1143) -------------------------
+    @staticmethod
+    def update_attention_mask(attention_mask):
+        """bert.py:1110-1117: grow a [b,n,n] mask to [b,n+1,n+1]; the new row copies the last row and sees itself."""
+        b, n, _ = attention_mask.shape
+        up = attention_mask.new_zeros(b, n + 1, n + 1)
+        up[:, :n, :n] = attention_mask
+        up[:, n, :n] = attention_mask[:, n - 1, :n]
+        up[:, n, n] = 1
+        return up
+
+    def prepare_inputs_for_generation(self, input_ids, attention_mask=None, encoder_hidden_states=None, **_):
+        """bert.py:1126-1143: append one [MASK] token whose output row predicts the next token."""
+        dummy = torch.full((input_ids.shape[0], 1), self.tokenizer.mask_token_id, dtype=torch.long, device=input_ids.device)
+        return {"input_ids": torch.cat([input_ids, dummy], dim=1), "attention_mask": self.update_attention_mask(attention_mask),
+                "encoder_hidden_states": encoder_hidden_states}
+
+    @torch.no_grad()
+    def next_token_logits(self, input_ids, attention_mask, encoder_hidden_states):
+        """One decode step of the reference protocol: logits [rows, vocab] of the appended [MASK] position.  Only that row
+        goes through the 768x30522 LM head (the reference evaluates it for every position and slices, bert.py:1085)."""
+        inp = self.prepare_inputs_for_generation(input_ids, attention_mask, encoder_hidden_states)
+        seq = self.bert(inp["input_ids"], inp["attention_mask"], inp["encoder_hidden_states"]).last_hidden_state
+        last = seq[:, -1:, :].contiguous()
+        return Fn.LMLogitsFn.apply(last, *[p.detach() for p in self._head_params()])[:, 0, :]
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, max_new_tokens=20, num_beams=1,
+                 eos_token_id=None, pad_token_id=None, length_penalty=1.0, **unused):
+        """Beam search with the semantics of transformers==4.31 GenerationMixin.generate / BeamSearchScorer as the reference
+        calls it (inference_demo.py:164-171: num_beams 3, length_penalty 0.6, early_stopping False, no logits processors):
+        2*num_beams candidates per step, finished hypotheses scored sum_logprob / len**length_penalty, the "cannot improve"
+        stop heuristic, finalisation with the open beams, eos-terminated pad-filled output.  The search bookkeeping runs on
+        the host over 2*num_beams candidates per sample; the model step and log-softmax / top-k run on the device."""
+        if unused:
+            raise TypeError(f"generate(): unsupported arguments {sorted(unused)}")
+        dev = input_ids.device
+        B, cur = input_ids.shape
+        nb = int(num_beams)
+        max_length = cur + int(max_new_tokens)
+        ids = input_ids.repeat_interleave(nb, dim=0)
+        mask = attention_mask.repeat_interleave(nb, dim=0)
+        enc = encoder_hidden_states.repeat_interleave(nb, dim=0).contiguous() if encoder_hidden_states is not None else None
+        beam_scores = torch.zeros(B, nb, dtype=torch.float32, device=dev)
+        beam_scores[:, 1:] = -1e9
+        beam_scores = beam_scores.view(-1)
+        hyps = [_BeamHypotheses(nb, length_penalty) for _ in range(B)]
+        done = [False] * B
+        while True:
+            logits = self.next_token_logits(ids, mask, enc).float()
+            scores = torch.log_softmax(logits, dim=-1) + beam_scores[:, None]
+            V = scores.shape[-1]
+            top_s, top_i = torch.topk(scores.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
+            top_s, top_i = top_s.cpu(), top_i.cpu()
+            src_beam, tok = top_i // V, top_i % V
+            ids_cpu = ids.cpu()
+            cur_len = ids.shape[1] + 1
+            nxt_s = torch.zeros(B, nb)
+            nxt_t = torch.zeros(B, nb, dtype=torch.long)
+            nxt_b = torch.zeros(B, nb, dtype=torch.long)
+            for b in range(B):
+                if done[b]:
+                    nxt_t[b] = pad_token_id
+                    continue
+                k = 0
+                for rank in range(2 * nb):
+                    row = b * nb + int(src_beam[b, rank])
+                    if eos_token_id is not None and int(tok[b, rank]) == eos_token_id:
+                        if rank >= nb:
+                            continue
+                        hyps[b].add(ids_cpu[row].clone(), float(top_s[b, rank]))
+                    else:
+                        nxt_s[b, k], nxt_t[b, k], nxt_b[b, k] = top_s[b, rank], tok[b, rank], row
+                        k += 1
+                    if k == nb:
+                        break
+                done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+            beam_scores = nxt_s.view(-1).to(dev)
+            ids = torch.cat([ids[nxt_b.view(-1).to(dev)], nxt_t.view(-1, 1).to(dev)], dim=1)
+            mask = self.update_attention_mask(mask)
+            if all(done) or ids.shape[1] >= max_length:
+                break
+        ids_cpu, fin = ids.cpu(), beam_scores.cpu()
+        best = []
+        for b in range(B):
+            if not done[b]:
+                for k in range(nb):
+                    hyps[b].add(ids_cpu[b * nb + k], float(fin[b * nb + k]))
+            best.append(max(hyps[b].beams, key=lambda h: h[0])[1])
+        lens = [int(h.shape[0]) for h in best]
+        width = min(max(lens) + 1, max_length)
+        out = torch.full((B, width), pad_token_id if pad_token_id is not None else 0, dtype=torch.long)
+        for b, h in enumerate(best):
+            out[b, :lens[b]] = h
+            if lens[b] < width:
+                out[b, lens[b]] = eos_token_id
+        return out.to(dev)
+
+
+class _BeamHypotheses:
+    """n-best list of finished hypotheses of one sample (transformers==4.31 BeamHypotheses, early_stopping=False)."""
+
+    def __init__(self, num_beams, length_penalty):
+        self.num_beams, self.length_penalty = num_beams, length_penalty
+        self.beams, self.worst_score = [], 1e9
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)
+        if len(self.beams) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.num_beams:
+                order = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[order[0][1]]
+                self.worst_score = order[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.beams) < self.num_beams:
+            return False
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
 def build_tokenizer():

@@ -435,3 +435,97 @@ def token_masker(tokens, mask_prob, rng, mask_token=103, range_start=106, range_
                     toks[i][j] = rng.choice(list(range(range_start, range_end)))
                 labels[i][j] = src
     return torch.from_numpy(toks).long(), torch.from_numpy(labels).long()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# caption decoding (inference_demo.py:161-174).  The search itself is third-party code the reference tree does not
+# hold: transformers==4.31.0 GenerationMixin.generate -> beam_search + BeamSearchScorer (set_env.sh:12 pins the
+# version); it cannot run under the transformers 5.x of this image, so this restatement follows the published
+# 4.31 algorithm and is NOT pinned by a reference-generated golden ("parity unpinned").
+# The model-side protocol is the reference's own: bert.py:1110-1143 appends a [MASK] token per step, grows the
+# 3-D attention mask causally and takes the logits of the last row; nothing is cached between steps.
+# --------------------------------------------------------------------------------------------------------------
+def grow_mask(m):
+    """bert.py:1110-1117."""
+    b, n, _ = m.shape
+    out = m.new_zeros(b, n + 1, n + 1)
+    out[:, :n, :n] = m
+    out[:, n, :n] = m[:, n - 1, :n]
+    out[:, n, n] = 1
+    return out
+
+
+def decode_step_logits(sd, ids, mask, cond, mask_token_id=103):
+    step_ids = torch.cat([ids, torch.full((ids.shape[0], 1), mask_token_id, dtype=torch.long)], dim=1)
+    seq = bert_forward(sd, step_ids, grow_mask(mask), cond)
+    return bert_lm_logits(sd, seq[:, -1:])[:, 0]
+
+
+def generate_beam(sd, cond, max_new_tokens, num_beams, length_penalty, bos=101, eos=102, pad=0, mask_token_id=103):
+    """cond [B, E, 768] -> token ids [B, <= 1 + max_new_tokens] (first column [CLS]); see the block comment above."""
+    B = cond.shape[0]
+    nb = num_beams
+    ids = torch.full((B * nb, 1), bos, dtype=torch.long)
+    mask = torch.ones(B * nb, 1, 1, dtype=torch.long)
+    cond_x = cond.repeat_interleave(nb, dim=0)
+    running = torch.zeros(B, nb)
+    running[:, 1:] = -1e9
+    running = running.reshape(-1)
+    finished = [[] for _ in range(B)]        # per sample: list of (score, ids), at most nb kept
+    worst = [1e9] * B
+    closed = [False] * B
+    max_length = 1 + max_new_tokens
+
+    def push(b, hyp, logp):
+        score = logp / (hyp.shape[-1] ** length_penalty)
+        if len(finished[b]) < nb or score > worst[b]:
+            finished[b].append((score, hyp))
+            if len(finished[b]) > nb:
+                ranked = sorted((sc, i) for i, (sc, _) in enumerate(finished[b]))
+                del finished[b][ranked[0][1]]
+                worst[b] = ranked[1][0]
+            else:
+                worst[b] = min(score, worst[b])
+
+    while True:
+        logp = torch.log_softmax(decode_step_logits(sd, ids, mask, cond_x, mask_token_id).float(), dim=-1) + running[:, None]
+        V = logp.shape[-1]
+        cand_s, cand_i = torch.topk(logp.view(B, nb * V), 2 * nb, dim=1)
+        new_s, new_t, new_src = torch.zeros(B, nb), torch.zeros(B, nb, dtype=torch.long), torch.zeros(B, nb, dtype=torch.long)
+        length_now = ids.shape[1] + 1
+        for b in range(B):
+            if closed[b]:
+                new_t[b] = pad
+                continue
+            filled = 0
+            for rank in range(2 * nb):
+                t = int(cand_i[b, rank]) % V
+                src = b * nb + int(cand_i[b, rank]) // V
+                if t == eos:
+                    if rank < nb:
+                        push(b, ids[src].clone(), float(cand_s[b, rank]))
+                    continue
+                new_s[b, filled], new_t[b, filled], new_src[b, filled] = cand_s[b, rank], t, src
+                filled += 1
+                if filled == nb:
+                    break
+            if len(finished[b]) >= nb and worst[b] >= float(cand_s[b].max()) / length_now ** length_penalty:
+                closed[b] = True
+        running = new_s.reshape(-1)
+        ids = torch.cat([ids[new_src.reshape(-1)], new_t.reshape(-1, 1)], dim=1)
+        mask = grow_mask(mask)
+        if all(closed) or ids.shape[1] >= max_length:
+            break
+    picks = []
+    for b in range(B):
+        if not closed[b]:
+            for k in range(nb):
+                push(b, ids[b * nb + k], float(running[b * nb + k]))
+        picks.append(sorted(finished[b], key=lambda h: h[0])[-1][1])
+    width = min(max(len(h) for h in picks) + 1, max_length)
+    out = torch.full((B, width), pad, dtype=torch.long)
+    for b, h in enumerate(picks):
+        out[b, :len(h)] = h
+        if len(h) < width:
+            out[b, len(h)] = eos
+    return out

@@ -1,0 +1,50 @@
+"""Caption decoding: BertForMaskedLM.generate on the device against the CPU restatement
+oracle.mico_oracle.generate_beam - token ids bit-exact.  The [SEP] output bias is raised so that end-of-sequence
+candidates actually occur (finished-hypothesis bookkeeping, length penalty, early close, eos/pad fill); num_beams = 1 must
+equal the step-by-step argmax chain."""
+import pytest
+import torch
+
+from common import build_model
+from mico_amd import runtime
+from oracle import mico_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("num_beams,sep_bias,max_new", [(1, 0.0, 6), (3, 0.0, 6), (3, 1.2, 8), (3, 1.5, 8), (3, 1.7, 8), (2, 1.6, 8), (2, 1.8, 8)])
+def test_generate_matches_oracle(cuda, num_beams, sep_bias, max_new):
+    torch.set_num_threads(16)
+    m, sd = build_model("evaclip02_base", 1, device=cuda)
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    bias = sdo["multimodal_encoder.cls.predictions.bias"].clone()
+    bias[102] += sep_bias
+    sdo["multimodal_encoder.cls.predictions.bias"] = bias
+    with torch.no_grad():
+        m.multimodal_encoder.cls.predictions.bias.copy_(bias.to(cuda))
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(3, 7, 768, generator=g)
+    with torch.no_grad():
+        ref = O.generate_beam(sdo, cond, max_new, num_beams, 0.6)
+    tk = m.multimodal_encoder.tokenizer
+    with runtime.precision(torch.float16):
+        init = torch.full((3, 1), tk.bos_token_id, dtype=torch.long, device=cuda)
+        out = m.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(3, 1, 1), encoder_hidden_states=cond.to(cuda),
+                                            max_new_tokens=max_new, num_beams=num_beams, eos_token_id=tk.sep_token_id,
+                                            pad_token_id=tk.pad_token_id, length_penalty=0.6)
+    print(num_beams, sep_bias, out.tolist(), ref.tolist())
+    assert out.cpu().tolist() == ref.tolist()
+    if sep_bias > 0:
+        assert (ref == 102).any(), "the case was meant to produce finished hypotheses"
+    if num_beams == 1 and sep_bias == 0:
+        ids = torch.full((3, 1), 101)
+        mask = torch.ones(3, 1, 1, dtype=torch.long)
+        with torch.no_grad():
+            for _ in range(max_new):
+                t = O.decode_step_logits(sdo, ids, mask, cond).argmax(-1)
+                ids = torch.cat([ids, t[:, None]], 1)
+                mask = O.grow_mask(mask)
+        assert ids.tolist() == ref.tolist()
+    with pytest.raises(TypeError):
+        m.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(3, 1, 1), do_sample=True)

@@ -1,6 +1,6 @@
 """inference_demo.py flow (BASELINE configs[0] plumbing): synthetic pretrain dir with pre-rename keys -> load_from_pretrained_dir
--> MiCo.from_pretrained -> ImageProcessor on a synthetic 428x640 jpeg -> image/text features, similarity, ITM score, against the
-CPU oracle evaluated on the same processed pixels and the same (remapped) weights.  Token ids bit-exact."""
+-> MiCo.from_pretrained -> ImageProcessor on a synthetic 428x640 jpeg -> image/text features, similarity, ITM score, beam-search
+caption, against the CPU oracle evaluated on the same processed pixels and the same (remapped) weights.  Token ids bit-exact."""
 import os
 
 import numpy as np
@@ -55,3 +55,8 @@ def test_demo_flow(cuda, tmp_path):
     assert (out["sim_t2v"].cpu() - ft @ fv.t()).abs().max() < 1e-3
     assert rel_err(out["itm_scores"], sc) < 2e-3
     assert model.vision_encoder.text is None
+    # caption step: same beam search on the oracle's condition tensor, token ids bit-exact
+    with torch.no_grad():
+        cap_ref = O.generate_beam(sdo, O.multimodal_input(sdo, "vision", vo), model.max_caption_len, model.beam_size, 0.6)
+    assert out["caption_ids"].cpu().tolist() == cap_ref.tolist()
+    assert len(out["captions"]) == 1 and isinstance(out["captions"][0], str)
