@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--vision", default="evaclip01_giant")
     ap.add_argument("--layers", type=int, default=None, help="truncate the ViT (debug only; invalidates the metric)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--task", default="ret%tva_cap%tva")
+    ap.add_argument("--task", default=None)
+    ap.add_argument("--workload", default="img_aud_txt", choices=["img_aud_txt", "omni"],
+                    help="img_aud_txt = BASELINE configs[2] (the metric's single-GPU configuration, default); omni = one rank's share "
+                         "of configs[3]: image+video (9 vision frames) + depth + audio + text, 14 frames/sample (not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
@@ -65,7 +68,7 @@ def cpu_baseline(sd_cpu, args):
     torch.set_num_threads(ncores)
     arch = O.ARCHS[args.vision]
     b = args.cpu_batch
-    inp = synth_inputs(dict(b=b, vision=1, audio=4, S=77), seed=99)
+    inp = synth_inputs(dict(b=b, **WORKLOADS[args.workload]["shape"]), seed=99)
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_cpu.items()}
     sd["multimodal_encoder.cls.predictions.decoder.weight"] = sd["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
     mi, lab = O.token_masker(inp["input_ids"], 0.6, random.Random(0))
@@ -80,8 +83,16 @@ def cpu_baseline(sd_cpu, args):
                        f"1 step, {dt:.1f} s on {ncores} threads")
 
 
+WORKLOADS = {
+    "img_aud_txt": dict(shape=dict(vision=1, audio=4, S=77), task="ret%tva_cap%tva", key="vitg_img1_aud4_txt77_stepB", frames=5),
+    "omni": dict(shape=dict(vision=9, depth=1, audio=4, S=77), task="ret%tva%tvd_cap%tva", key="vitg_omni14_txt77", frames=14),
+}
+
+
 def main():
     args = parse()
+    wl = WORKLOADS[args.workload]
+    args.task = args.task or wl["task"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,7 +120,7 @@ def main():
     model.to(dev)
     model.eval() if args.eval_mode else model.train()
     b = args.batch
-    batch = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, vision=1, audio=4, S=77), seed=1234 + rank).items()}
+    batch = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, **wl["shape"]), seed=1234 + rank).items()}
     reducer = GradBucketReducer(model.parameters()) if world > 1 else None
 
     def step():
@@ -174,21 +185,24 @@ def main():
                     launches=dom[1]["launches"],
                     avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
                     all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
-    workload = "vitg_img1_aud4_txt77_stepB"
-    full = args.layers is None and args.vision == "evaclip01_giant" and args.task == "ret%tva_cap%tva"
+    workload = wl["key"]
+    full = args.layers is None and args.vision == "evaclip01_giant" and args.task == "ret%tva_cap%tva" and args.workload == "img_aud_txt"
     # stochastic depth: a dropped (block, branch, frame) contributes exactly zero to values and gradients, so the engine does
     # not evaluate it.  The nominal (dense) FLOP count is what the reference executes; the executed count scales the ViT-block
     # share (5 frames x 40 blocks x 13.341 GF x 3 = 8.00 of the 8.74 TF/sample) by the kept fraction of this run's draws.
     kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
-    nominal = ALG_TFLOP_PER_SAMPLE[workload]
-    executed = nominal - 8.00 * (1.0 - kept)
+    nominal = ALG_TFLOP_PER_SAMPLE.get(workload)
+    executed = nominal - 8.00 * (1.0 - kept) if nominal else None
     step_tflops = executed * value / world if full else None
     res = {
         "metric": "omni-modal samples/sec (ViT-g/14 fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, "
-                               f"b={b}/GPU, task {args.task} (ITC+ITM+CAP)", "per_gpu_batch": b, "global_batch": b * world,
+        "config": {"workload": (f"BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, "
+                                f"b={b}/GPU, task {args.task} (ITC+ITM+CAP)" if args.workload == "img_aud_txt" else
+                                f"BASELINE.json configs[3] per-rank share: ViT-g/14 image+video(9)+depth(1)+audio(4)+text(77) fwd+bwd, "
+                                f"b={b}/GPU, task {args.task}; tower chunked with recompute"),
+                   "per_gpu_batch": b, "global_batch": b * world,
                    "vision": args.vision, "vit_layers": args.layers or "full", "parallelism": f"dp{world}",
                    "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),
                    "droppath_schedule": ("dense: every branch evaluated then scaled by 0 | 1/keep" if args.dense_droppath

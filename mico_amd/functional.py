@@ -128,266 +128,337 @@ class DropPlan:
         return sum(self.counts) / float(len(self.counts) * self.n_frames)
 
 
+def _tower_forward(spec, groups, dp_scale, params, save):
+    """One pass of the tower over the frames in `groups`.  save=False keeps nothing for a backward (chunked forward)."""
+    dt = runtime.compute_dtype()
+    P = lambda n: params[spec.idx[n]]
+    dev = params[0].device
+    D, N, np_, H, hd = spec.D, spec.N, spec.np, spec.H, spec.hd
+    arch = spec.arch
+    depth = arch["depth_built"]
+    Bf = sum(g.shape[0] for g in groups)
+    M = Bf * N
+    plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
+    x = _empty((M, D), torch.float32, dev)
+    # ---- patch embedding: im2row + GEMM(+bias +pos, patch rows -> token rows) ; CLS rows ----
+    pe_w, pe_b, pos = P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed")
+    pos2 = pos.detach().reshape(N, D)
+    saved_rows = []
+    f0 = 0
+    for g in groups:
+        C = g.shape[1]
+        kpad = spec.kpad3 if C == 3 else spec.kpad1
+        w16, ks = runtime.gemm_weight([pe_w], "pe3" if C == 3 else "pe1", k_pad=kpad, channel_sum=(C != 3))
+        rows16 = _empty((g.shape[0] * np_, kpad), dt, dev)
+        ops.im2row(g.contiguous().float(), rows16, spec.P, kpad)
+        ops.gemm(rows16, w16, x[f0 * N:], M=g.shape[0] * np_, N=D, K=kpad, bias=pe_b, pos=pos2, pos_rows=N,
+                 remap=(np_, 1, 1), ksegs=ks)
+        if save:
+            saved_rows.append(rows16)
+        f0 += g.shape[0]
+    ops.cls_rows(x, Bf, N, P("cls_token").detach().reshape(D), pos2[0])
+
+    def branch_io(i, which):
+        """-> (kept frames, frame list | None, scale vector | None)"""
+        return plan.branch(i, which) if plan is not None else (Bf, None, None)
+
+    def strides3():
+        return dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D), o_strides=(N * D, D))
+
+    acts = []
+    Hd = spec.hidden
+    for i in range(depth):
+        b = f"blocks.{i}."
+        a = {}
+        # --- attention branch: x <- x + s1 * proj(attn(LN1 x)) on the kept frames ---
+        B1, fmap1, sc1 = branch_io(i, 0)
+        a.update(B1=B1, fmap1=fmap1, sc1=sc1)
+        if B1 > 0:
+            M1 = B1 * N
+            xc1 = _empty((M1, D), torch.float32, dev) if fmap1 is not None else None
+            ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev,
+                                            frame_map=fmap1, rows_per_frame=N, x_copy=xc1)
+            qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
+            qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
+            qkv = _empty((M1, 3 * D), dt, dev)
+            _gemm_fwd(ln1b, D, _qkv_params(P, b, arch), "qkv", qkv, bias=qkv_bias)
+            if spec.rope is not None:
+                ops.rope(qkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1])
+                ops.rope(qkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1])
+            ao = _empty((M1, D), dt, dev)
+            lse = _empty((B1, H, N), torch.float32, dev)
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=B1, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3())
+            proj_in = ao
+            if arch["subln"]:
+                proj_in, aln, mean_a, rstd_a = _ln16(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"),
+                                                     spec.eps, M1, D, dt, dev)
+                a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
+            # every frame kept: out of place, the input buffer itself is the saved LN input; otherwise the epilogue
+            # scatters the kept frames onto the stream in place and the LN's compact copy (xc1) is what is saved
+            x_mid = _empty((M, D), torch.float32, dev) if fmap1 is None else x
+            _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=sc1,
+                      rows_per_scale=N, row_map=fmap1, rows_per_map=N)
+            a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse)
+            x = x_mid
+        # --- MLP branch ---
+        B2, fmap2, sc2 = branch_io(i, 1)
+        a.update(B2=B2, fmap2=fmap2, sc2=sc2)
+        if B2 > 0:
+            M2 = B2 * N
+            xc2 = _empty((M2, D), torch.float32, dev) if fmap2 is not None else None
+            ln2b, ln2, mean2, rstd2 = _ln16(x, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev,
+                                            frame_map=fmap2, rows_per_frame=N, x_copy=xc2)
+            x_out = _empty((M, D), torch.float32, dev) if fmap2 is None else x
+            epi = dict(resid=x, row_scale=sc2, rows_per_scale=N, row_map=fmap2, rows_per_map=N)
+            if arch["swiglu"]:
+                g1, g2 = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
+                if runtime.split_precision():
+                    # parity configuration: the gate runs in fp32 (x1, x2 and the gated product never round to fp16 on the
+                    # forward path); 16-bit copies of x1 / x2 are kept for the backward kernels only
+                    x1f, x2f = _empty((M2, Hd), torch.float32, dev), _empty((M2, Hd), torch.float32, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=P(b + "mlp.w1.bias"))
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=P(b + "mlp.w2.bias"))
+                    hsw = _empty((M2, Hd), torch.float32, dev)
+                    ops.swiglu_fwd_f32(x1f, x2f, hsw)
+                    ops.cast_f32_to_16(x1f, g1)
+                    ops.cast_f32_to_16(x2f, g2)
+                    del x1f, x2f
+                else:
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", g1, bias=P(b + "mlp.w1.bias"))
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", g2, bias=P(b + "mlp.w2.bias"))
+                    hsw = _empty((M2, Hd), dt, dev)
+                    ops.swiglu_fwd(g1, g2, hsw)
+                hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M2, Hd, dt, dev)
+                _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), **epi)
+                a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
+            else:
+                h = _empty((M2, Hd), dt, dev)
+                act = _empty((M2, Hd), dt, dev)
+                _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
+                _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), **epi)
+                a.update(h=h, act=act)
+            a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=ln2)
+            x = x_out
+        if save:
+            acts.append(a)
+        del a
+    out = _empty((M, D), torch.float32, dev)
+    mean_n, rstd_n = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+    ops.layernorm_fwd(x, P("norm.weight"), P("norm.bias"), spec.eps, out32=out, mean=mean_n, rstd=rstd_n, dtype=dt)
+    saved = None
+    if save:
+        saved = dict(acts=acts, dt=dt, final=(x, mean_n, rstd_n), groups_meta=[(g.shape[0], g.shape[1]) for g in groups],
+                     saved_rows=saved_rows, Bf=Bf)
+    return out.view(Bf, N, D), saved
+
+
+def _tower_backward(spec, params, saved, dout, grads):
+    """Backward of one _tower_forward(save=True) pass; parameter gradients are accumulated into the shared `grads` list."""
+    dt = saved["dt"]
+    P = lambda n: params[spec.idx[n]]
+    dev = dout.device
+    D, N, np_, H, hd, Bf = spec.D, spec.N, spec.np, spec.H, spec.hd, saved["Bf"]
+    arch = spec.arch
+    M = Bf * N
+    S = runtime.grad_scale()
+    inv_s = 1.0 / S
+
+    def G(name, like=None):
+        i = spec.idx[name]
+        if grads[i] is None:
+            grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
+        return grads[i]
+
+    def w16_of(p):
+        return runtime.gemm_weight([p])[0]
+
+    strides3 = dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D),
+                    o_strides=(N * D, D))
+    x_last, mean_n, rstd_n = saved["final"]
+    g = _empty((M, D), torch.float32, dev)   # running gradient of the fp32 residual stream (updated in place)
+    ops.layernorm_bwd(dout.contiguous().view(M, D), x_last, P("norm.weight"), mean_n, rstd_n, dx32=g,
+                      dgamma=G("norm.weight"), dbeta=G("norm.bias"), dtype=dt)
+    saved["final"] = None
+    del x_last
+    Hd = spec.hidden
+    for i in reversed(range(arch["depth_built"])):
+        b = f"blocks.{i}."
+        a = saved["acts"].pop()
+        # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
+        if a["B2"] > 0:
+            M2, fmap2 = a["B2"] * N, a["fmap2"]
+            g16 = _empty((M2, D), dt, dev)
+            ops.gather_rows_cast(g, g16, row_scale=a["sc2"], rows_per_scale=N, scale=S, frame_map=fmap2, rows_per_frame=N)
+            dln2 = _empty((M2, D), torch.float32, dev)
+            if arch["swiglu"]:
+                w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
+                linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
+                ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
+                dhln = _empty((M2, Hd), dt, dev)
+                ops.gemm(g16, w16_of(w3), dhln, tb=True, M=M2, N=Hd, K=D)
+                dhsw = _empty((M2, Hd), dt, dev)
+                ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
+                                  dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
+                dx1, dx2 = dhln, _empty((M2, Hd), dt, dev)   # reuse dhln storage for dx1
+                ops.swiglu_bwd(a["g1"], a["g2"], dhsw, dx1, dx2)
+                linear_wgrad(dx1, a["ln2"], G(b + "mlp.w1.weight"), inv_s)
+                linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
+                ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
+                ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
+                ops.gemm(dx1, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
+                ops.gemm(dx2, w16_of(w2), dln2, tb=True, M=M2, N=D, K=Hd, accumulate=True)
+                del dhln, dhsw, dx1, dx2
+            else:
+                w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+                linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
+                ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
+                dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
+                ops.gemm(g16, w16_of(w2), dh, tb=True, M=M2, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
+                linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
+                ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
+                ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
+                del dh
+            ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
+                              dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt, frame_map=fmap2,
+                              rows_per_frame=N)
+            del dln2, g16
+        # ---------------- attention branch ----------------
+        if a["B1"] > 0:
+            B1, fmap1 = a["B1"], a["fmap1"]
+            M1 = B1 * N
+            g16 = _empty((M1, D), dt, dev)
+            ops.gather_rows_cast(g, g16, row_scale=a["sc1"], rows_per_scale=N, scale=S, frame_map=fmap1, rows_per_frame=N)
+            wp = P(b + "attn.proj.weight")
+            proj_in = a["aln"] if arch["subln"] else a["ao"]
+            linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
+            ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
+            dao = _empty((M1, D), dt, dev)
+            ops.gemm(g16, w16_of(wp), dao, tb=True, M=M1, N=D, K=D)
+            if arch["subln"]:
+                dao2 = _empty((M1, D), dt, dev)
+                ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,
+                                  dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
+                                  grad_scale=inv_s, dtype=dt)
+                dao = dao2
+            qkv = a["qkv"]
+            dqkv = _empty((M1, 3 * D), dt, dev)
+            delta = _empty((B1, H, N), torch.float32, dev)
+            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["ao"], dao, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
+                         B=B1, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
+            if spec.rope is not None:
+                ops.rope(dqkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
+                ops.rope(dqkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
+            dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+            ops.colsum(dqkv, dbias, scale=inv_s)
+            G(b + "attn.q_bias").add_(dbias[:D])
+            G(b + "attn.v_bias").add_(dbias[2 * D:])
+            wqkv = runtime.gemm_weight(_qkv_params(P, b, arch), "qkv")[0]
+            if arch["subln"]:
+                dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
+                linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
+                G(b + "attn.q_proj.weight").add_(dwf[:D])
+                G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
+                G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
+            else:
+                linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
+            dln1 = _empty((M1, D), torch.float32, dev)
+            ops.gemm(dqkv, wqkv, dln1, tb=True, M=M1, N=D, K=3 * D)
+            ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
+                              dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,
+                              rows_per_frame=N)
+            del dqkv, dao, dln1, g16
+        del a
+    # ---------------- patch embedding ----------------
+    dpos = torch.zeros(N * D, dtype=torch.float32, device=dev)
+    ops.colsum(g, dpos, rows=Bf, cols=N * D, ld=N * D)
+    G("pos_embed").add_(dpos.view(1, N, D))
+    G("cls_token").add_(dpos[:D].view(1, 1, D))
+    pe_w = P("patch_embed.proj.weight")
+    PP = spec.P * spec.P
+    f0 = 0
+    for (nf, C), rows16 in zip(saved["groups_meta"], saved["saved_rows"]):
+        gp16 = _empty((nf * np_, D), dt, dev)
+        ops.gather_rows_cast(g[f0 * N:], gp16, remap=(np_, 1, 1), scale=S)
+        kpad = rows16.shape[1]
+        dw = torch.zeros((D, kpad), dtype=torch.float32, device=dev)
+        linear_wgrad(gp16, rows16, dw, inv_s)
+        if C == 3:
+            G("patch_embed.proj.weight").add_(dw[:, :3 * PP].reshape(D, 3, spec.P, spec.P))
+        else:
+            G("patch_embed.proj.weight").add_(dw[:, :PP].reshape(D, 1, spec.P, spec.P))
+        ops.colsum(gp16, G("patch_embed.proj.bias"), scale=inv_s, accumulate=True)
+        f0 += nf
+    saved["saved_rows"] = None
+
+
+def _slice_groups(groups, c0, c1):
+    """The frames [c0, c1) of the concatenated modality groups, as a list of per-group slices."""
+    out, f0 = [], 0
+    for g in groups:
+        f1 = f0 + g.shape[0]
+        lo, hi = max(c0, f0), min(c1, f1)
+        if lo < hi:
+            out.append(g[lo - f0:hi - f0])
+        f0 = f1
+    return out
+
+
+def tower_chunk_frames(spec, n_frames, device):
+    """Frames per tower pass.  Saved activations cost depth * N * (20 D + 4 hidden) bytes per frame (542 MB for ViT-g/14:
+    two fp32 stream copies, LN outputs, qkv, attention output, the two MLP intermediates); when all frames do not fit in
+    the memory budget the tower runs in chunks: forward without saving, and in the backward each chunk is recomputed with
+    saving and differentiated (+1 tower forward) - BASELINE configs[3] has 14 frames per sample, 896 per GPU at b = 64."""
+    if torch.device(device).type != "cuda":
+        from ._lib import MicoHipError
+        raise MicoHipError("the ViT tower runs on an MI355X device only (parameters are on %s): mico_amd has no CPU path" % device)
+    forced = runtime.tower_chunk_override()
+    if forced:
+        return forced
+    per_frame = spec.arch["depth_built"] * spec.N * (20 * spec.D + 4 * spec.hidden)
+    free, _ = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)    # cached blocks are reusable
+    budget = int(0.70 * free)
+    if n_frames * per_frame <= budget:
+        return n_frames
+    return max(1, budget // per_frame)
+
+
 class EvaTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, groups, dp_scale, *params):
-        dt = runtime.compute_dtype()
-        P = lambda n: params[spec.idx[n]]
-        dev = params[0].device
-        D, N, np_, H, hd = spec.D, spec.N, spec.np, spec.H, spec.hd
-        arch = spec.arch
-        depth = arch["depth_built"]
         Bf = sum(g.shape[0] for g in groups)
-        M = Bf * N
-        plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
-        x = _empty((M, D), torch.float32, dev)
-        # ---- patch embedding: im2row + GEMM(+bias +pos, patch rows -> token rows) ; CLS rows ----
-        pe_w, pe_b, pos = P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed")
-        pos2 = pos.detach().reshape(N, D)
-        saved_rows = []
-        f0 = 0
-        for g in groups:
-            C = g.shape[1]
-            kpad = spec.kpad3 if C == 3 else spec.kpad1
-            w16, ks = runtime.gemm_weight([pe_w], "pe3" if C == 3 else "pe1", k_pad=kpad, channel_sum=(C != 3))
-            rows16 = _empty((g.shape[0] * np_, kpad), dt, dev)
-            ops.im2row(g.contiguous().float(), rows16, spec.P, kpad)
-            ops.gemm(rows16, w16, x[f0 * N:], M=g.shape[0] * np_, N=D, K=kpad, bias=pe_b, pos=pos2, pos_rows=N,
-                     remap=(np_, 1, 1), ksegs=ks)
-            saved_rows.append(rows16)
-            f0 += g.shape[0]
-        ops.cls_rows(x, Bf, N, P("cls_token").detach().reshape(D), pos2[0])
-
-        def branch_io(i, which):
-            """-> (kept frames, frame list | None, scale vector | None)"""
-            return plan.branch(i, which) if plan is not None else (Bf, None, None)
-
-        def strides3():
-            return dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D), o_strides=(N * D, D))
-
-        acts = []
-        Hd = spec.hidden
-        for i in range(depth):
-            b = f"blocks.{i}."
-            a = {}
-            # --- attention branch: x <- x + s1 * proj(attn(LN1 x)) on the kept frames ---
-            B1, fmap1, sc1 = branch_io(i, 0)
-            a.update(B1=B1, fmap1=fmap1, sc1=sc1)
-            if B1 > 0:
-                M1 = B1 * N
-                xc1 = _empty((M1, D), torch.float32, dev) if fmap1 is not None else None
-                ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev,
-                                                frame_map=fmap1, rows_per_frame=N, x_copy=xc1)
-                qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
-                qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
-                qkv = _empty((M1, 3 * D), dt, dev)
-                _gemm_fwd(ln1b, D, _qkv_params(P, b, arch), "qkv", qkv, bias=qkv_bias)
-                if spec.rope is not None:
-                    ops.rope(qkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1])
-                    ops.rope(qkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1])
-                ao = _empty((M1, D), dt, dev)
-                lse = _empty((B1, H, N), torch.float32, dev)
-                ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=B1, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3())
-                proj_in = ao
-                if arch["subln"]:
-                    proj_in, aln, mean_a, rstd_a = _ln16(ao, P(b + "attn.inner_attn_ln.weight"), P(b + "attn.inner_attn_ln.bias"),
-                                                         spec.eps, M1, D, dt, dev)
-                    a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
-                # every frame kept: out of place, the input buffer itself is the saved LN input; otherwise the epilogue
-                # scatters the kept frames onto the stream in place and the LN's compact copy (xc1) is what is saved
-                x_mid = _empty((M, D), torch.float32, dev) if fmap1 is None else x
-                _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=sc1,
-                          rows_per_scale=N, row_map=fmap1, rows_per_map=N)
-                a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse)
-                x = x_mid
-            # --- MLP branch ---
-            B2, fmap2, sc2 = branch_io(i, 1)
-            a.update(B2=B2, fmap2=fmap2, sc2=sc2)
-            if B2 > 0:
-                M2 = B2 * N
-                xc2 = _empty((M2, D), torch.float32, dev) if fmap2 is not None else None
-                ln2b, ln2, mean2, rstd2 = _ln16(x, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev,
-                                                frame_map=fmap2, rows_per_frame=N, x_copy=xc2)
-                x_out = _empty((M, D), torch.float32, dev) if fmap2 is None else x
-                epi = dict(resid=x, row_scale=sc2, rows_per_scale=N, row_map=fmap2, rows_per_map=N)
-                if arch["swiglu"]:
-                    g1, g2 = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
-                    if runtime.split_precision():
-                        # parity configuration: the gate runs in fp32 (x1, x2 and the gated product never round to fp16 on the
-                        # forward path); 16-bit copies of x1 / x2 are kept for the backward kernels only
-                        x1f, x2f = _empty((M2, Hd), torch.float32, dev), _empty((M2, Hd), torch.float32, dev)
-                        _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=P(b + "mlp.w1.bias"))
-                        _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=P(b + "mlp.w2.bias"))
-                        hsw = _empty((M2, Hd), torch.float32, dev)
-                        ops.swiglu_fwd_f32(x1f, x2f, hsw)
-                        ops.cast_f32_to_16(x1f, g1)
-                        ops.cast_f32_to_16(x2f, g2)
-                        del x1f, x2f
-                    else:
-                        _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", g1, bias=P(b + "mlp.w1.bias"))
-                        _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", g2, bias=P(b + "mlp.w2.bias"))
-                        hsw = _empty((M2, Hd), dt, dev)
-                        ops.swiglu_fwd(g1, g2, hsw)
-                    hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M2, Hd, dt, dev)
-                    _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), **epi)
-                    a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
-                else:
-                    h = _empty((M2, Hd), dt, dev)
-                    act = _empty((M2, Hd), dt, dev)
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
-                    _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), **epi)
-                    a.update(h=h, act=act)
-                a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=ln2)
-                x = x_out
-            acts.append(a)
-        out = _empty((M, D), torch.float32, dev)
-        mean_n, rstd_n = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
-        ops.layernorm_fwd(x, P("norm.weight"), P("norm.bias"), spec.eps, out32=out, mean=mean_n, rstd=rstd_n, dtype=dt)
-        ctx.spec, ctx.params, ctx.acts, ctx.dt = spec, params, acts, dt
-        ctx.final = (x, mean_n, rstd_n)
-        ctx.groups_meta = [(g.shape[0], g.shape[1]) for g in groups]
-        ctx.saved_rows = saved_rows
-        ctx.Bf = Bf
-        return out.view(Bf, N, D)
+        needs_grad = any(ctx.needs_input_grad)    # False under torch.no_grad(): nothing is kept for a backward then
+        chunk = tower_chunk_frames(spec, Bf, params[0].device) if needs_grad else Bf
+        ctx.spec, ctx.params = spec, params
+        if chunk >= Bf:
+            out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad)
+            ctx.chunked = None
+            return out
+        outs = []
+        for c0 in range(0, Bf, chunk):
+            c1 = min(Bf, c0 + chunk)
+            sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
+            o, _ = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=False)
+            outs.append(o)
+        ctx.saved = None
+        ctx.chunked = (groups, dp_scale, chunk, Bf)
+        return torch.cat(outs, dim=0)
 
     @staticmethod
     def backward(ctx, dout):
-        spec, params, dt = ctx.spec, ctx.params, ctx.dt
-        P = lambda n: params[spec.idx[n]]
-        dev = dout.device
-        D, N, np_, H, hd, Bf = spec.D, spec.N, spec.np, spec.H, spec.hd, ctx.Bf
-        arch = spec.arch
-        M = Bf * N
-        S = runtime.grad_scale()
-        inv_s = 1.0 / S
+        spec, params = ctx.spec, ctx.params
         grads = [None] * len(params)
-
-        def G(name, like=None):
-            i = spec.idx[name]
-            if grads[i] is None:
-                grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
-            return grads[i]
-
-        def w16_of(p):
-            return runtime.gemm_weight([p])[0]
-
-        strides3 = dict(q_strides=(N * 3 * D, 3 * D), k_strides=(N * 3 * D, 3 * D), v_strides=(N * 3 * D, 3 * D),
-                        o_strides=(N * D, D))
-        x_last, mean_n, rstd_n = ctx.final
-        g = _empty((M, D), torch.float32, dev)   # running gradient of the fp32 residual stream (updated in place)
-        ops.layernorm_bwd(dout.contiguous().view(M, D), x_last, P("norm.weight"), mean_n, rstd_n, dx32=g,
-                          dgamma=G("norm.weight"), dbeta=G("norm.bias"), dtype=dt)
-        ctx.final = None
-        del x_last
-        Hd = spec.hidden
-        for i in reversed(range(arch["depth_built"])):
-            b = f"blocks.{i}."
-            a = ctx.acts.pop()
-            # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
-            if a["B2"] > 0:
-                M2, fmap2 = a["B2"] * N, a["fmap2"]
-                g16 = _empty((M2, D), dt, dev)
-                ops.gather_rows_cast(g, g16, row_scale=a["sc2"], rows_per_scale=N, scale=S, frame_map=fmap2, rows_per_frame=N)
-                dln2 = _empty((M2, D), torch.float32, dev)
-                if arch["swiglu"]:
-                    w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
-                    linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
-                    ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
-                    dhln = _empty((M2, Hd), dt, dev)
-                    ops.gemm(g16, w16_of(w3), dhln, tb=True, M=M2, N=Hd, K=D)
-                    dhsw = _empty((M2, Hd), dt, dev)
-                    ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
-                                      dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
-                    dx1, dx2 = dhln, _empty((M2, Hd), dt, dev)   # reuse dhln storage for dx1
-                    ops.swiglu_bwd(a["g1"], a["g2"], dhsw, dx1, dx2)
-                    linear_wgrad(dx1, a["ln2"], G(b + "mlp.w1.weight"), inv_s)
-                    linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
-                    ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
-                    ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
-                    ops.gemm(dx1, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
-                    ops.gemm(dx2, w16_of(w2), dln2, tb=True, M=M2, N=D, K=Hd, accumulate=True)
-                    del dhln, dhsw, dx1, dx2
-                else:
-                    w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
-                    linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
-                    ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
-                    dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                    ops.gemm(g16, w16_of(w2), dh, tb=True, M=M2, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
-                    linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
-                    ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
-                    ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
-                    del dh
-                ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
-                                  dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt, frame_map=fmap2,
-                                  rows_per_frame=N)
-                del dln2, g16
-            # ---------------- attention branch ----------------
-            if a["B1"] > 0:
-                B1, fmap1 = a["B1"], a["fmap1"]
-                M1 = B1 * N
-                g16 = _empty((M1, D), dt, dev)
-                ops.gather_rows_cast(g, g16, row_scale=a["sc1"], rows_per_scale=N, scale=S, frame_map=fmap1, rows_per_frame=N)
-                wp = P(b + "attn.proj.weight")
-                proj_in = a["aln"] if arch["subln"] else a["ao"]
-                linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
-                ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
-                dao = _empty((M1, D), dt, dev)
-                ops.gemm(g16, w16_of(wp), dao, tb=True, M=M1, N=D, K=D)
-                if arch["subln"]:
-                    dao2 = _empty((M1, D), dt, dev)
-                    ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,
-                                      dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
-                                      grad_scale=inv_s, dtype=dt)
-                    dao = dao2
-                qkv = a["qkv"]
-                dqkv = _empty((M1, 3 * D), dt, dev)
-                delta = _empty((B1, H, N), torch.float32, dev)
-                ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["ao"], dao, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
-                             B=B1, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
-                if spec.rope is not None:
-                    ops.rope(dqkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
-                    ops.rope(dqkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
-                dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
-                ops.colsum(dqkv, dbias, scale=inv_s)
-                G(b + "attn.q_bias").add_(dbias[:D])
-                G(b + "attn.v_bias").add_(dbias[2 * D:])
-                wqkv = runtime.gemm_weight(_qkv_params(P, b, arch), "qkv")[0]
-                if arch["subln"]:
-                    dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
-                    linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
-                    G(b + "attn.q_proj.weight").add_(dwf[:D])
-                    G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
-                    G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
-                else:
-                    linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
-                dln1 = _empty((M1, D), torch.float32, dev)
-                ops.gemm(dqkv, wqkv, dln1, tb=True, M=M1, N=D, K=3 * D)
-                ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
-                                  dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,
-                                  rows_per_frame=N)
-                del dqkv, dao, dln1, g16
-            del a
-        # ---------------- patch embedding ----------------
-        dpos = torch.zeros(N * D, dtype=torch.float32, device=dev)
-        ops.colsum(g, dpos, rows=Bf, cols=N * D, ld=N * D)
-        G("pos_embed").add_(dpos.view(1, N, D))
-        G("cls_token").add_(dpos[:D].view(1, 1, D))
-        pe_w = P("patch_embed.proj.weight")
-        PP = spec.P * spec.P
-        f0 = 0
-        for (nf, C), rows16 in zip(ctx.groups_meta, ctx.saved_rows):
-            gp16 = _empty((nf * np_, D), dt, dev)
-            ops.gather_rows_cast(g[f0 * N:], gp16, remap=(np_, 1, 1), scale=S)
-            kpad = rows16.shape[1]
-            dw = torch.zeros((D, kpad), dtype=torch.float32, device=dev)
-            linear_wgrad(gp16, rows16, dw, inv_s)
-            if C == 3:
-                G("patch_embed.proj.weight").add_(dw[:, :3 * PP].reshape(D, 3, spec.P, spec.P))
-            else:
-                G("patch_embed.proj.weight").add_(dw[:, :PP].reshape(D, 1, spec.P, spec.P))
-            ops.colsum(gp16, G("patch_embed.proj.bias"), scale=inv_s, accumulate=True)
-            f0 += nf
-        ctx.saved_rows = None
+        if ctx.chunked is None:
+            _tower_backward(spec, params, ctx.saved, dout, grads)
+            ctx.saved = None
+        else:
+            groups, dp_scale, chunk, Bf = ctx.chunked
+            for c0 in range(0, Bf, chunk):
+                c1 = min(Bf, c0 + chunk)
+                sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
+                _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True)
+                _tower_backward(spec, params, saved, dout[c0:c1], grads)
+                del saved
         return (None, None, None) + tuple(grads)
 
 

@@ -114,3 +114,16 @@ def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False):
         kp = buf.shape[1] // 2
         return buf[:, :kp], (kp, [0, 0], [0, kp])
     return buf, None
+
+
+_tower_chunk = None
+
+
+def tower_chunk_override():
+    """Frames per ViT tower pass forced by set_tower_chunk (None = size it from the free device memory)."""
+    return _tower_chunk
+
+
+def set_tower_chunk(frames):
+    global _tower_chunk
+    _tower_chunk = int(frames) if frames else None

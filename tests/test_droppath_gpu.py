@@ -88,3 +88,38 @@ def test_alignment_step_with_masks(cuda):
         e = abs(out[k].item() - v.item()) / max(abs(v.item()), 1e-6)
         print(k, out[k].item(), v.item(), f"{e:.2e}")
         assert e < 2e-3, k
+
+
+def test_chunked_tower_recompute(cuda):
+    """Tower passes in chunks (forward without saving, per-chunk recompute + backward; configs[3]-sized inputs need this):
+    same values and gradients as the single-pass schedule, with and without stochastic depth, across mixed modality groups."""
+    from mico_amd import runtime as rt
+    depth = 2
+    m, sd = build_model("evaclip02_base", depth, device=cuda)
+    vis = m.vision_encoder.visual
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(4, 3, 224, 224, generator=g).to(cuda)
+    aud = torch.randn(3, 1, 224, 224, generator=g).to(cuda)
+    dps = _masks(depth, 7, 0.7, 21)
+    w = (torch.randn(7, 197, 768, generator=g) / (7 * 197 * 768) ** 0.5).to(cuda)
+    res = {}
+    for chunk in (None, 3, 2):
+        rt.set_tower_chunk(chunk)
+        try:
+            for use_dp in (False, True):
+                with rt.precision(torch.float16):
+                    m.zero_grad(set_to_none=True)
+                    out = vis.forward_groups([img, aud], drop_path_scale=dps if use_dp else None)
+                    (out * w).sum().backward()
+                grads = {n: p.grad.clone() for n, p in vis.named_parameters() if p.grad is not None}
+                res[(chunk, use_dp)] = (out.detach().clone(), grads)
+        finally:
+            rt.set_tower_chunk(None)
+    for use_dp in (False, True):
+        o0, g0 = res[(None, use_dp)]
+        for chunk in (3, 2):
+            o1, g1 = res[(chunk, use_dp)]
+            assert torch.equal(o0, o1), (chunk, use_dp)          # per-frame arithmetic is batch independent
+            assert set(g0) == set(g1)
+            for n in g0:
+                assert rel_err(g1[n], g0[n]) < 2e-3, (chunk, use_dp, n, rel_err(g1[n], g0[n]))

@@ -3,7 +3,8 @@
     alone, and those match the CPU oracle (fp32) within the parity gate;
   * unit-norm contrastive features; ITC loss recomputed on the host from the product's own features;
   * one full forward+backward finishes with finite losses and gradients for every parameter the task touches.
-configs[1]: ViT-B/16 image+text contrastive, bs=256, 224^2 + 77 tokens.   configs[2]: ViT-g/14 image+audio+text, bs=64."""
+configs[1]: ViT-B/16 image+text contrastive, bs=256, 224^2 + 77 tokens.   configs[2]: ViT-g/14 image+audio+text, bs=64.
+configs[3]: one rank (b = 64) of the full omni-modal job: image+video+depth+audio+text, 896 frames."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -27,6 +28,9 @@ def _oracle_feats(sd, vtype, inp, conds):
 @pytest.mark.parametrize("name,vtype,cfg,task,conds,nsub", [
     ("config2", "evaclip02_base", dict(b=256, vision=1, S=77), "ret%tv", ("v",), 4),
     ("config3", "evaclip01_giant", dict(b=64, vision=1, audio=4, S=77), "ret%tva_cap%tva", ("va",), 1),
+    # configs[3], one rank's share of the 8-GPU job: image (1) + video (8) frames through the vision branch, depth (1), audio (4)
+    # = 14 frames / sample, 896 ViT-g/14 frames per step: the tower runs chunked with per-chunk recompute (functional.py)
+    ("config4_rank", "evaclip01_giant", dict(b=64, vision=9, depth=1, audio=4, S=77), "ret%tva%tvd_cap%tva", ("va", "vd"), 1),
 ])
 def test_full_size_config(cuda, name, vtype, cfg, task, conds, nsub):
     torch.set_num_threads(32)
