@@ -33,6 +33,32 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+class GradArena:
+    """fp32 parameter-gradient storage of one backward pass: ONE zero-filled flat buffer with a view per parameter (a ViT-g
+    backward otherwise issues ~1600 tiny fill launches per step).  Parameters nobody asked a view for report None."""
+
+    def __init__(self, params):
+        self.shapes = [tuple(p.shape) for p in params]
+        self.offsets, n = [], 0
+        for p in params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        self.views = [None] * len(params)
+
+    def get(self, i):
+        if self.views[i] is None:
+            o = self.offsets[i]
+            numel = 1
+            for d in self.shapes[i]:
+                numel *= d
+            self.views[i] = self.flat[o:o + numel].view(self.shapes[i])
+        return self.views[i]
+
+    def result(self):
+        return tuple(self.views)
+
+
 def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None):
     """dw[N_out, N_in] += inv_s * dy16^T x16   (reduction over the rows)."""
     n_out = n_out or dw.shape[0]
@@ -264,10 +290,7 @@ def _tower_backward(spec, params, saved, dout, grads):
     inv_s = 1.0 / S
 
     def G(name, like=None):
-        i = spec.idx[name]
-        if grads[i] is None:
-            grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
-        return grads[i]
+        return grads.get(spec.idx[name])
 
     def w16_of(p):
         return runtime.gemm_weight([p])[0]
@@ -447,7 +470,7 @@ class EvaTowerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         spec, params = ctx.spec, ctx.params
-        grads = [None] * len(params)
+        grads = GradArena(params)
         if ctx.chunked is None:
             _tower_backward(spec, params, ctx.saved, dout, grads)
             ctx.saved = None
@@ -459,7 +482,7 @@ class EvaTowerFn(torch.autograd.Function):
                 _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True)
                 _tower_backward(spec, params, saved, dout[c0:c1], grads)
                 del saved
-        return (None, None, None) + tuple(grads)
+        return (None, None, None) + grads.result()
 
 
 # ======================================================================================================================
@@ -798,13 +821,10 @@ class BertFn(torch.autograd.Function):
         Sg = runtime.grad_scale()
         inv_s = 1.0 / Sg
         scale = 1.0 / math.sqrt(hd)
-        grads = [None] * len(params)
+        grads = GradArena(params)
 
         def G(name):
-            i = spec.idx[name]
-            if grads[i] is None:
-                grads[i] = torch.zeros_like(params[i], dtype=torch.float32)
-            return grads[i]
+            return grads.get(spec.idx[name])
 
         g = dseq.contiguous().view(rows, D).float().clone()
         dcond = torch.zeros((b * E, D), dtype=torch.float32, device=dev) if cond16 is not None else None
@@ -892,7 +912,7 @@ class BertFn(torch.autograd.Function):
         ops.embed_scatter_add(ids, g, G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"), dtype0, S)
         G("embeddings.token_type_embeddings.weight")[0].add_(dtype0)
         dc = dcond.view(b, E, D) if (dcond is not None and ctx.cond_needs_grad) else None
-        return (None, None, None, dc) + tuple(grads)
+        return (None, None, None, dc) + grads.result()
 
 
 # ======================================================================================================================
