@@ -39,8 +39,8 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--vision", default="evaclip01_giant")
     ap.add_argument("--layers", type=int, default=None, help="truncate the ViT (debug only; invalidates the metric)")
@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
+    ap.add_argument("--no-bert-dropout", action="store_true", help="A/B switch: BERT dropout probabilities set to 0 (invalidates the metric)")
     ap.add_argument("--dense-droppath", action="store_true",
                     help="evaluate dropped residual branches too and multiply them by 0 (the reference's schedule) instead of skipping them")
     return ap.parse_args()
@@ -117,6 +118,8 @@ def main():
     model = MiCo(cfg)
     sd_cpu = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
     model.load_state_dict(sd_cpu, strict=False)
+    if args.no_bert_dropout:
+        model.multimodal_encoder.bert.config.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     model.to(dev)
     model.eval() if args.eval_mode else model.train()
     b = args.batch
@@ -207,7 +210,9 @@ def main():
                    "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),
                    "droppath_schedule": ("dense: every branch evaluated then scaled by 0 | 1/keep" if args.dense_droppath
                                          else "dropped (block, branch, frame) triples are skipped - exact, zero contribution"),
-                   "kept_branch_fraction": kept, "bert_dropout": False},
+                   "kept_branch_fraction": kept,
+                   "bert_dropout": (False if (args.eval_mode or args.no_bert_dropout) else
+                                    "on: p=0.1 hidden + attention-probability (reference config.json)")},
         "samples_per_sec_per_gpu": value / world,
         "step_executed_tflops_per_gpu": step_tflops,
         "tflop_per_sample": {"dense_nominal": nominal, "executed": executed},

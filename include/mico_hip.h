@@ -84,6 +84,12 @@ typedef struct mico_gemm_epilogue {
      * NULL = identity.  Not combinable with remap_group. */
     const int* row_map;
     int rows_per_map;
+    /* dropout on the GEMM result (after bias / activation, before row_scale / pos / resid): element (m, n) is kept with
+     * probability 1 - drop_p and scaled by 1/(1 - drop_p), decided by mico_dropout's counter hash of
+     * (drop_seed, drop_site, m * N + n).  drop_p == 0 disables.  BertSelfOutput / BertOutput, bert.py:291-297, 369-375. */
+    float drop_p;
+    unsigned drop_seed;
+    int drop_site;
 } mico_gemm_epilogue;
 
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
@@ -101,12 +107,14 @@ int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
  *   frame_map (optional, int32 [rows / rows_per_frame]): input row r is read from row
  *   frame_map[r / rows_per_frame] * rows_per_frame + r % rows_per_frame of x (compacting gather of whole frames; all outputs
  *   are compact);  x_copy (optional, fp32 [rows, cols]) receives the gathered input rows (saved for the backward).
+ *   drop_p > 0: dropout on the outputs (BertEmbeddings, bert.py:147-148), element index row * cols + col, see mico_dropout.
  * ------------------------------------------------------------------------------------------------------------- */
 int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                        void* y16, float* y32, float* mean, float* rstd,
                        int64_t rows, int cols, float eps,
                        const float* post_add, int post_rows_per_group, int post_groups, int y16_split,
                        const int* frame_map, int rows_per_frame, float* x_copy,
+                       float drop_p, unsigned drop_seed, int drop_site,
                        int dtype, void* stream);
 /* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
  * (dx16 = T(dx * scale16)).
@@ -137,6 +145,12 @@ typedef struct mico_attn_params {
     float scale;
     const float* mask;
     int mask_mode;
+    /* dropout on the attention probabilities (bert.py:267): P[b,h,i,j] kept with probability 1 - drop_p and scaled by
+     * 1/(1 - drop_p); the decision is mico_dropout's counter hash of (drop_seed, drop_site, ((b*H + h)*Sq + i)*Sk + j), so the
+     * backward kernels regenerate it instead of storing a mask.  drop_p == 0 disables. */
+    float drop_p;
+    unsigned drop_seed;
+    int drop_site;
 } mico_attn_params;
 
 int mico_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -174,6 +188,13 @@ int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst, int64_t l
                           int remap_group, int remap_skip, int remap_offset,
                           const float* row_scale, int rows_per_scale, float scale,
                           const int* frame_map, int rows_per_frame, int dtype, void* stream);
+/* In-place dropout x[r, c] *= keep(r * cols + c) / (1 - p) on an fp32 or 16-bit [rows, cols] tensor (leading dim ld): the
+ * backward of every hidden-state dropout (the same mask multiplies the gradient).  keep() is a stateless counter hash of
+ * (seed, site, index) - no mask tensor exists anywhere:
+ *   h = seed ^ site * 0x9E3779B9;  h ^= lo32(idx) * 0x85EBCA6B;  h = rotl(h, 13) * 5 + 0xE6546B64;
+ *   h ^= hi32(idx) * 0xC2B2AE35;   h = rotl(h, 13) * 5 + 0xE6546B64;
+ *   h ^= h >> 16;  h *= 0x85EBCA6B;  h ^= h >> 13;  h *= 0xC2B2AE35;  h ^= h >> 16;     keep = (h >> 8) >= (uint32)(p * 2^24) */
+int mico_dropout(void* x, int x_dtype, int64_t rows, int cols, int64_t ld, float p, unsigned seed, int site, void* stream);
 /* out[c] (+)= scale * sum_r x[r, c]   (bias gradients, positional-table gradients).  x fp32 or 16-bit. */
 int mico_colsum(const void* x, int x_dtype, int64_t ld, int64_t rows, int cols, float* out, float scale, int accumulate,
                 void* stream);

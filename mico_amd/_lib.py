@@ -27,6 +27,7 @@ class GemmEpilogue(C.Structure):
         ("remap_group", c_int), ("remap_skip", c_int), ("remap_offset", c_int), ("alpha", c_f), ("accumulate", c_int),
         ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
         ("row_map", c_vp), ("rows_per_map", c_int),
+        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int),
     ]
 
 
@@ -35,6 +36,7 @@ class AttnParams(C.Structure):
         ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int), ("hd", c_int),
         ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64), ("v_bs", c_i64), ("v_rs", c_i64),
         ("o_bs", c_i64), ("o_rs", c_i64), ("scale", c_f), ("mask", c_vp), ("mask_mode", c_int),
+        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int),
     ]
 
 
@@ -45,7 +47,7 @@ PROTOTYPES = {
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
-                           c_int, c_vp, c_int, c_vp, c_int, c_vp],
+                           c_int, c_vp, c_int, c_vp, c_f, C.c_uint, c_int, c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
     "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
                            c_i64, c_int, c_vp, c_int, c_int, c_vp],
@@ -57,6 +59,7 @@ PROTOTYPES = {
     "mico_cast_16_to_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f, c_int, c_int, c_vp],
     "mico_gather_rows_cast": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_int, c_f, c_vp, c_int,
                               c_int, c_vp],
+    "mico_dropout": [c_vp, c_int, c_i64, c_int, c_i64, c_f, C.c_uint, c_int, c_vp],
     "mico_colsum": [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_f, c_int, c_vp],
     "mico_cls_rows": [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp],
     "mico_add_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_int, c_vp],

@@ -208,6 +208,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
                 s[tn][r] = e;
                 lloc += e;
             }
+        if (p.drop_p > 0.f) {   // dropout on the probabilities: the row sum above stays the undropped one
+            const unsigned thr = drop_threshold(p.drop_p);
+            const float ik = 1.f / (1.f - p.drop_p);
+            const unsigned long long rowbase = (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s[tn][r] *= drop_mult(p.drop_seed, p.drop_site, rowbase + (t * 64 + tn * 16 + g * 4 + r), thr, ik);
+        }
         l_run = l_run * alpha + group_sum(lloc);
         m_run = m_new;
 #pragma unroll
@@ -318,7 +328,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
                     float x = s[tn][r] * p.scale;
                     if (p.mask_mode) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk);
                     const float pr = __expf(x - lse_i);
-                    ds = pr * (dp[tn][r] - dl) * p.scale;
+                    float dpe = dp[tn][r];
+                    if (p.drop_p > 0.f)
+                        dpe *= drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
+                                         drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
+                    ds = pr * (dpe - dl) * p.scale;
                 }
                 s[tn][r] = ds;
             }
@@ -419,7 +433,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
                     float x = s[ti][r] * p.scale;
                     if (p.mask_mode) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk);
                     pv = __expf(x - lv[r]);
-                    ds = pv * (dp[ti][r] - dv4[r]) * p.scale;
+                    float dm = 1.f;
+                    if (p.drop_p > 0.f)
+                        dm = drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
+                                       drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
+                    ds = pv * (dp[ti][r] * dm - dv4[r]) * p.scale;
+                    pv *= dm;      // dV sees the dropped probabilities
                 }
                 pr[ti][r] = pv;
                 s[ti][r] = ds;
@@ -458,6 +477,7 @@ int check_params(const mico_attn_params* p, const char* who) {
                    p->k_bs % 8 == 0 && p->v_bs % 8 == 0 && p->o_bs % 8 == 0,
                "%s: strides must be multiples of 8 elements", who);
     MICO_CHECK(p->mask_mode >= 0 && p->mask_mode <= 2 && (p->mask_mode == 0 || p->mask), "%s: bad mask", who);
+    MICO_CHECK(p->drop_p >= 0.f && p->drop_p < 1.f, "%s: drop_p must be in [0, 1)", who);
     return MICO_OK;
 }
 

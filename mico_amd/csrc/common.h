@@ -110,6 +110,22 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // wave64 reductions
+// ---- stateless dropout decision (documented at mico_dropout in include/mico_hip.h; oracle/mico_oracle.py restates it) ----
+__device__ __forceinline__ unsigned drop_hash(unsigned seed, int site, unsigned long long idx) {
+    unsigned h = seed ^ ((unsigned)site * 0x9E3779B9u);
+    h ^= (unsigned)idx * 0x85EBCA6Bu;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+    h ^= (unsigned)(idx >> 32) * 0xC2B2AE35u;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h >> 8;
+}
+// multiplier of element idx: 0 or 1/(1-p).  thr = (unsigned)(p * 2^24), inv_keep = 1/(1-p)
+__device__ __forceinline__ float drop_mult(unsigned seed, int site, unsigned long long idx, unsigned thr, float inv_keep) {
+    return drop_hash(seed, site, idx) >= thr ? inv_keep : 0.f;
+}
+__host__ __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(p * 16777216.f); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

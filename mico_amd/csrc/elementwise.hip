@@ -64,6 +64,19 @@ __global__ void gather_rows_cast_kernel(const float* __restrict__ src, int64_t l
     }
 }
 
+// ---- in-place dropout (gradient side of the hidden-state dropouts) ------------------------------------------------------
+template <typename XT>
+__global__ void dropout_kernel(XT* __restrict__ x, int64_t rows, int cols, int64_t ld, unsigned thr, float inv_keep, unsigned seed,
+                               int site) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        XT* p = x + r * ld + c;
+        *p = (XT)((float)*p * drop_mult(seed, site, (unsigned long long)i, thr, inv_keep));
+    }
+}
+
 // ---- column sums: out[c] (+)= scale * sum_r x[r,c] ----------------------------------------------------------------
 // grid (col slabs of 256, row chunks); each thread owns one column for a chunk of rows, partial sums via atomics.
 template <typename XT>
@@ -320,6 +333,21 @@ extern "C" int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst
     if (frame_map) MICO_CHECK(rows_per_frame > 0 && !remap_group, "mico_gather_rows_cast: frame_map needs rows_per_frame > 0 and no remap_group");
     if (rows <= 0) return MICO_OK;
     DISPATCH_T16(dtype, MICO_LAUNCH(gather_rows_cast_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, remap_group, remap_skip, remap_offset, row_scale, rows_per_scale, scale, frame_map, rows_per_frame));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_dropout(void* x, int x_dtype, int64_t rows, int cols, int64_t ld, float p, unsigned seed, int site, void* stream) {
+    MICO_CHECK(x && cols > 0 && ld >= cols, "mico_dropout: bad args");
+    MICO_CHECK(p >= 0.f && p < 1.f, "mico_dropout: p must be in [0, 1)");
+    MICO_CHECK(x_dtype == MICO_F32 || x_dtype == MICO_F16 || x_dtype == MICO_BF16, "mico_dropout: bad dtype");
+    if (rows <= 0 || p == 0.f) return MICO_OK;
+    const unsigned thr = drop_threshold(p);
+    const float ik = 1.f / (1.f - p);
+    const dim3 grid(egrid(rows * cols));
+    if (x_dtype == MICO_F32) MICO_LAUNCH(dropout_kernel<float>, grid, dim3(EB), 0, ST, (float*)x, rows, cols, ld, thr, ik, seed, site);
+    else if (x_dtype == MICO_F16) MICO_LAUNCH(dropout_kernel<f16>, grid, dim3(EB), 0, ST, (f16*)x, rows, cols, ld, thr, ik, seed, site);
+    else MICO_LAUNCH(dropout_kernel<bf16>, grid, dim3(EB), 0, ST, (bf16*)x, rows, cols, ld, thr, ik, seed, site);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -226,6 +226,15 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
                     v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
                 }
         }
+        if (e.drop_p > 0.f) {
+            const unsigned thr = drop_threshold(e.drop_p);
+            const float ik = 1.f / (1.f - e.drop_p);
+            const unsigned long long i0 = (unsigned long long)m * (unsigned long long)g.N + (unsigned long long)n;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v4[v][k] *= drop_mult(e.drop_seed, e.drop_site, i0 + v * 4 + k, thr, ik);
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             if (v >= nvec) continue;
@@ -549,13 +558,14 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     }
     if (g.split_k > 1) {
         MICO_CHECK(c_dtype == MICO_F32 && g.e.accumulate, "mico_gemm: split_k > 1 needs fp32 accumulate output");
-        MICO_CHECK(!g.e.bias && !g.e.aux_out && g.e.act == MICO_ACT_NONE && !g.e.row_scale && !g.e.resid && !g.e.pos && !g.e.remap_group && !g.e.row_map,
+        MICO_CHECK(!g.e.bias && !g.e.aux_out && g.e.act == MICO_ACT_NONE && !g.e.row_scale && !g.e.resid && !g.e.pos && !g.e.remap_group && !g.e.row_map && g.e.drop_p == 0.f,
                    "mico_gemm: split_k > 1 supports only the alpha-scaled accumulate epilogue");
     }
     if (g.e.act == MICO_ACT_GELU_GRAD) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD needs aux_in");
     if (g.e.row_scale) MICO_CHECK(g.e.rows_per_scale > 0, "mico_gemm: rows_per_scale must be > 0");
     if (g.e.row_map) MICO_CHECK(g.e.rows_per_map > 0 && !g.e.remap_group, "mico_gemm: row_map needs rows_per_map > 0 and no remap_group");
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
+    MICO_CHECK(g.e.drop_p >= 0.f && g.e.drop_p < 1.f, "mico_gemm: drop_p must be in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
     if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
     else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));

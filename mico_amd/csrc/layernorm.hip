@@ -30,7 +30,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            const float* __restrict__ post_add, int post_rpg,
                                                            int post_groups, int split16,
                                                            const int* __restrict__ frame_map, int rpf,
-                                                           float* __restrict__ x_copy) {
+                                                           float* __restrict__ x_copy, float drop_p, unsigned drop_seed,
+                                                           int drop_site) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
@@ -73,6 +74,13 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
                 f32x4 o = (v[i] - mean) * rstd * g + b;
                 if (pa) o += *(const f32x4*)(pa + c * 4);
+                if (drop_p > 0.f) {
+                    const unsigned thr = drop_threshold(drop_p);
+                    const float ik = 1.f / (1.f - drop_p);
+                    const unsigned long long i0 = (unsigned long long)row * cols + c * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] *= drop_mult(drop_seed, drop_site, i0 + k, thr, ik);
+                }
                 if (y32) *(f32x4*)(y32 + row * cols + c * 4) = o;
                 if (y16) {
                     if (!split16) {
@@ -204,8 +212,8 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
 template <typename T, typename XT>
 void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
                    float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16,
-                   const int* fmap, int rpf, float* x_copy) {
-#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy)
+                   const int* fmap, int rpf, float* x_copy, float dp, unsigned dseed, int dsite) {
+#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite)
     if (cols <= 1024) LNF(4);
     else if (cols <= 1536) LNF(6);
     else if (cols <= 2048) LNF(8);
@@ -231,7 +239,8 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows) { return ln_grid(rows); }
 extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* y32,
                                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add,
                                   int post_rows_per_group, int post_groups, int y16_split, const int* frame_map,
-                                  int rows_per_frame, float* x_copy, int dtype, void* stream) {
+                                  int rows_per_frame, float* x_copy, float drop_p, unsigned drop_seed, int drop_site,
+                                  int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
     MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
@@ -242,8 +251,8 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_grid(rows));
     DISPATCH_T16(dtype, {
-        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy);
-        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy);
+        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site);
+        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site);
     });
     MICO_LAUNCH_CHECK();
     return MICO_OK;

@@ -722,10 +722,19 @@ def _fwd_gemm(x, key, plist, out, **kw):
     return _gemm_fwd(x, kin, plist, key, out, **kw)
 
 
+# dropout sites of one BERT pass (the `site` of mico_dropout's counter hash): layer * 8 + {self-output, cross-output, FFN output,
+# self-attention probabilities, cross-attention probabilities}; the embedding dropout has its own id
+SITE_SELF_OUT, SITE_CROSS_OUT, SITE_FFN_OUT, SITE_SELF_P, SITE_CROSS_P, SITE_EMB = 0, 1, 2, 3, 4, 100000
+
+
 class BertFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec, input_ids, add_mask, cond, *params):
+    def forward(ctx, spec, input_ids, add_mask, cond, drop, *params):
+        """drop: None (eval) or (p_hidden, p_attention, seed) - train-mode dropout of bert.py:148,267,295,373."""
         dt = runtime.compute_dtype()
+        ph, pa, dseed = drop if drop is not None else (0.0, 0.0, 0)
+        hd_drop = (lambda site: (ph, dseed, site)) if ph > 0 else (lambda site: None)
+        at_drop = (lambda site: (pa, dseed, site)) if pa > 0 else (lambda site: None)
         P = lambda n: params[spec.idx[n]]
         dev = input_ids.device
         b, S = input_ids.shape
@@ -740,7 +749,7 @@ class BertFn(torch.autograd.Function):
         x32, x16 = _empty((rows, D), torch.float32, dev), _empty((rows, 2 * D if split0 else D), dt, dev)
         mean_e, rstd_e = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
         ops.layernorm_fwd(emb, P("embeddings.LayerNorm.weight"), P("embeddings.LayerNorm.bias"), spec.eps, out16=x16, out32=x32,
-                          mean=mean_e, rstd=rstd_e, split16=split0, dtype=dt)
+                          mean=mean_e, rstd=rstd_e, split16=split0, dtype=dt, drop=hd_drop(SITE_EMB))
         cond16 = None
         E = 0
         if cond is not None:
@@ -771,10 +780,11 @@ class BertFn(torch.autograd.Function):
             co = _empty((rows, D), dt, dev)
             lse = _empty((b, H, S), torch.float32, dev)
             st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
-            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], co, lse, B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, **st)
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], co, lse, B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask,
+                         drop=at_drop(li * 8 + SITE_SELF_P), **st)
             wo = P(p + "attention.output.dense.weight")
             u = _empty((rows, D), torch.float32, dev)
-            _fwd_gemm(co, "w1", [wo], u, bias=P(p + "attention.output.dense.bias"), resid=x32)
+            _fwd_gemm(co, "w1", [wo], u, bias=P(p + "attention.output.dense.bias"), resid=x32, drop=hd_drop(li * 8 + SITE_SELF_OUT))
             x32, x16, m1, r1 = ln_out(u, p + "attention.output.")
             a.update(qkv=qkv, co=co, lse=lse, u=u, m1=m1, r1=r1)
             if cond16 is not None:
@@ -788,10 +798,11 @@ class BertFn(torch.autograd.Function):
                 cc = _empty((rows, D), dt, dev)
                 lse_c = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
-                ops.attn_fwd(q, kv, kv[:, D:], cc, lse_c, B=b, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None, **stc)
+                ops.attn_fwd(q, kv, kv[:, D:], cc, lse_c, B=b, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None,
+                             drop=at_drop(li * 8 + SITE_CROSS_P), **stc)
                 u2 = _empty((rows, D), torch.float32, dev)
                 _fwd_gemm(cc, "w1", [P(p + "crossattention.output.dense.weight")], u2,
-                          bias=P(p + "crossattention.output.dense.bias"), resid=x32)
+                          bias=P(p + "crossattention.output.dense.bias"), resid=x32, drop=hd_drop(li * 8 + SITE_CROSS_OUT))
                 x32, x16, m2, r2 = ln_out(u2, p + "crossattention.output.")
                 a.update(q=q, kv=kv, cc=cc, lse_c=lse_c, u2=u2, m2=m2, r2=r2)
             a["x16b"] = x16[:, :D]
@@ -800,12 +811,14 @@ class BertFn(torch.autograd.Function):
             _fwd_gemm(x16, "w1", [P(p + "intermediate.dense.weight")], act, bias=P(p + "intermediate.dense.bias"),
                       aux_out=h, act=ops.ACT_GELU)
             u3 = _empty((rows, D), torch.float32, dev)
-            _fwd_gemm(act, "w1", [P(p + "output.dense.weight")], u3, bias=P(p + "output.dense.bias"), resid=x32)
+            _fwd_gemm(act, "w1", [P(p + "output.dense.weight")], u3, bias=P(p + "output.dense.bias"), resid=x32,
+                      drop=hd_drop(li * 8 + SITE_FFN_OUT))
             x32, x16, m3, r3 = ln_out(u3, p + "output.")
             a.update(h=h, act=act, u3=u3, m3=m3, r3=r3)
             acts.append(a)
         ctx.spec, ctx.params, ctx.acts, ctx.dt = spec, params, acts, dt
         ctx.misc = (ids, emb, mean_e, rstd_e, cond16, mask, b, S, E)
+        ctx.drop = drop
         ctx.cond_needs_grad = cond is not None and cond.requires_grad
         return x32.view(b, S, D)
 
@@ -814,6 +827,8 @@ class BertFn(torch.autograd.Function):
         spec, params, dt = ctx.spec, ctx.params, ctx.dt
         P = lambda n: params[spec.idx[n]]
         ids, emb, mean_e, rstd_e, cond16, mask, b, S, E = ctx.misc
+        ph, pa, dseed = ctx.drop if ctx.drop is not None else (0.0, 0.0, 0)
+        at_drop = (lambda site: (pa, dseed, site)) if pa > 0 else (lambda site: None)
         dev = dseq.device
         D, H, I = spec.D, spec.H, spec.I
         hd = D // H
@@ -829,11 +844,14 @@ class BertFn(torch.autograd.Function):
         g = dseq.contiguous().view(rows, D).float().clone()
         dcond = torch.zeros((b * E, D), dtype=torch.float32, device=dev) if cond16 is not None else None
 
-        def ln_bwd(gin, u, m_, r_, pre):
-            """d(LN input) fp32 (in place into gin) and its scaled 16-bit copy."""
+        def ln_bwd(gin, u, m_, r_, pre, site):
+            """d(LN input) fp32 (in place into gin: the residual branch's gradient) and its scaled 16-bit copy for the dense
+            branch, which sat behind a dropout in training: the same mask multiplies its gradient."""
             d16 = _empty((rows, D), dt, dev)
             ops.layernorm_bwd(gin, u, P(pre + "LayerNorm.weight"), m_, r_, dx32=gin, dx16=d16, scale16=Sg,
                               dgamma=G(pre + "LayerNorm.weight"), dbeta=G(pre + "LayerNorm.bias"), dtype=dt)
+            if ph > 0:
+                ops.dropout_(d16, (ph, dseed, site))
             return d16
 
         def split_rows(dwf, names):
@@ -847,7 +865,7 @@ class BertFn(torch.autograd.Function):
             p = f"encoder.layer.{li}."
             a = ctx.acts.pop()
             # ---- FFN ----
-            d16 = ln_bwd(g, a["u3"], a["m3"], a["r3"], p + "output.")          # g := dL/du3 (= dL/d(resid x32b) too)
+            d16 = ln_bwd(g, a["u3"], a["m3"], a["r3"], p + "output.", li * 8 + SITE_FFN_OUT)   # g := dL/du3 (= dL/d(resid) too)
             linear_wgrad(d16, a["act"], G(p + "output.dense.weight"), inv_s)
             ops.colsum(d16, G(p + "output.dense.bias"), scale=inv_s, accumulate=True)
             dh = a["act"]
@@ -858,7 +876,7 @@ class BertFn(torch.autograd.Function):
             # ---- cross attention ----
             if cond16 is not None:
                 ca = p + "crossattention.self."
-                d16 = ln_bwd(g, a["u2"], a["m2"], a["r2"], p + "crossattention.output.")
+                d16 = ln_bwd(g, a["u2"], a["m2"], a["r2"], p + "crossattention.output.", li * 8 + SITE_CROSS_OUT)
                 linear_wgrad(d16, a["cc"], G(p + "crossattention.output.dense.weight"), inv_s)
                 ops.colsum(d16, G(p + "crossattention.output.dense.bias"), scale=inv_s, accumulate=True)
                 dcc = _empty((rows, D), dt, dev)
@@ -869,7 +887,7 @@ class BertFn(torch.autograd.Function):
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 kv = a["kv"]
                 ops.attn_bwd(a["q"], kv, kv[:, D:], a["cc"], dcc, a["lse_c"], dq, dkv, dkv[:, D:], delta, B=b, H=H, Sq=S, Sk=E,
-                             hd=hd, scale=scale, mask=None, **stc)
+                             hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), **stc)
                 linear_wgrad(dq, a["x16a"], G(ca + "query.weight"), inv_s)
                 ops.colsum(dq, G(ca + "query.bias"), scale=inv_s, accumulate=True)
                 dwkv = torch.zeros((2 * D, D), dtype=torch.float32, device=dev)
@@ -885,7 +903,7 @@ class BertFn(torch.autograd.Function):
                 del dq, dkv, dcc
             # ---- self attention ----
             sa = p + "attention.self."
-            d16 = ln_bwd(g, a["u"], a["m1"], a["r1"], p + "attention.output.")
+            d16 = ln_bwd(g, a["u"], a["m1"], a["r1"], p + "attention.output.", li * 8 + SITE_SELF_OUT)
             linear_wgrad(d16, a["co"], G(p + "attention.output.dense.weight"), inv_s)
             ops.colsum(d16, G(p + "attention.output.dense.bias"), scale=inv_s, accumulate=True)
             dco = _empty((rows, D), dt, dev)
@@ -895,7 +913,7 @@ class BertFn(torch.autograd.Function):
             delta = _empty((b, H, S), torch.float32, dev)
             st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
             ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["co"], dco, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
-                         B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, **st)
+                         B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, drop=at_drop(li * 8 + SITE_SELF_P), **st)
             dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
             linear_wgrad(dqkv, a["x16"], dwf, inv_s)
             split_rows(dwf, [sa + "query.weight", sa + "key.weight", sa + "value.weight"])
@@ -906,13 +924,15 @@ class BertFn(torch.autograd.Function):
             ops.gemm(dqkv, wqkv, g, tb=True, M=rows, N=D, K=3 * D, alpha=inv_s, resid=g)
             del a, dqkv, dco, d16
         # ---- embeddings ----
+        if ph > 0:
+            ops.dropout_(g, (ph, dseed, SITE_EMB))
         ops.layernorm_bwd(g, emb, P("embeddings.LayerNorm.weight"), mean_e, rstd_e, dx32=g,
                           dgamma=G("embeddings.LayerNorm.weight"), dbeta=G("embeddings.LayerNorm.bias"), dtype=dt)
         dtype0 = torch.zeros(D, dtype=torch.float32, device=dev)
         ops.embed_scatter_add(ids, g, G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"), dtype0, S)
         G("embeddings.token_type_embeddings.weight")[0].add_(dtype0)
         dc = dcond.view(b, E, D) if (dcond is not None and ctx.cond_needs_grad) else None
-        return (None, None, None, dc) + grads.result()
+        return (None, None, None, dc, None) + grads.result()
 
 
 # ======================================================================================================================

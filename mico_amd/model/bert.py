@@ -93,6 +93,7 @@ class BertModel(nn.Module):
         self.embeddings = _Embeddings(c)
         self.encoder = _Encoder(c)
         self._spec = None
+        self.dropout_seed_source = None   # callable -> int; None: one draw per pass from torch's host generator
 
     def _bert_spec(self):
         named = list(self.named_parameters())
@@ -108,7 +109,13 @@ class BertModel(nn.Module):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         spec, params = self._bert_spec()
-        seq = Fn.BertFn.apply(spec, input_ids, extended_attention_mask(attention_mask), encoder_hidden_states, *params)
+        drop = None
+        ph, pa = self.config["hidden_dropout_prob"], self.config["attention_probs_dropout_prob"]
+        if self.training and (ph > 0 or pa > 0):
+            # nn.Dropout sites of bert.py:148,267,295,373: masks come from a counter hash of (seed, site, element), one seed per pass
+            seed = self.dropout_seed_source() if self.dropout_seed_source is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)))
+            drop = (float(ph), float(pa), int(seed))
+        seq = Fn.BertFn.apply(spec, input_ids, extended_attention_mask(attention_mask), encoder_hidden_states, drop, *params)
         return _Out(last_hidden_state=seq)
 
 

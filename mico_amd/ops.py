@@ -56,7 +56,7 @@ def pad8(n):
 
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
          row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
-         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0):
+         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0, drop=None):
     """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
     leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
     dtype = dtype or A.dtype
@@ -83,6 +83,8 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.accumulate = 1 if accumulate else 0
     e.row_map = _p(row_map)
     e.rows_per_map = rows_per_map
+    if drop is not None:   # (p, seed, site)
+        e.drop_p, e.drop_seed, e.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     if ksegs is not None:   # (kseg, a_offsets, b_offsets)
         e.kseg, e.nseg = ksegs[0], len(ksegs[1])
         for i, (ao, bo) in enumerate(zip(ksegs[1], ksegs[2])):
@@ -104,7 +106,7 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
 
 def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
                   post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16, frame_map=None,
-                  rows_per_frame=0, x_copy=None):
+                  rows_per_frame=0, x_copy=None, drop=None):
     """split16: out16 is [rows, 2*cols] and receives [hi | lo] (split-precision GEMM operand).  frame_map (int32 [frames]):
     compacting gather of whole frames out of x; the number of rows is then len(frame_map) * rows_per_frame."""
     rows, cols = x.shape[0], x.shape[1]
@@ -112,7 +114,9 @@ def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rst
         rows = frame_map.shape[0] * rows_per_frame
     rc = _lib.lib().mico_layernorm_fwd(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(out32), _p(mean),
                                        _p(rstd), rows, cols, eps, _p(post_add), post_rows_per_group, post_groups,
-                                       int(split16), _p(frame_map), rows_per_frame, _p(x_copy), dt_code(dtype), _st())
+                                       int(split16), _p(frame_map), rows_per_frame, _p(x_copy),
+                                       float(drop[0]) if drop else 0.0, (int(drop[1]) & 0xFFFFFFFF) if drop else 0,
+                                       int(drop[2]) if drop else 0, dt_code(dtype), _st())
     check(rc, "mico_layernorm_fwd")
 
 
@@ -130,8 +134,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=N
     check(rc, "mico_layernorm_bwd")
 
 
-def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides):
+def dropout_(x, drop):
+    """In-place dropout of a 2-D fp32 / 16-bit tensor with the (p, seed, site) counter hash (see mico_dropout)."""
+    rows, cols = x.shape
+    check(_lib.lib().mico_dropout(_p(x), dt_code(x.dtype), rows, cols, x.stride(0), float(drop[0]), int(drop[1]) & 0xFFFFFFFF,
+                                  int(drop[2]), _st()), "mico_dropout")
+    return x
+
+
+def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop=None):
     p = AttnParams()
+    if drop is not None:
+        p.drop_p, p.drop_seed, p.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     p.B, p.H, p.Sq, p.Sk, p.hd = B, H, Sq, Sk, hd
     p.q_bs, p.q_rs = q_strides
     p.k_bs, p.k_rs = k_strides
@@ -148,17 +162,17 @@ def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides
     return p
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides, v_strides, o_strides):
+def attn_fwd(q, k, v, o, lse, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides, v_strides, o_strides, drop=None):
     """q/k/v/o are 16-bit tensors (possibly views into one fused projection buffer); *_strides = (batch, row) in
     elements.  mask: additive fp32 [B,Sk] or [B,Sq,Sk]."""
-    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides)
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop)
     rc = _lib.lib().mico_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), C.byref(p), dt_code(q.dtype), _st())
     check(rc, "mico_attn_fwd")
 
 
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, delta, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides,
-             v_strides, o_strides):
-    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides)
+             v_strides, o_strides, drop=None):
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop)
     rc = _lib.lib().mico_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk), _p(dv), _p(delta),
                                   C.byref(p), dt_code(q.dtype), _st())
     check(rc, "mico_attn_bwd")

@@ -164,8 +164,57 @@ def extended_mask(attention_mask):
     return (1.0 - m) * -10000.0
 
 
-def bert_attention(sd, p, hidden, kv_src, add_mask):
-    """model/bert.py:184-283 (BertSelfAttention) + :293-297 (BertSelfOutput), dropout off."""
+# ---- train-mode dropout (bert.py:148,267,295,373) -----------------------------------------------------------
+# torch's nn.Dropout draws are not reproducible across devices, so stochastic parity is tested the same way as the
+# negative-sampling and DropPath draws: with an injected mask.  The product derives its masks from a stateless
+# counter hash (include/mico_hip.h, mico_dropout); drop_mask restates that hash so both sides see the same mask,
+# and the rest of the arithmetic is the reference's: x * mask / (1 - p).
+_DROPOUT = None          # dict(p_hidden, p_attn, seeds=iterator) while a `bert_dropout` context is active
+SITE_SELF_OUT, SITE_CROSS_OUT, SITE_FFN_OUT, SITE_SELF_P, SITE_CROSS_P, SITE_EMB = 0, 1, 2, 3, 4, 100000
+
+
+class bert_dropout:
+    """with bert_dropout(p_hidden, p_attn, seeds): every bert_forward call inside consumes one seed (in call order)."""
+
+    def __init__(self, p_hidden, p_attn, seeds):
+        self.cfg = dict(p_hidden=p_hidden, p_attn=p_attn, seeds=iter(seeds))
+
+    def __enter__(self):
+        global _DROPOUT
+        self.prev, _DROPOUT = _DROPOUT, self.cfg
+
+    def __exit__(self, *a):
+        global _DROPOUT
+        _DROPOUT = self.prev
+
+
+def drop_mask(seed, site, shape, p):
+    """keep / (1 - p) multipliers for a contiguous tensor of `shape` (element index = flat row-major index)."""
+    import numpy as np
+    n = 1
+    for d in shape:
+        n *= d
+    idx = np.arange(n, dtype=np.uint64)
+    lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(site) * np.uint32(0x9E3779B9))
+        h = h ^ (lo * np.uint32(0x85EBCA6B))
+        h = ((h << np.uint32(13)) | (h >> np.uint32(19))) * np.uint32(5) + np.uint32(0xE6546B64)
+        h = h ^ (hi * np.uint32(0xC2B2AE35))
+        h = ((h << np.uint32(13)) | (h >> np.uint32(19))) * np.uint32(5) + np.uint32(0xE6546B64)
+        h ^= h >> np.uint32(16)
+        h *= np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+    thr = np.uint32(int(np.float32(p) * np.float32(16777216.0)))
+    keep = (h >> np.uint32(8)) >= thr
+    return torch.from_numpy(keep.astype(np.float32)).view(*shape) / (1.0 - p)
+
+
+def bert_attention(sd, p, hidden, kv_src, add_mask, drop=None):
+    """model/bert.py:184-283 (BertSelfAttention) + :293-297 (BertSelfOutput).  drop: None or
+    (p_hidden, p_attn, seed, site_probs, site_out) - the nn.Dropout calls of :267 and :295."""
     b, S, D = hidden.shape
     H, hd = BERT_HEADS, D // BERT_HEADS
 
@@ -178,8 +227,13 @@ def bert_attention(sd, p, hidden, kv_src, add_mask):
     s = q @ k.transpose(-1, -2) / math.sqrt(hd)
     if add_mask is not None:
         s = s + add_mask
-    ctx = (s.softmax(dim=-1) @ v).permute(0, 2, 1, 3).reshape(b, S, D)
+    probs = s.softmax(dim=-1)
+    if drop is not None and drop[1] > 0:
+        probs = probs * drop_mask(drop[2], drop[3], probs.shape, drop[1])
+    ctx = (probs @ v).permute(0, 2, 1, 3).reshape(b, S, D)
     out = F.linear(ctx, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    if drop is not None and drop[0] > 0:
+        out = out * drop_mask(drop[2], drop[4], out.shape, drop[0])
     return layer_norm(out + hidden, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT_EPS)
 
 
@@ -192,6 +246,11 @@ def bert_forward(sd, input_ids, attention_mask, encoder_hidden_states=None, pre=
     x = sd[e + "word_embeddings.weight"][input_ids] + sd[e + "token_type_embeddings.weight"][0] \
         + sd[e + "position_embeddings.weight"][:S]
     x = layer_norm(x, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], BERT_EPS)
+    dr = None
+    if _DROPOUT is not None:
+        dr = (_DROPOUT["p_hidden"], _DROPOUT["p_attn"], next(_DROPOUT["seeds"]))
+        if dr[0] > 0:
+            x = x * drop_mask(dr[2], SITE_EMB, x.shape, dr[0])
     am = extended_mask(attention_mask)
     L = n_layers
     if L is None:
@@ -200,11 +259,14 @@ def bert_forward(sd, input_ids, attention_mask, encoder_hidden_states=None, pre=
             L += 1
     for i in range(L):
         p = pre + f"encoder.layer.{i}."
-        x = bert_attention(sd, p + "attention.", x, x, am)
+        x = bert_attention(sd, p + "attention.", x, x, am, dr and dr + (i * 8 + SITE_SELF_P, i * 8 + SITE_SELF_OUT))
         if encoder_hidden_states is not None:
-            x = bert_attention(sd, p + "crossattention.", x, encoder_hidden_states, None)
+            x = bert_attention(sd, p + "crossattention.", x, encoder_hidden_states, None,
+                               dr and dr + (i * 8 + SITE_CROSS_P, i * 8 + SITE_CROSS_OUT))
         h = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
         h = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        if dr is not None and dr[0] > 0:
+            h = h * drop_mask(dr[2], i * 8 + SITE_FFN_OUT, h.shape, dr[0])
         x = layer_norm(h + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], BERT_EPS)
     return x
 
