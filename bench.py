@@ -165,8 +165,8 @@ def main():
     samples = b * world * args.steps
     value = samples / elapsed
     summ = timer.summary()
-    names = {(0, 0): "gemm_kernel<T,false,false> (y = x W^T, forward)", (0, 1): "gemm_kernel<T,false,true> (dx = dy W)",
-             (1, 1): "gemm_kernel<T,true,true> (dW = dy^T x)"}
+    names = {(0, 0): "gemm_kernel<T,false,false,Big> (y = x W^T, forward)", (0, 1): "gemm_kernel<T,false,true,Big> (dx = dy W)",
+             (1, 1): "gemm_pc_kernel<T,true,true,32> (dW = dy^T x, producer/consumer waves)"}
     per_variant = {names[k]: dict(launches=v["launches"], avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / v["ms"] / 1e9)
                    for k, v in summ.items()}
     tot_flops = sum(v["flops"] for v in summ.values())

@@ -157,11 +157,11 @@ __device__ __forceinline__ void dma_offsets(unsigned (&vo)[NDMA], int wave, int 
     }
 }
 
-template <int THREADS, int NDMA>
+template <int THREADS, int NDMA, int NISSUE = NDMA>
 __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, const unsigned (&vo)[NDMA],
                                           unsigned koff) {
 #pragma unroll
-    for (int it = 0; it < NDMA; ++it) {
+    for (int it = 0; it < NISSUE; ++it) {
         unsigned v = (vo[it] == 0xFFFFFFF0u) ? 0xFFFFFFF0u : vo[it] + koff;
         if (MICO_GEMM_ABLATE == 4) v |= 0xFFFFFFF0u;   // ablation: every DMA out of bounds (issue + LDS zero-fill, no memory traffic)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), 16, v, 0, 0, 0);
@@ -174,14 +174,14 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char
 // parks a 64x64 fp32 block of its accumulators in LDS (16 KiB, XOR-swizzled 16-byte chunks, conflict free both ways) and
 // re-reads it so that a lane owns 16 consecutive columns of one row: bias / residual / auxiliary loads and the stores are
 // then 32-64 contiguous bytes per lane, 128-256 per row - whole cache lines.  acc[0..3] is the block for 64 rows at mrow0.
-template <typename T>
+template <typename T, int MB = 4>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
     const mico_gemm_epilogue& e = g.e;
     {
         const int p = lane & 15, gq = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = i * 16 + p, cc = j * 4 + gq;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
 #pragma unroll
     for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && v < nvec) ? *(const f32x4*)(e.bias + n + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < MB; ++pass) {
         const int row = pass * 16 + (lane >> 2);
         const int64_t m = mrow0 + row;
         if (m >= g.M) continue;
@@ -254,10 +254,11 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
 
 // Direct (register-layout) epilogue for split-K partial tiles: alpha-scaled fp32 atomics straight from the MFMA layout
 // (4 consecutive columns per lane); measured 2x faster for atomics than the LDS-transposed 16-column form.
+template <int MB = 4>
 __device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& g, const f32x4 (*acc)[4], int64_t mrow0, int64_t ncol0,
                                                      int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MB; ++i) {
         const int64_t m = mrow0 + i * 16 + (lane & 15);
         if (m >= g.M) continue;
 #pragma unroll
@@ -466,6 +467,230 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// ======================================================================================================================
+// Producer / consumer kernel for the large GEMMs.
+// Probes (tools/probes/producer_consumer.hip, dma_mfma_overlap.hip) showed what bounds the 8-wave kernel above: a wave that
+// issues LDS-DMA instructions stalls on VMEM issue back-pressure (the memory side returns a 256x256x64 tile's 64 KiB in
+// 0.5-0.65 us) and cannot issue MFMAs meanwhile, so fill time adds to compute time instead of hiding behind it; the same DMA
+// issued by waves that do nothing else costs the MFMA waves ~5 %.  Hence 12 waves per workgroup: waves 0-7 are CONSUMERS
+// (2x4, ds_read + MFMA only, the same two-group ping-pong as above), waves 8-11 are PRODUCERS (one per SIMD; all DMA, counted
+// vmcnt, 3 K-tiles in flight).  Three waves per SIMD leave 168 VGPRs per wave, so the block tile is 192x256: a consumer owns
+// 96x64 (24 accumulator tiles = 96 VGPRs, 10 fragments).  The LDS images keep the 256-row layout and swizzles of the kernel
+// above - only rows 0-191 of the A image are filled - and a consumer's 96 rows are rows wm*64..+63 and 128+wm*32..+31, so both
+// operand orientations reuse the same fragment addressing.
+// ======================================================================================================================
+// K-tile depth: 32 (4-stage ring) when both operands are reduction-major (their DMA rows are 512 bytes anyway); 64 (2 stages)
+// when an operand is k-contiguous, so that its DMA rows are whole 128-byte lines instead of 64-byte halves (fill ceiling 95-128
+// instead of 58-77 GB/s per CU, tools/probes/dma_fill.hip) - with producers the shallower ring costs the consumers nothing.
+template <int BK_> struct Wide {
+    static constexpr int BM = 192, BN = 256, BK = BK_, STAGES = BK_ == 32 ? 4 : 2, MT = 6, KSTEPS = BK_ / 32;
+    static constexpr int CWAVES = 8, PWAVES = 4, THREADS = (CWAVES + PWAVES) * 64, PTHREADS = PWAVES * 64;
+    static constexpr int A_BYTES = 256 * BK * 2, STAGE_BYTES = 2 * A_BYTES, LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int NDMA = A_BYTES / 16 / PTHREADS;   // DMA instructions per producer thread per 256-row operand image
+};
+
+template <typename T, bool TA, bool TB, int BKW>
+__global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmArgs g) {
+    using CFG = Wide<BKW>;
+    constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, MT = CFG::MT, PTH = CFG::PTHREADS, ND = CFG::NDMA;
+    constexpr int RING = CFG::STAGES * CFG::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[CFG::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int bid = blockIdx.x;
+    const int ks = bid / g.ntiles;
+    bid -= ks * g.ntiles;
+    {
+        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    int tile_m, tile_n;
+    {
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        tile_m = first + in % gm;
+        tile_n = in / gm;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int kt0 = ks * g.ktiles_per_split;
+    const int kt1 = min(g.ktiles, kt0 + g.ktiles_per_split);
+    const int T_ = kt1 - kt0;
+
+    if (wave >= CFG::CWAVES) {
+        // ------------------------------------------------ producers ------------------------------------------------
+        const int pw = wave - CFG::CWAVES;
+        const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+        const char* a_base = TA ? g.A + m0 * 2 : g.A + m0 * lda_b;
+        const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
+        int64_t a_bytes = TA ? g.ka_rows * lda_b - m0 * 2 : (g.M - m0) * lda_b;
+        int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+        if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+        if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+        __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+        const int64_t a_crem = min(g.M - m0, (int64_t)BM), b_crem = g.N - n0;
+        unsigned voa[ND], vob[ND];
+        dma_offsets<TA, 256, PTH, BK, ND>(voa, pw, lane, lda_b, a_crem);
+        dma_offsets<TB, 256, PTH, BK, ND>(vob, pw, lane, ldb_b, b_crem);
+        // k-contiguous A image: rows are chunk-major, the last quarter of the instructions is exactly rows 192..255 -> never
+        // issued; reduction-major A image: columns >= 192 are scattered over all instructions -> issued, marked out of bounds
+        constexpr int NA = TA ? ND : ND - ND / 4;
+        constexpr int PTI = NA + ND;
+        const int nseg = g.e.nseg, kseg = g.e.kseg;
+        const bool ktail = (g.K % BK) != 0;
+        auto stage = [&](int kt, int bo) {
+            const int k0 = kt * BK;
+            int ka = k0, kb = k0;
+            int64_t kda = g.K, kdb = g.K;
+            if (nseg > 0) {
+                const int sg = k0 / kseg, kin = k0 - sg * kseg;
+                ka = g.e.a_seg_off[sg] + kin;
+                kb = g.e.b_seg_off[sg] + kin;
+                kda = g.e.a_seg_off[sg] + kseg;
+                kdb = g.e.b_seg_off[sg] + kseg;
+            }
+            if (MICO_GEMM_ABLATE == 1 && kt >= kt0 + 3) return;
+            if (ktail && kt == g.ktiles - 1) {   // ragged last K-tile: masked path (issues ND + ND instructions; it is waited with vmcnt(0))
+                stage_tile<TA, 256, PTH, BK>(rsa, lds + bo, pw, lane, lda_b, ka, kda, a_crem);
+                stage_tile<TB, 256, PTH, BK>(rsb, lds + bo + CFG::A_BYTES, pw, lane, ldb_b, kb, kdb, b_crem);
+                return;
+            }
+            const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
+            const unsigned kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
+            dma_issue<PTH, ND, NA>(rsa, lds + bo, pw, voa, koa);
+            dma_issue<PTH, ND, ND>(rsb, lds + bo + CFG::A_BYTES, pw, vob, kob);
+        };
+        constexpr int AHEAD = CFG::STAGES - 1;   // K-tiles in flight
+        for (int i = 0; i < AHEAD && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
+        int bo = 0;
+        for (int t = 0; t < T_; ++t) {
+            asm volatile("" : "+s"(bo));
+            const int ahead = T_ - 1 - t;
+            // this wave's share of tile t has landed; the barrier publishes it.  (A masked last tile carries more
+            // instructions than PTI: the counts below then over-wait, never under-wait.)
+            if (AHEAD >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PTI) : "memory");
+            else if (AHEAD >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PTI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // the buffer of tile t-1: every consumer retired its reads of it before the barrier above
+            if (t + AHEAD < T_) stage(kt0 + t + AHEAD, (bo + AHEAD * CFG::STAGE_BYTES) & (RING - 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2 * CFG::KSTEPS - 1; ++r) {   // the consumers' remaining barriers of this K-tile
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+        }
+        __builtin_amdgcn_s_barrier();   // the consumers' end-of-loop barrier
+        return;
+    }
+
+    // -------------------------------------------------- consumers --------------------------------------------------
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const FragBase ab = frag_base<TA, 256, BK>(wm * 64, lane), ab2 = frag_base<TA, 256, BK>(128 + wm * 32, lane);
+    const FragBase bb = frag_base<TB, 256, BK>(wn * 64, lane);
+    s16x8 fa[MT], fb[4];
+    auto read_k = [&](int bo, int kk) {
+        LDS_AS const char* ta = lds + bo;
+        LDS_AS const char* tb = ta + CFG::A_BYTES;
+        const int a1 = kk ? ab.b1 : ab.b0, a2 = kk ? ab2.b1 : ab2.b0, b1 = kk ? bb.b1 : bb.b0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag_b<TA, 256, BK>(ta, a1, i);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[4 + i] = read_frag_b<TA, 256, BK>(ta, a2, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag_b<TB, 256, BK>(tb, b1, j);
+    };
+    auto mma_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[j], fa[i], acc[i][j]);
+    };
+    auto head = [&]() {   // own LDS reads of the buffer about to be refilled have returned; then the producers' barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int bo = 0;
+    if (wm == 0) {
+        for (int t = 0; t < T_; ++t) {
+            asm volatile("" : "+s"(bo));
+            head();
+            read_k(bo, 0);
+            bar();
+            mma_k();
+            if constexpr (CFG::KSTEPS == 2) {
+                bar();
+                read_k(bo, 1);
+                bar();
+                mma_k();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+        }
+    } else {
+        for (int t = 0; t < T_; ++t) {
+            asm volatile("" : "+s"(bo));
+            head();
+            if (t > 0) mma_k();
+            bar();
+            read_k(bo, 0);
+            if constexpr (CFG::KSTEPS == 2) {
+                bar();
+                mma_k();
+                bar();
+                read_k(bo, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+        }
+        if (T_ > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mma_k();
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is done with the operand tiles: LDS may be reused by the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue: three 32-row blocks per consumer ----
+#pragma unroll
+    for (int hb = 0; hb < 3; ++hb) {
+        const int64_t mrow = m0 + (hb < 2 ? wm * 64 + hb * 32 : 128 + wm * 32);
+        if (g.split_k > 1) gemm_epilogue_atomic<2>(g, &acc[hb * 2], mrow, n0 + wn * 64, lane);
+        else gemm_epilogue_block<T, 2>(g, &acc[hb * 2], lds + wave * 8192, mrow, n0 + wn * 64, lane);
+    }
+}
+
+constexpr int pc_bk(int ta, int tb) { return (ta && tb) ? 32 : 64; }
+
+template <typename T>
+void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
+    const dim3 grid(g.ntiles * g.split_k), block(Wide<32>::THREADS);
+    if (!ta && !tb) MICO_LAUNCH((gemm_pc_kernel<T, false, false, 64>), grid, block, 0, st, g);
+    else if (!ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, false, true, 64>), grid, block, 0, st, g);
+    else if (ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, true, true, 32>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_pc_kernel<T, true, false, 64>), grid, block, 0, st, g);
+}
+
 template <typename T, typename CFG>
 void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles * g.split_k), block(CFG::THREADS);
@@ -534,13 +759,22 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // the parallelism, so the big tile pays as soon as K is long
     const bool long_k_acc = split_k <= 0 && c_dtype == MICO_F32 && g.e.accumulate && K >= 8192 && big_tiles >= 8;
     const bool big = (big_tiles >= 128 || long_k_acc) && N >= 192;
-    const int BM = big ? 256 : 128, BN = big ? 256 : 128;
+    // the producer/consumer kernel (192x256) takes every large problem; MICO_GEMM_NO_PC (ablation builds) keeps the 8-wave kernel
+#ifdef MICO_GEMM_NO_PC
+    const bool pc = false;
+#else
+    // measured (tools/gemm_bench.py, ViT-g/14 shapes): the producer/consumer kernel wins for the weight-gradient orientation
+    // (both operands reduction-major, long K per workgroup: 911 vs 730 TFLOP/s) and loses for the short-K forward / dX GEMMs
+    // (742-866 vs 946-960), whose per-tile prologue + epilogue cost weighs more on the smaller 192x256 tile
+    const bool pc = big && ta && tb;
+#endif
+    const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = big ? 256 : 128;
     const int slots = big ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
     g.ntiles = g.ntm * g.ntn;
-    const int BKc = big ? Big::BK : Small::BK;
+    const int BKc = pc ? pc_bk(ta, tb) : (big ? Big::BK : Small::BK);
     g.ktiles = (int)((K + BKc - 1) / BKc);
-    if (split_k <= 0) split_k = (c_dtype == MICO_F32 && g.e.accumulate) ? auto_split(g.ntiles, g.ktiles, slots, big ? 32 : 16, big ? 24 : 12) : 1;
+    if (split_k <= 0) split_k = (c_dtype == MICO_F32 && g.e.accumulate) ? auto_split(g.ntiles, g.ktiles, slots, big ? 1024 / BKc : 16, big ? 768 / BKc : 12) : 1;
     if (split_k > g.ktiles) split_k = g.ktiles;
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
@@ -567,7 +801,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
     MICO_CHECK(g.e.drop_p >= 0.f && g.e.drop_p < 1.f, "mico_gemm: drop_p must be in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
-    if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
+    if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
+    else if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
     else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));
     MICO_LAUNCH_CHECK();
     return MICO_OK;

@@ -1,0 +1,93 @@
+"""The large-problem GEMM path (producer/consumer kernel, 192x256 tiles; chosen when the problem has >= 128 256x256 tiles or is a
+long-reduction weight gradient): every operand orientation, ragged M / N / K edges, split-K accumulation, the fused epilogues,
+frame-scatter row map, k-segments - against fp32 matmul."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from common import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops(A, B, ta, tb):
+    Af = (A.t() if ta else A).float()
+    Bf = (B.t() if tb else B).float()
+    return Af @ Bf.t()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(4096 + 77, 2048 + 8, 512 + 24), (6000, 1408, 352), (193 * 40 + 5, 4224, 96)])
+def test_large_plain(cuda, dtype, ta, tb, M, N, K):
+    from mico_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ldm, ldn, ldk = ops.pad8(M), ops.pad8(N), ops.pad8(K)
+    A = torch.randn((K, ldm) if ta else (M, ldk), device=cuda, generator=g).to(dtype)
+    B = torch.randn((K, ldn) if tb else (N, ldk), device=cuda, generator=g).to(dtype)
+    ref = _ops(A[:, :M] if ta else A[:, :K], B[:, :N] if tb else B[:, :K], ta, tb)
+    out = torch.full((M, N), float("nan"), device=cuda, dtype=torch.float32)
+    ops.gemm(A, B, out, ta=ta, tb=tb, M=M, N=N, K=K, dtype=dtype)
+    assert rel_err(out, ref) < 1e-5 * math.sqrt(K) + 1e-6
+    out16 = torch.empty((M, N), device=cuda, dtype=dtype)
+    ops.gemm(A, B, out16, ta=ta, tb=tb, M=M, N=N, K=K, dtype=dtype)
+    assert rel_err(out16, ref) < (4e-3 if dtype == torch.float16 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_large_weight_gradient_split_k(cuda, dtype):
+    """dW += alpha * dy^T x with the library-chosen K split (atomics), tokens = 257 * 37 (ragged K tail)."""
+    from mico_amd import ops
+    torch.manual_seed(6)
+    rows, n_out, n_in = 257 * 37, 1408, 2816
+    dy = (0.1 * torch.randn(rows, n_out, device=cuda)).to(dtype)
+    x = torch.randn(rows, n_in, device=cuda).to(dtype)
+    dw = torch.randn(n_out, n_in, device=cuda)
+    ref = dw + 0.25 * (dy.float().t() @ x.float())
+    ops.gemm(dy, x, dw, ta=True, tb=True, M=n_out, N=n_in, K=rows, accumulate=True, alpha=0.25, split_k=0)
+    assert rel_err(dw, ref) < 2e-5 * math.sqrt(rows)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_large_epilogues(cuda, dtype):
+    from mico_amd import ops
+    torch.manual_seed(7)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    M, N, K = 257 * 24, 6144, 264
+    A = (0.5 * torch.randn(M, K, device=cuda)).to(dtype)
+    W = (0.1 * torch.randn(N, K, device=cuda)).to(dtype)
+    bias = torch.randn(N, device=cuda)
+    acc = A.float() @ W.float().t()
+    h = torch.empty(M, N, device=cuda, dtype=dtype)
+    a = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(A, W, a, bias=bias, aux_out=h, act=ops.ACT_GELU)
+    assert rel_err(h, acc + bias) < tol and rel_err(a, F.gelu(acc + bias)) < tol
+    dh = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(A, W, dh, aux_in=h, act=ops.ACT_GELU_GRAD, alpha=0.5)
+    hf = h.float()
+    gp = 0.5 * (1 + torch.erf(hf / math.sqrt(2))) + hf * torch.exp(-0.5 * hf * hf) / math.sqrt(2 * math.pi)
+    assert rel_err(dh, 0.5 * acc * gp) < tol
+    # residual stream update in place, per-frame scale, frame scatter (stochastic-depth compaction): 24 kept of 31 frames
+    kept = torch.tensor(sorted(torch.randperm(31)[:24].tolist()), dtype=torch.int32, device=cuda)
+    scale = torch.zeros(31, device=cuda)
+    scale[kept.long()] = 1.0 / 0.7
+    x = torch.randn(31 * 257, N, device=cuda)
+    ref = x.clone()
+    rows = (kept.long()[:, None] * 257 + torch.arange(257, device=cuda)[None]).reshape(-1)
+    ref[rows] += (acc + bias) / 0.7
+    ops.gemm(A, W, x, bias=bias, resid=x, row_scale=scale, rows_per_scale=257, row_map=kept, rows_per_map=257)
+    assert rel_err(x, ref) < 1e-5 * math.sqrt(K) + 1e-6
+    # split-precision k-segments (fp16 parity configuration)
+    if dtype == torch.float16:
+        Kp = 320
+        xx = torch.randn(M, Kp, device=cuda)
+        ww = 0.05 * torch.randn(N, Kp, device=cuda)
+        xh, wh = xx.half(), ww.half()
+        x2 = torch.cat((xh, (xx - xh.float()).half()), 1).contiguous()
+        w2 = torch.cat((wh, (ww - wh.float()).half()), 1).contiguous()
+        out = torch.empty(M, N, device=cuda)
+        ops.gemm(x2[:, :Kp], w2[:, :Kp], out, ksegs=(Kp, [0, Kp, 0], [0, 0, Kp]))
+        ref = xx.double() @ ww.double().t()
+        assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
