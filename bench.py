@@ -180,9 +180,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
     if os.path.exists(tpath) and world == 1:
         tj = json.load(open(tpath))
-        key = {(0, 0): "NN_big", (0, 1): "dX_big", (1, 1): "dW_big"}[dom[0]]
-        if key in tj:
-            traffic = tj[key]["hbm_bytes_per_launch"]
+        for key in {(0, 0): ("NN_big",), (0, 1): ("dX_big",), (1, 1): ("dW_pc", "dW_big")}[dom[0]]:
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+                break
     roofline = dict(bound="mfma", kernel=names[dom[0]], achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
                     launches=dom[1]["launches"],
