@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
+    ap.add_argument("--optimizer", action="store_true",
+                    help="also run the AdamW step (mico_amd.optim, SURVEY section 8 row f4) inside the timed step: a full training step, "
+                         "beyond the metric's fwd+bwd definition")
     ap.add_argument("--no-bert-dropout", action="store_true", help="A/B switch: BERT dropout probabilities set to 0 (invalidates the metric)")
     ap.add_argument("--dense-droppath", action="store_true",
                     help="evaluate dropped residual branches too and multiply them by 0 (the reference's schedule) instead of skipping them")
@@ -125,6 +128,13 @@ def main():
     b = args.batch
     batch = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, **wl["shape"]), seed=1234 + rank).items()}
     reducer = GradBucketReducer(model.parameters()) if world > 1 else None
+    optimizer = None
+    if args.optimizer:
+        from mico_amd.optim import AdamW
+        decay = [p for n, p in model.named_parameters() if not any(k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+        nodecay = [p for n, p in model.named_parameters() if any(k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+        optimizer = AdamW([dict(params=decay, weight_decay=0.01, lr=1e-6), dict(params=nodecay, weight_decay=0.0, lr=1e-6)],
+                          lr=1e-6, betas=(0.9, 0.98))
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -133,6 +143,8 @@ def main():
         total.backward()
         if reducer is not None:
             reducer.finish()
+        if optimizer is not None:
+            optimizer.step()
         return losses
 
     for _ in range(args.warmup):
@@ -211,7 +223,7 @@ def main():
                    "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),
                    "droppath_schedule": ("dense: every branch evaluated then scaled by 0 | 1/keep" if args.dense_droppath
                                          else "dropped (block, branch, frame) triples are skipped - exact, zero contribution"),
-                   "kept_branch_fraction": kept,
+                   "kept_branch_fraction": kept, "optimizer_step_in_timed_region": bool(args.optimizer),
                    "bert_dropout": (False if (args.eval_mode or args.no_bert_dropout) else
                                     "on: p=0.1 hidden + attention-probability (reference config.json)")},
         "samples_per_sec_per_gpu": value / world,

@@ -245,6 +245,34 @@ int mico_sgemm_small(int ta, int tb, int M, int N, int K, const float* A, int64_
 int mico_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int cols, void* stream);
 int mico_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int cols, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Optimizer step: the decoupled-weight-decay Adam of data/utils/build_optimizer.py:105-197,
+ * one launch for a whole parameter group (multi-tensor).  Per element, in this order (fp32):
+ *     m = beta1 m + (1 - beta1) g;   v = beta2 v + (1 - beta2) g g;   p -= step_size * m / (sqrt(v) + eps);
+ *     if (weight_decay > 0) p -= lr * weight_decay * p;
+ * step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t) when correct_bias, else lr (computed by the caller).
+ * tensors: device array of n_tensors descriptors; chunk_tensor / chunk_start (device int32 / int64, nchunks each) split the
+ * tensors into pieces of at most chunk_elems elements, one workgroup each.  A descriptor may name a 16-bit mirror of the
+ * parameter (the GEMM-operand copy the engine keeps): w16[(i / cols) * ld16 + i % cols] = T(p[i]) is refreshed in the same
+ * pass (and, for the split-precision layout, the low half T(p - hi) at + lo_off), so no re-cast pass follows a step.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct mico_adamw_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t numel;
+    void* w16;        /* optional 16-bit mirror (NULL: none) */
+    int64_t ld16;     /* row stride of the mirror in elements */
+    int64_t lo_off;   /* > 0: also write the low half at w16 + lo_off (split-precision layout) */
+    int cols;         /* row length of the parameter viewed as [rows, cols] */
+    int w16_dtype;    /* MICO_F16 / MICO_BF16 */
+} mico_adamw_tensor;
+
+int mico_adamw_step(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
+                    int nchunks, int chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float step_size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,71 @@ __global__ void dropout_kernel(XT* __restrict__ x, int64_t rows, int cols, int64
     }
 }
 
+// ---- multi-tensor AdamW (data/utils/build_optimizer.py:105-197) ---------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(const mico_adamw_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
+                                                    const int64_t* __restrict__ chunk_start, int chunk_elems, float lr, float beta1,
+                                                    float beta2, float eps, float wd, float step_size) {
+    const mico_adamw_tensor t = tensors[chunk_tensor[blockIdx.x]];
+    const int64_t s0 = chunk_start[blockIdx.x];
+    const int64_t s1 = min(t.numel, s0 + (int64_t)chunk_elems);
+    const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
+    auto upd = [&](float p, float g, float& m, float& v) {
+        m = m * beta1 + ob1 * g;
+        v = v * beta2 + ob2 * g * g;
+        p = p - step_size * (m / (sqrtf(v) + eps));
+        if (wd > 0.f) p = p - lr * wd * p;
+        return p;
+    };
+    auto mirror = [&](int64_t i, float p) {
+        const int64_t r = i / t.cols, c = i - r * t.cols;
+        if (t.w16_dtype == MICO_BF16) {
+            bf16* d = (bf16*)t.w16 + r * t.ld16 + c;
+            const bf16 hi = (bf16)p;
+            *d = hi;
+            if (t.lo_off > 0) d[t.lo_off] = (bf16)(p - (float)hi);
+        } else {
+            f16* d = (f16*)t.w16 + r * t.ld16 + c;
+            const f16 hi = (f16)p;
+            *d = hi;
+            if (t.lo_off > 0) d[t.lo_off] = (f16)(p - (float)hi);
+        }
+    };
+    const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0 && (s0 & 3) == 0;
+    int64_t i = s0 + (vec ? threadIdx.x * 4 : threadIdx.x);
+    if (vec) {
+        for (; i + 3 < s1; i += 256 * 4) {
+            f32x4 p = *(const f32x4*)(t.p + i), g = *(const f32x4*)(t.g + i), m = *(const f32x4*)(t.m + i), v = *(const f32x4*)(t.v + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float mk = m[k], vk = v[k];
+                p[k] = upd(p[k], g[k], mk, vk);
+                m[k] = mk; v[k] = vk;
+            }
+            *(f32x4*)(t.p + i) = p; *(f32x4*)(t.m + i) = m; *(f32x4*)(t.v + i) = v;
+            if (t.w16) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mirror(i + k, p[k]);
+            }
+        }
+        // ragged tail of the tensor (numel % 4): handled by the first threads one element each
+        const int64_t tail0 = s1 - ((s1 - s0) & 3);
+        i = tail0 + threadIdx.x;
+        if (i < s1 && i >= tail0) {
+            float mk = t.m[i], vk = t.v[i];
+            const float p = upd(t.p[i], t.g[i], mk, vk);
+            t.p[i] = p; t.m[i] = mk; t.v[i] = vk;
+            if (t.w16) mirror(i, p);
+        }
+    } else {
+        for (; i < s1; i += 256) {
+            float mk = t.m[i], vk = t.v[i];
+            const float p = upd(t.p[i], t.g[i], mk, vk);
+            t.p[i] = p; t.m[i] = mk; t.v[i] = vk;
+            if (t.w16) mirror(i, p);
+        }
+    }
+}
+
 // ---- column sums: out[c] (+)= scale * sum_r x[r,c] ----------------------------------------------------------------
 // grid (col slabs of 256, row chunks); each thread owns one column for a chunk of rows, partial sums via atomics.
 template <typename XT>
@@ -348,6 +413,19 @@ extern "C" int mico_dropout(void* x, int x_dtype, int64_t rows, int cols, int64_
     if (x_dtype == MICO_F32) MICO_LAUNCH(dropout_kernel<float>, grid, dim3(EB), 0, ST, (float*)x, rows, cols, ld, thr, ik, seed, site);
     else if (x_dtype == MICO_F16) MICO_LAUNCH(dropout_kernel<f16>, grid, dim3(EB), 0, ST, (f16*)x, rows, cols, ld, thr, ik, seed, site);
     else MICO_LAUNCH(dropout_kernel<bf16>, grid, dim3(EB), 0, ST, (bf16*)x, rows, cols, ld, thr, ik, seed, site);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_adamw_step(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
+                               int nchunks, int chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float step_size, void* stream) {
+    MICO_CHECK(tensors && chunk_tensor && chunk_start && n_tensors > 0, "mico_adamw_step: null table");
+    MICO_CHECK(chunk_elems > 0 && chunk_elems % 4 == 0, "mico_adamw_step: chunk_elems must be a positive multiple of 4");
+    MICO_CHECK(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "mico_adamw_step: bad hyper-parameters");
+    if (nchunks <= 0) return MICO_OK;
+    MICO_LAUNCH(adamw_kernel, dim3(nchunks), dim3(256), 0, ST, tensors, chunk_tensor, chunk_start, chunk_elems, lr, beta1, beta2, eps,
+                weight_decay, step_size);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -49,6 +49,8 @@ def precision(dtype):
 
 
 _W16 = {}
+_COPIES = {}      # id(param) -> {cache key: (buffer, first row, kp, split, channel_sum)}: every 16-bit copy derived from it
+_ENTRY_SRC = {}   # cache key -> ids of the parameters the entry was built from
 
 
 def w16(key, params, build):
@@ -66,6 +68,41 @@ def w16(key, params, build):
 
 def clear_weight_cache():
     _W16.clear()
+    _COPIES.clear()
+    _ENTRY_SRC.clear()
+
+
+def _live_copies(p):
+    out = []
+    for key, c in _COPIES.get(id(p), {}).items():
+        hit = _W16.get(key)
+        if key[1] == CFG.compute_dtype and hit is not None and hit[1] is c[0]:
+            out.append((key, c))
+    return out
+
+
+def weight_mirror(p):
+    """(ptr, ld, lo_off, cols, dtype code) of THE cached 16-bit copy of parameter p in the active compute dtype, for
+    mico_adamw_step to refresh in the pass that updates p - or None when p has no copy, several (the patch-embed weight:
+    3-channel and channel-summed forms) or only a transformed one."""
+    live = _live_copies(p)
+    if len(live) != 1 or live[0][1][4]:
+        return None
+    buf, row0, kp, split, _ = live[0][1]
+    ld = buf.stride(0)
+    return (buf.data_ptr() + row0 * ld * 2, ld, kp if split else 0, p.numel() // p.shape[0], ops.dt_code(buf.dtype))
+
+
+def after_optimizer_step(refreshed_ids):
+    """Called by mico_amd.optim.AdamW.step() with the ids of the parameters whose mirrors it refreshed in place.  A cache
+    entry stays valid iff every parameter it was built from was refreshed that way (raw-pointer updates do not bump tensor
+    versions, so the version check alone would keep stale copies); every other entry is dropped and rebuilt lazily.
+    A foreign optimizer that writes through `.data` (as the reference's does) must call clear_weight_cache() after its step."""
+    for key in list(_W16):
+        src = _ENTRY_SRC.get(key)
+        if src is None or not all(i in refreshed_ids for i in src):
+            del _W16[key]
+            _ENTRY_SRC.pop(key, None)
 
 
 def cast_weight(w, dt, k_pad=None, n_pad=None):
@@ -107,6 +144,12 @@ def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False):
             resid = torch.zeros((N, kp), dtype=torch.float32, device=w.device)
             resid[:, :K] = w2 - hi32[:, :K]
             ops.cast_f32_to_16(resid, out[:N, kp:], cols=kp, cols_pad=kp)
+        key = ((tag, id(plist[0]), k_pad, n_pad, split), dt)
+        r0 = 0
+        for p in plist:   # every source parameter occupies a row range of this buffer (see weight_mirror)
+            _COPIES.setdefault(id(p), {})[key] = (out, r0, kp, do_split, channel_sum)
+            r0 += p.shape[0]
+        _ENTRY_SRC[key] = [id(p) for p in plist]
         return out
 
     buf = w16((tag, id(plist[0]), k_pad, n_pad, split), plist, build)

@@ -332,6 +332,76 @@ def ckpt_fixture():
     print("wrote ckpt_remap.pt")
 
 
+def optimizer_fixture():
+    """Reference AdamW (data/utils/build_optimizer.py:105-197), its parameter grouping (:11-76) and the lr schedules
+    (data/utils/sched.py) on small seeded tensors: parameters after every step, moments after the last."""
+    import importlib.util
+    import types
+    import torch.nn as nn
+    for name, path in (("data", ref_import.REF_ROOT + "/data"), ("data.utils", ref_import.REF_ROOT + "/data/utils")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    mods = {}
+    for name in ("logger", "build_optimizer", "sched"):
+        spec = importlib.util.spec_from_file_location("data.utils." + name, ref_import.REF_ROOT + f"/data/utils/{name}.py")
+        mods[name] = importlib.util.module_from_spec(spec)
+        sys.modules["data.utils." + name] = mods[name]
+        spec.loader.exec_module(mods[name])
+    bo, sched = mods["build_optimizer"], mods["sched"]
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    shapes = [[(5, 7), (33,)], [(4, 3, 2, 2)]]
+    for cb in (True, False):
+        params = [[nn.Parameter(torch.randn(*sh, generator=g)) for sh in grp] for grp in shapes]
+        init = [[p.detach().clone() for p in grp] for grp in params]
+        opt = bo.AdamW([dict(params=params[0], weight_decay=0.01, lr=1e-3), dict(params=params[1], weight_decay=0.0, lr=5e-4)],
+                       lr=1e-3, betas=(0.9, 0.98), correct_bias=cb)
+        grads, after = [], []
+        for step in range(4):
+            gs = [[torch.randn(*sh, generator=g) for sh in grp] for grp in shapes]
+            for gi, grp in enumerate(params):
+                for pi, p in enumerate(grp):
+                    p.grad = None if (step == 1 and gi == 0 and pi == 1) else gs[gi][pi].clone()   # one parameter skips a step
+            opt.step()
+            grads.append(gs)
+            after.append([[p.detach().clone() for p in grp] for grp in params])
+        moments = [[(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone(), opt.state[p]["step"]) for p in grp] for grp in params]
+        out[f"correct_bias_{cb}"] = dict(init=init, grads=grads, after=after, moments=moments)
+    xs = [i / 40.0 for i in range(41)]
+    out["sched"] = {name: [getattr(sched, name)(x, 0.1) for x in xs] for name in ("warmup_cosine", "warmup_constant", "warmup_linear")}
+    out["sched_x"] = xs
+    o = types.SimpleNamespace(scheduler="warmup_linear", num_train_steps=200, warmup_ratio=0.05)
+    out["get_lr_sched"] = [sched.get_lr_sched(st, o) for st in range(0, 201, 10)]
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vision_encoder = nn.Module()
+            self.vision_encoder.visual = nn.Module()
+            self.vision_encoder.visual.proj = nn.Linear(3, 2)
+            self.vision_encoder.visual.LayerNorm = nn.LayerNorm(2)
+            self.multimodal_encoder = nn.Module()
+            self.multimodal_encoder.dense = nn.Linear(2, 2)
+            self.multimodal_encoder.LayerNorm = nn.LayerNorm(2)
+            self.fresh_head = nn.Linear(2, 2)
+            self.contra_temp = nn.Parameter(torch.tensor(0.07))
+
+    tiny = Tiny()
+    ED = ref_import.load().EasyDict
+    args = ED(dict(model_cfg=dict(vision_encoder_type="evaclip01_giant"),
+                   run_cfg=dict(new_params_name=["fresh_head"], weight_decay=0.01, learning_rate=1e-4, new_lr=5e-4, clip_lr=5e-7,
+                                betas=[0.9, 0.98], optim="adamw")))
+    ropt = bo.build_optimizer(tiny, args, None)
+    ids = {id(p): n for n, p in tiny.named_parameters()}
+    out["groups"] = [dict(names=[ids[id(p)] for p in gr["params"]], lr=gr["lr"], weight_decay=gr["weight_decay"], init_lr=gr["init_lr"])
+                     for gr in ropt.param_groups]
+    out["group_attrs"] = dict(new_params_name=ropt.new_params_name, clip_lr_visual_len=ropt.clip_lr_visual_len)
+    torch.save(out, os.path.join(OUT, "optimizer.pt"))
+    print("wrote optimizer.pt")
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -364,6 +434,8 @@ def main(which):
         vit_full_fixture()
     if want("ckpt"):
         ckpt_fixture()
+    if want("opt"):
+        optimizer_fixture()
 
 
 if __name__ == "__main__":

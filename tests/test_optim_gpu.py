@@ -1,0 +1,85 @@
+"""mico_adamw_step (multi-tensor, one launch per group) against the reference optimizer's own outputs (tests/golden/optimizer.pt):
+parameters after each of 4 steps (one parameter skips a step, so step counts diverge inside a group), both bias-correction
+modes, decoupled weight decay; then the in-pass refresh of the 16-bit GEMM-operand mirrors on a real model."""
+import pytest
+import torch
+import torch.nn as nn
+
+from common import build_model, golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("correct_bias", [True, False])
+def test_adamw_matches_reference(cuda, correct_bias):
+    from mico_amd.optim import AdamW
+    fx = golden("optimizer.pt")[f"correct_bias_{correct_bias}"]
+    params = [[nn.Parameter(t.clone().to(cuda)) for t in grp] for grp in fx["init"]]
+    opt = AdamW([dict(params=params[0], weight_decay=0.01, lr=1e-3), dict(params=params[1], weight_decay=0.0, lr=5e-4)],
+                lr=1e-3, betas=(0.9, 0.98), correct_bias=correct_bias)
+    for step in range(4):
+        for gi, grp in enumerate(params):
+            for pi, p in enumerate(grp):
+                p.grad = None if (step == 1 and gi == 0 and pi == 1) else fx["grads"][step][gi][pi].to(cuda)
+        opt.step()
+        for gi, grp in enumerate(params):
+            for pi, p in enumerate(grp):
+                want = fx["after"][step][gi][pi]
+                assert (p.detach().cpu() - want).abs().max() <= 2e-7 * want.abs().max().clamp_min(1.0), (step, gi, pi)
+    for gi, grp in enumerate(params):
+        for pi, p in enumerate(grp):
+            m, v, st = fx["moments"][gi][pi]
+            s = opt.state[p]
+            assert s["step"] == st
+            assert rel_err(s["exp_avg"], m) < 1e-6 and rel_err(s["exp_avg_sq"], v) < 1e-6
+    sd = opt.state_dict()     # state layout interchanges with the reference's (same keys)
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_weight_mirrors_refreshed_in_step(cuda):
+    """After AdamW.step() the cached 16-bit weights equal a fresh cast of the updated parameters (no re-cast pass), in the bf16 and
+    the split fp16 layouts; the doubly-derived patch-embed weight is rebuilt instead; a training step after the update sees the new
+    weights."""
+    from mico_amd import runtime
+    from mico_amd.optim import AdamW
+    from mico_amd.weights import synth_inputs
+    for dt in (torch.bfloat16, torch.float16):
+        runtime.clear_weight_cache()
+        m, sd = build_model("evaclip02_base", 1, device=cuda)
+        m.train()
+        opt = AdamW([dict(params=[p for p in m.parameters()], weight_decay=0.01, lr=1e-2)], lr=1e-2)
+        batch = {k: v.to(cuda) for k, v in synth_inputs(dict(b=2, vision=1, audio=1, S=8), seed=5).items()}
+        with runtime.precision(dt):
+            loss = sum(m(dict(batch), "ret%tva_cap%tva").values())
+            loss.backward()
+            before = {k: v[1].clone() for k, v in runtime._W16.items()}
+            opt.step()
+            kept = dict(runtime._W16)
+            assert len(kept) > 20, "most weight copies must survive the step through their mirrors"
+            changed = 0
+            for key, (_, buf) in kept.items():
+                src = runtime._ENTRY_SRC[key]
+                plist = [p for p in m.parameters() if id(p) in src]
+                plist.sort(key=lambda p: src.index(id(p)))
+                w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in plist], 0)
+                n, k = w.shape
+                kp = buf.shape[1] // 2 if getattr(buf, "_mico_split", False) else buf.shape[1]
+                hi = w.to(dt)
+                assert torch.equal(buf[:n, :k], hi), key
+                if getattr(buf, "_mico_split", False):
+                    assert torch.equal(buf[:n, kp:kp + k], (w - hi.float()).to(dt)), key
+                changed += int(not torch.equal(buf, before[key]))
+            assert changed > 20
+            m.zero_grad(set_to_none=True)
+            loss2 = sum(m(dict(batch), "ret%tva_cap%tva").values())
+            runtime.clear_weight_cache()
+            m.eval(); m.train()
+            # same dropout / drop-path draws are not reproduced across calls: compare in eval mode
+            m.eval()
+            with torch.no_grad():
+                a = m(dict(batch), "ret%tva", compute_loss=False)["feat_t"]
+                runtime.clear_weight_cache()
+                b = m(dict(batch), "ret%tva", compute_loss=False)["feat_t"]
+            assert torch.equal(a, b)
+            assert torch.isfinite(loss2)
+    runtime.clear_weight_cache()
