@@ -26,10 +26,22 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
-                           // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles
+                           // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles,
+                           // 6 = no epilogue
 #define MICO_GEMM_ABLATE 0
+#endif
+
+#if MICO_GEMM_ABLATE == 7   // timing build: per-workgroup phase timestamps (s_memrealtime, 100 MHz) of the 8-wave kernel
+__device__ unsigned long long g_mico_phase_times[8192 * 8];
+extern "C" int mico_debug_phase_times(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mico_phase_times), sizeof(unsigned long long) * n);
+}
+#define PHASE_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_mico_phase_times[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PHASE_STAMP(slot) do {} while (0)
 #endif
 
 namespace {
@@ -56,6 +68,7 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc;
     int ntm, ntn, ntiles, split_k, ktiles, ktiles_per_split;
     int c_dtype;
+    int stagger;                // first-round start delay per phase group in s_sleep(127) units (~4 us), 0 = none
     int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
 };
@@ -174,79 +187,127 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char
 // parks a 64x64 fp32 block of its accumulators in LDS (16 KiB, XOR-swizzled 16-byte chunks, conflict free both ways) and
 // re-reads it so that a lane owns 16 consecutive columns of one row: bias / residual / auxiliary loads and the stores are
 // then 32-64 contiguous bytes per lane, 128-256 per row - whole cache lines.  acc[0..3] is the block for 64 rows at mrow0.
+// LDS chunk swizzle of the epilogue staging image (16 chunks of 16 B per 64-column row): a 4-bit permutation found by search
+// that makes the MFMA-layout writes (8-lane groups) and both row-major read-back ownerships below conflict free.
+__device__ __forceinline__ int epi_key(int row) { return (int)((0xF615B0AC843297DEull >> ((row & 15) * 4)) & 15); }
+
 template <typename T, int MB = 4>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
-    const mico_gemm_epilogue& e = g.e;
+    // every argument field the epilogue needs, read ONCE into scalars: left as g.e.<field> references the compiler re-loaded
+    // them from the kernel-argument segment inside every pass (66 s_load_dwordx8 + waits in the unrolled code)
+    const struct {
+        const float* bias; void* aux_out; const void* aux_in; int64_t ldaux; int act; const float* row_scale; int rows_per_scale;
+        const float* resid; const float* pos; int pos_rows; int remap_group, remap_skip, remap_offset; float alpha; int accumulate;
+        const int* row_map; int rows_per_map; float drop_p; unsigned drop_seed; int drop_site;
+    } e = {g.e.bias, g.e.aux_out, g.e.aux_in, g.e.ldaux, g.e.act, g.e.row_scale, g.e.rows_per_scale, g.e.resid, g.e.pos, g.e.pos_rows,
+           g.e.remap_group, g.e.remap_skip, g.e.remap_offset, g.e.alpha, g.e.accumulate, g.e.row_map, g.e.rows_per_map,
+           g.e.drop_p, g.e.drop_seed, g.e.drop_site};
+    const int64_t gM = g.M, gN = g.N, gldc = g.ldc;
+    char* const gC = g.C;
     {
-        const int p = lane & 15, gq = lane >> 4;
+        const int p = lane & 15, gq = lane >> 4, kp = epi_key(p);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = i * 16 + p, cc = j * 4 + gq;
-                *(LDS_AS f32x4*)(wbuf + row * 256 + ((cc ^ p) << 4)) = acc[i][j] * e.alpha;
+                *(LDS_AS f32x4*)(wbuf + row * 256 + ((cc ^ kp) << 4)) = acc[i][j] * e.alpha;
             }
     }
+    // Read-back ownership: a lane owns four 4-column groups of one row, chosen so that ONE store instruction covers 64
+    // contiguous bytes per row (4 lanes x 16 B) - with the former "16 consecutive columns per lane" ownership every store
+    // instruction wrote 8- or 16-byte pieces at a 32- / 64-byte stride, i.e. each output line was written by four partial
+    // stores, and the epilogue took 18 us per 256x256 tile (26 % of the forward GEMM, tools/probes/gemm_phases.py).
+    //   fp32 output : group v = columns v*16 + q*4 .. +3          (store v: 16 B per lane)
+    //   16-bit      : groups (2u, 2u+1) = columns u*32 + q*8 .. +7 (store u: 16 B per lane)
     const int q = lane & 3;
-    const int64_t n = ncol0 + q * 16;
-    if (n >= g.N) return;
-    const int nvec = (int)min((int64_t)4, (g.N - n) >> 2);   // valid 4-column groups of this lane (N % 4 == 0)
+    const bool wide = g.c_dtype == MICO_F32;
+    int col[4];
+    bool ok[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        col[v] = wide ? (v * 16 + q * 4) : ((v >> 1) * 32 + q * 8 + (v & 1) * 4);
+        ok[v] = ncol0 + col[v] < gN;    // N % 4 == 0: a 4-column group is either fully inside or fully outside
+    }
+    if (!ok[0]) return;   // group 0 is the lane's leftmost
     f32x4 bias4[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && v < nvec) ? *(const f32x4*)(e.bias + n + v * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && ok[v]) ? *(const f32x4*)(e.bias + ncol0 + col[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // NOT unrolled: the pass body is ~1.5k instructions with every epilogue feature inlined; unrolled 4x (and twice per tile) the
+    // epilogue was ~90 KiB of straight-line code executed once per tile - far beyond the 64 KiB instruction cache shared by two
+    // CUs - and took 15 us per 256x256 tile against a 5.5 us store-bandwidth floor (tools/probes/gemm_phases.py, store_pattern.hip)
+#pragma unroll 1
     for (int pass = 0; pass < MB; ++pass) {
         const int row = pass * 16 + (lane >> 2);
         const int64_t m = mrow0 + row;
-        if (m >= g.M) continue;
+        if (m >= gM) continue;
         int64_t mo = m;
         if (e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
         else if (e.row_map) { const int64_t f = m / e.rows_per_map; mo = (int64_t)e.row_map[f] * e.rows_per_map + (m - f * e.rows_per_map); }
         float rscale = 1.f;
         if (e.row_scale) rscale = e.row_scale[(e.row_map ? mo : m) / e.rows_per_scale];
+        const int kr = epi_key(row);
         f32x4 v4[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + (((q * 4 + v) ^ (row & 15)) << 4)) + bias4[v];
-        if (e.aux_out) {
-            T* ap = (T*)e.aux_out + m * e.ldaux + n;
+        for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + ((((col[v] >> 2)) ^ kr) << 4)) + bias4[v];
+        if (e.aux_out) {   // 16-bit pre-activation copy; present only with 16-bit outputs, i.e. the paired ownership
+            T* ap = (T*)e.aux_out + m * e.ldaux + ncol0;
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (v < nvec) *(s16x4*)(ap + v * 4) = pack4<T>(v4[v][0], v4[v][1], v4[v][2], v4[v][3]);
+            for (int u = 0; u < 2; ++u) {
+                const s16x4 lo = pack4<T>(v4[2 * u][0], v4[2 * u][1], v4[2 * u][2], v4[2 * u][3]);
+                const s16x4 hi = pack4<T>(v4[2 * u + 1][0], v4[2 * u + 1][1], v4[2 * u + 1][2], v4[2 * u + 1][3]);
+                if (!wide && ok[2 * u + 1]) *(s16x8*)(ap + col[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                else {
+                    if (ok[2 * u]) *(s16x4*)(ap + col[2 * u]) = lo;
+                    if (ok[2 * u + 1]) *(s16x4*)(ap + col[2 * u + 1]) = hi;
+                }
+            }
         }
         if (e.act == MICO_ACT_GELU) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) { v4[v][0] = gelu_f(v4[v][0]); v4[v][1] = gelu_f(v4[v][1]); v4[v][2] = gelu_f(v4[v][2]); v4[v][3] = gelu_f(v4[v][3]); }
         } else if (e.act == MICO_ACT_GELU_GRAD) {
-            const T* hp = (const T*)e.aux_in + m * e.ldaux + n;
+            const T* hp = (const T*)e.aux_in + m * e.ldaux + ncol0;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (v < nvec) {
-                    const f32x4 h = unpack4<T>(*(const s16x4*)(hp + v * 4));
+                if (ok[v]) {
+                    const f32x4 h = unpack4<T>(*(const s16x4*)(hp + col[v]));
                     v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
                 }
         }
         if (e.drop_p > 0.f) {
             const unsigned thr = drop_threshold(e.drop_p);
             const float ik = 1.f / (1.f - e.drop_p);
-            const unsigned long long i0 = (unsigned long long)m * (unsigned long long)g.N + (unsigned long long)n;
+            const unsigned long long i0 = (unsigned long long)m * (unsigned long long)gN + (unsigned long long)ncol0;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v4[v][k] *= drop_mult(e.drop_seed, e.drop_site, i0 + v * 4 + k, thr, ik);
+                for (int k = 0; k < 4; ++k) v4[v][k] *= drop_mult(e.drop_seed, e.drop_site, i0 + col[v] + k, thr, ik);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            if (v >= nvec) continue;
-            f32x4 x = v4[v] * rscale;
-            if (e.pos) x += *(const f32x4*)(e.pos + (mo % e.pos_rows) * g.N + n + v * 4);
-            if (e.resid) x += *(const f32x4*)(e.resid + mo * g.ldc + n + v * 4);
-            if (g.c_dtype == MICO_F32) {
-                float* cp = (float*)g.C + mo * g.ldc + n + v * 4;
-                if (e.accumulate) *(f32x4*)cp += x;
-                else *(f32x4*)cp = x;
-            } else {
-                *(s16x4*)((T*)g.C + mo * g.ldc + n + v * 4) = pack4<T>(x[0], x[1], x[2], x[3]);
+            v4[v] *= rscale;
+            if (!ok[v]) continue;
+            if (e.pos) v4[v] += *(const f32x4*)(e.pos + (mo % e.pos_rows) * gN + ncol0 + col[v]);
+            if (e.resid) v4[v] += *(const f32x4*)(e.resid + mo * gldc + ncol0 + col[v]);
+        }
+        if (wide) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (!ok[v]) continue;
+                float* cp = (float*)gC + mo * gldc + ncol0 + col[v];
+                if (e.accumulate) *(f32x4*)cp += v4[v];
+                else *(f32x4*)cp = v4[v];
+            }
+        } else {
+            T* cp = (T*)gC + mo * gldc + ncol0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const s16x4 lo = pack4<T>(v4[2 * u][0], v4[2 * u][1], v4[2 * u][2], v4[2 * u][3]);
+                const s16x4 hi = pack4<T>(v4[2 * u + 1][0], v4[2 * u + 1][1], v4[2 * u + 1][2], v4[2 * u + 1][3]);
+                if (ok[2 * u + 1]) *(s16x8*)(cp + col[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                else if (ok[2 * u]) *(s16x4*)(cp + col[2 * u]) = lo;
             }
         }
     }
@@ -287,6 +348,16 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
     const int wrow = wm * (BM / CFG::WM), wcol = wn * 64;
 
+    // ---- start stagger: every workgroup of a multi-round launch takes the same time, so all 256 CUs would reach their
+    // epilogues together and each round would end in one synchronised 30-60 MB store burst that the terminating workgroups sit
+    // through (measured: the epilogue costs 27 % of the forward GEMM time, far more than its instructions).  The first-round
+    // workgroups therefore start in four phase groups a quarter tile-time apart; later workgroups inherit the phase of the CU
+    // slot they take over, so store drains of one group overlap the K loops of the others. ----
+    PHASE_STAMP(0);
+    if (PINGPONG && g.stagger > 0 && blockIdx.x < 256) {
+        const int ph = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // ---- workgroup -> (k-split, tile) : XCD-contiguous remap (bijective), then grouped row-panel order ----
     int bid = blockIdx.x;
     const int ks = bid / g.ntiles;
@@ -428,6 +499,7 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         };
         for (int i = 0; i < 3 && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
+        PHASE_STAMP(1);
         int bo = 0;   // ring offset of tile t (kept opaque so LDS addresses are not hoisted per buffer)
         if (grp == 0) {
             for (int t = 0; t < T_; ++t) {
@@ -455,16 +527,32 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
         }
     }
 
+    PHASE_STAMP(2);
     // ---- epilogue ----
+    if (MICO_GEMM_ABLATE == 6 && g.K > 0) {   // ablation: no epilogue at all (keep the accumulators live)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     if (g.split_k > 1) {   // split-K partials carry no bias / activation / residual (checked on the host side)
 #pragma unroll
         for (int h = 0; h < MT / 4; ++h) gemm_epilogue_atomic(g, &acc[h * 4], m0 + wrow + h * 64, n0 + wcol, lane);
     } else {
         __syncthreads();   // every wave is done with the operand tiles (and the DMA queue is empty) before LDS is reused
+        PHASE_STAMP(4);
 #pragma unroll
-        for (int h = 0; h < MT / 4; ++h)
+        for (int h = 0; h < MT / 4; ++h) {
             gemm_epilogue_block<T>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
+            if (h == 0) PHASE_STAMP(5);
+        }
     }
+    PHASE_STAMP(3);
+#if MICO_GEMM_ABLATE == 7
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_STAMP(6);
+#endif
 }
 
 // ======================================================================================================================
@@ -737,6 +825,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     MICO_CHECK(M > 0 && N > 0 && K > 0, "mico_gemm: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     MICO_CHECK(lda % 8 == 0 && ldb % 8 == 0, "mico_gemm: lda/ldb must be multiples of 8 elements (got %lld, %lld)", (long long)lda, (long long)ldb);
     MICO_CHECK(N % 4 == 0 && ldc % 4 == 0, "mico_gemm: N and ldc must be multiples of 4 (got %lld, %lld)", (long long)N, (long long)ldc);
+    if (c_dtype != MICO_F32) MICO_CHECK(ldc % 8 == 0 && ((uintptr_t)C & 15) == 0, "mico_gemm: a 16-bit C needs ldc %% 8 == 0 and a 16-byte aligned base (16-byte stores)");
+    if (epi && (epi->aux_out || epi->aux_in)) MICO_CHECK(epi->ldaux % 8 == 0, "mico_gemm: ldaux must be a multiple of 8");
     const bool segs = epi && epi->nseg > 0;
     if (!ta) MICO_CHECK(K % 8 == 0 && (segs || lda >= K), "mico_gemm: A[M,K] needs K %% 8 == 0 and lda >= K");
     else MICO_CHECK(lda >= M, "mico_gemm: A^T[K,M] needs lda >= M");
@@ -779,6 +869,13 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
     g.split_k = split_k;
+    g.stagger = 0;
+    if (big && !pc && split_k == 1 && g.ntiles >= 3 * 256) {
+        // tile time ~ 10 us + 0.9 us per 32-deep K-tile (measured); a quarter of it per phase group, in ~4 us sleep units
+        const char* env = getenv("MICO_GEMM_STAGGER");
+        const float tile_us = 10.f + 0.9f * (float)g.ktiles;
+        g.stagger = env ? atoi(env) : (int)(tile_us / 4.f / 4.f + 0.5f);
+    }
     g.ka_rows = g.kb_rows = K;
     if (g.e.nseg > 0) {
         MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % 64 == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
