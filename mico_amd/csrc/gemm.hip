@@ -26,7 +26,6 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
 
 #ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
                            // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles,
@@ -68,7 +67,6 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc;
     int ntm, ntn, ntiles, split_k, ktiles, ktiles_per_split;
     int c_dtype;
-    int stagger;                // first-round start delay per phase group in s_sleep(127) units (~4 us), 0 = none
     int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
 };
@@ -348,16 +346,7 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
     const int wrow = wm * (BM / CFG::WM), wcol = wn * 64;
 
-    // ---- start stagger: every workgroup of a multi-round launch takes the same time, so all 256 CUs would reach their
-    // epilogues together and each round would end in one synchronised 30-60 MB store burst that the terminating workgroups sit
-    // through (measured: the epilogue costs 27 % of the forward GEMM time, far more than its instructions).  The first-round
-    // workgroups therefore start in four phase groups a quarter tile-time apart; later workgroups inherit the phase of the CU
-    // slot they take over, so store drains of one group overlap the K loops of the others. ----
     PHASE_STAMP(0);
-    if (PINGPONG && g.stagger > 0 && blockIdx.x < 256) {
-        const int ph = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // ---- workgroup -> (k-split, tile) : XCD-contiguous remap (bijective), then grouped row-panel order ----
     int bid = blockIdx.x;
     const int ks = bid / g.ntiles;
@@ -768,15 +757,19 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     }
 }
 
-constexpr int pc_bk(int ta, int tb) { return (ta && tb) ? 32 : 64; }
+constexpr int pc_bk(int, int) { return 32; }
 
 template <typename T>
 void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
+    // only the weight-gradient orientation is routed here (see mico_gemm); the kernel template also covers k-contiguous operands
+    // with 64-deep K-tiles (measured slower than the 8-wave kernel on the forward / dX shapes, hence not instantiated)
     const dim3 grid(g.ntiles * g.split_k), block(Wide<32>::THREADS);
-    if (!ta && !tb) MICO_LAUNCH((gemm_pc_kernel<T, false, false, 64>), grid, block, 0, st, g);
-    else if (!ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, false, true, 64>), grid, block, 0, st, g);
-    else if (ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, true, true, 32>), grid, block, 0, st, g);
-    else MICO_LAUNCH((gemm_pc_kernel<T, true, false, 64>), grid, block, 0, st, g);
+    if (ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, true, true, 32>), grid, block, 0, st, g);
+#ifdef MICO_GEMM_PC_ALL   // experiment build: every large problem through the producer/consumer kernel (32-deep K-tiles)
+    else if (!ta && !tb) MICO_LAUNCH((gemm_pc_kernel<T, false, false, 32>), grid, block, 0, st, g);
+    else if (!ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, false, true, 32>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_pc_kernel<T, true, false, 32>), grid, block, 0, st, g);
+#endif
 }
 
 template <typename T, typename CFG>
@@ -856,7 +849,11 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // measured (tools/gemm_bench.py, ViT-g/14 shapes): the producer/consumer kernel wins for the weight-gradient orientation
     // (both operands reduction-major, long K per workgroup: 911 vs 730 TFLOP/s) and loses for the short-K forward / dX GEMMs
     // (742-866 vs 946-960), whose per-tile prologue + epilogue cost weighs more on the smaller 192x256 tile
+#ifdef MICO_GEMM_PC_ALL
+    const bool pc = big;
+#else
     const bool pc = big && ta && tb;
+#endif
 #endif
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = big ? 256 : 128;
     const int slots = big ? 256 : 512;
@@ -869,13 +866,6 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
     g.split_k = split_k;
-    g.stagger = 0;
-    if (big && !pc && split_k == 1 && g.ntiles >= 3 * 256) {
-        // tile time ~ 10 us + 0.9 us per 32-deep K-tile (measured); a quarter of it per phase group, in ~4 us sleep units
-        const char* env = getenv("MICO_GEMM_STAGGER");
-        const float tile_us = 10.f + 0.9f * (float)g.ktiles;
-        g.stagger = env ? atoi(env) : (int)(tile_us / 4.f / 4.f + 0.5f);
-    }
     g.ka_rows = g.kb_rows = K;
     if (g.e.nseg > 0) {
         MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % 64 == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
