@@ -246,6 +246,21 @@ int mico_l2norm_fwd(const float* x, float* y, float* inv_norm, int64_t rows, int
 int mico_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int64_t rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Device-side input preprocessing.
+ *  mico_image_preprocess: n decoded RGB frames, uint8 [n, H, W, 3]  ->  fp32 [n, 3, out_h, out_w]:
+ *     ToTensor (/255), Resize((out_h, out_w)) bilinear without antialias (source index (d + 0.5) * in/out - 0.5 clamped at 0,
+ *     as torch's upsample_bilinear2d with align_corners = False), Normalize(mean, std)   - model/imageprocessor.py:26-38,51-55,
+ *     model/videoprocessor.py:35-50.
+ *  mico_fbank_windows: log-mel filterbank [T, mel] fp32 -> n windows [n, target_len, mel]:
+ *     out[i, t, :] = (fbank[win[i] * target_len + t, :] - mean) * inv_scale, zero past T  (normalise, zero-pad, slice:
+ *     model/audioprocessor.py:45-70; inv_scale = 1 / (2 std)).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_image_preprocess(const unsigned char* src, int n, int H, int W, float* dst, int out_h, int out_w,
+                          float mean0, float mean1, float mean2, float istd0, float istd1, float istd2, void* stream);
+int mico_fbank_windows(const float* fbank, int T, int mel, const int* win, int n, int target_len, float mean, float inv_scale,
+                       float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Optimizer step: the decoupled-weight-decay Adam of data/utils/build_optimizer.py:105-197,
  * one launch for a whole parameter group (multi-tensor).  Per element, in this order (fp32):
  *     m = beta1 m + (1 - beta1) g;   v = beta2 v + (1 - beta2) g g;   p -= step_size * m / (sqrt(v) + eps);

@@ -77,6 +77,42 @@ __global__ void dropout_kernel(XT* __restrict__ x, int64_t rows, int cols, int64
     }
 }
 
+// ---- device-side input preprocessing ----------------------------------------------------------------------------------
+__global__ void image_preprocess_kernel(const unsigned char* __restrict__ src, int n, int H, int W, float* __restrict__ dst, int oh,
+                                        int ow, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int64_t total = (int64_t)n * oh * ow;
+    const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int x = (int)(i % ow), y = (int)((i / ow) % oh), f = (int)(i / ((int64_t)ow * oh));
+        float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const unsigned char* b = src + (int64_t)f * H * W * 3;
+        const unsigned char *p00 = b + ((int64_t)y0 * W + x0) * 3, *p01 = b + ((int64_t)y0 * W + x1) * 3;
+        const unsigned char *p10 = b + ((int64_t)y1 * W + x0) * 3, *p11 = b + ((int64_t)y1 * W + x1) * 3;
+        const float mean[3] = {m0, m1, m2}, istd[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float k = 1.f / 255.f;
+            const float v = hy * (hx * (p00[c] * k) + lx * (p01[c] * k)) + ly * (hx * (p10[c] * k) + lx * (p11[c] * k));
+            dst[(((int64_t)f * 3 + c) * oh + y) * ow + x] = (v - mean[c]) * istd[c];
+        }
+    }
+}
+
+__global__ void fbank_windows_kernel(const float* __restrict__ fbank, int T, int mel, const int* __restrict__ win, int n, int tl,
+                                     float mean, float inv, float* __restrict__ out) {
+    const int64_t total = (int64_t)n * tl * mel;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int m = (int)(i % mel), t = (int)((i / mel) % tl), w = (int)(i / ((int64_t)mel * tl));
+        const int64_t row = (int64_t)win[w] * tl + t;
+        out[i] = row < T ? (fbank[row * mel + m] - mean) * inv : 0.f;
+    }
+}
+
 // ---- multi-tensor AdamW (data/utils/build_optimizer.py:105-197) ---------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(const mico_adamw_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
                                                     const int64_t* __restrict__ chunk_start, int chunk_elems, float lr, float beta1,
@@ -413,6 +449,24 @@ extern "C" int mico_dropout(void* x, int x_dtype, int64_t rows, int cols, int64_
     if (x_dtype == MICO_F32) MICO_LAUNCH(dropout_kernel<float>, grid, dim3(EB), 0, ST, (float*)x, rows, cols, ld, thr, ik, seed, site);
     else if (x_dtype == MICO_F16) MICO_LAUNCH(dropout_kernel<f16>, grid, dim3(EB), 0, ST, (f16*)x, rows, cols, ld, thr, ik, seed, site);
     else MICO_LAUNCH(dropout_kernel<bf16>, grid, dim3(EB), 0, ST, (bf16*)x, rows, cols, ld, thr, ik, seed, site);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_image_preprocess(const unsigned char* src, int n, int H, int W, float* dst, int out_h, int out_w, float mean0,
+                                     float mean1, float mean2, float istd0, float istd1, float istd2, void* stream) {
+    MICO_CHECK(src && dst && n > 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0, "mico_image_preprocess: bad args");
+    MICO_LAUNCH(image_preprocess_kernel, dim3(egrid((int64_t)n * out_h * out_w)), dim3(EB), 0, ST, src, n, H, W, dst, out_h, out_w,
+                mean0, mean1, mean2, istd0, istd1, istd2);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_fbank_windows(const float* fbank, int T, int mel, const int* win, int n, int target_len, float mean,
+                                  float inv_scale, float* out, void* stream) {
+    MICO_CHECK(fbank && win && out && T > 0 && mel > 0 && n > 0 && target_len > 0, "mico_fbank_windows: bad args");
+    MICO_LAUNCH(fbank_windows_kernel, dim3(egrid((int64_t)n * target_len * mel)), dim3(EB), 0, ST, fbank, T, mel, win, n, target_len, mean,
+                inv_scale, out);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -11,17 +11,22 @@ import torch
 import torch.nn.functional as F
 
 
+def image_stats(encoder_type):
+    """imageprocessor.py:17-22 / videoprocessor.py:27-33: CLIP statistics for clip* / evaclip*, ImageNet otherwise."""
+    if encoder_type.startswith("clip") or encoder_type.startswith("evaclip"):
+        return [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    return [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
 class ImageProcessor(object):
-    def __init__(self, image_resolution, image_encoder_type, image_transforms="none", training=True):
+    def __init__(self, image_resolution, image_encoder_type, image_transforms="none", training=True, device=None):
+        """device=None: host path (torch ops); device="cuda": decode on the host, then ToTensor + Resize + Normalize in one
+        device kernel (mico_image_preprocess) - the returned tensor already lives on the device."""
         self.training = training
         self.resolution = image_resolution
         self.image_encoder_type = image_encoder_type
-        if image_encoder_type.startswith("clip") or image_encoder_type.startswith("evaclip"):
-            self.mean = [0.48145466, 0.4578275, 0.40821073]
-            self.std = [0.26862954, 0.26130258, 0.27577711]
-        else:
-            self.mean = [0.485, 0.456, 0.406]
-            self.std = [0.229, 0.224, 0.225]
+        self.device = device
+        self.mean, self.std = image_stats(image_encoder_type)
         if image_transforms != "none":
             raise NotImplementedError(image_transforms)
         self.image_transforms = image_transforms
@@ -41,8 +46,11 @@ class ImageProcessor(object):
                 return None
             from PIL import Image
             img = Image.open(image_file).convert("RGB")
-            img = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
-            return self.transform(img).unsqueeze(0)
+            u8 = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+            if self.device is not None:
+                from .videoprocessor import preprocess_frames_device
+                return preprocess_frames_device(u8.unsqueeze(0), self.resolution, self.mean, self.std, self.device)
+            return self.transform(u8.permute(2, 0, 1).float().div(255.0)).unsqueeze(0)
         except Exception as e:   # the reference swallows errors and returns None (imageprocessor.py:61-63)
             print(e)
             return None

@@ -402,6 +402,39 @@ def optimizer_fixture():
     print("wrote optimizer.pt")
 
 
+def processor_fixture():
+    """Reference pre-processing logic that is its own code (not torchvision / torchaudio / decord arithmetic): `split`, the
+    evaluation-mode frame / window choice, and everything AudioProcessor.__call__ does after the Kaldi filterbank (normalise,
+    zero-pad, cut and pick windows; model/audioprocessor.py:45-70).  torchaudio is absent here, so its three entry points are
+    stand-ins that hand a seeded filterbank to the reference code: the captured arithmetic is the reference's own."""
+    import importlib.util
+    import tempfile
+    import types
+    ta = types.ModuleType("torchaudio")
+    state = {}
+    ta.load = lambda f: (state["wave"], 16000)
+    ta.transforms = types.SimpleNamespace(Resample=lambda a, b: (lambda w: w))
+    ta.compliance = types.SimpleNamespace(kaldi=types.SimpleNamespace(fbank=lambda w, **k: state["fbank"]))
+    sys.modules["torchaudio"] = ta
+    spec = importlib.util.spec_from_file_location("ref_audioprocessor", ref_import.REF_ROOT + "/model/audioprocessor.py")
+    ap = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ap)
+    out = {"split": {}, "audio": []}
+    for n, k in ((10, 4), (3, 4), (17, 8), (8, 8), (1, 3), (23, 5)):
+        out["split"][(n, k)] = ap.split(list(range(n)), k)
+    g = torch.Generator().manual_seed(31)
+    wav = tempfile.NamedTemporaryFile(suffix=".wav")
+    for T, mel, tl, sn in ((998, 32, 224, 4), (150, 32, 224, 4), (1300, 16, 224, 3), (448, 16, 224, 2)):
+        fb = torch.randn(T, mel, generator=g) * 6.0 + 15.0
+        state["wave"], state["fbank"] = torch.zeros(1, 16), fb
+        proc = ap.AudioProcessor(melbins=mel, target_length=tl, sample_num=sn, resize_melbin_num=mel, training=False)
+        res = proc(wav.name)
+        out["audio"].append(dict(fbank=fb, melbins=mel, target_length=tl, sample_num=sn, out=res.clone()))
+    del sys.modules["torchaudio"]
+    torch.save(out, os.path.join(OUT, "processors.pt"))
+    print("wrote processors.pt")
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -436,6 +469,8 @@ def main(which):
         ckpt_fixture()
     if want("opt"):
         optimizer_fixture()
+    if want("proc"):
+        processor_fixture()
 
 
 if __name__ == "__main__":
