@@ -81,3 +81,33 @@ def test_full_size_config(cuda, name, vtype, cfg, task, conds, nsub):
         loss_e = m2(b2, "ret%" + st)["loss_itc"]
     assert abs(float(loss_e) - float(itc_host)) < 2e-3 * float(itc_host)
     print(name, {k: float(v) for k, v in out.items()}, "itc(eval)", float(loss_e), float(itc_host))
+
+
+def test_config5_video_caption_step(cuda):
+    """configs[4] shapes on one rank: video branch (8 frames of 224^2 per sample, b = 32 -> 256 ViT-g/14 frames) + the BERT
+    cross-attention generative head (CAP: causal masked-token LM over E = 8 * 257 condition tokens).  BASELINE quotes this
+    configuration for fp8 MFMA; the engine's 16-bit path is what exists, so the step runs in bf16 (disclosed in DESIGN.md) and the
+    condition tensor of the first sample is checked against the fp32 oracle in the fp16 parity configuration."""
+    torch.set_num_threads(32)
+    m, sd = build_model("evaclip01_giant", None, device=cuda)
+    inp = synth_inputs(dict(b=32, vision=8, S=77), seed=777)
+    dev_inp = {k: v.to(cuda) for k, v in inp.items()}
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    with torch.no_grad():
+        ref_enc = O.encode_batch(sdo, O.ARCHS["evaclip01_giant"], {k: v[:1] for k, v in inp.items()})
+    with runtime.precision(torch.float16), torch.no_grad():
+        enc = m.encode_batch({k: v[:1].contiguous() for k, v in dev_inp.items()})
+        assert rel_err(m._condition_feats(enc, "v"), O.condition_feats(ref_enc, "v")) < 1e-3
+    m.train()
+    with runtime.precision(torch.bfloat16):
+        m.zero_grad(set_to_none=True)
+        out = m(dict(dev_inp), "cap%tv")
+        assert set(out) == {"loss_cap"} and torch.isfinite(out["loss_cap"])
+        assert abs(float(out["loss_cap"]) - 10.33) < 0.6          # ~ ln(30522) for an untrained LM head
+        out["loss_cap"].backward()
+    touched = [n for n, p in m.named_parameters() if p.grad is not None]
+    assert any("crossattention" in n for n in touched) and any("vision_encoder" in n for n in touched)
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
