@@ -125,7 +125,7 @@ __device__ __forceinline__ float mask_val(const float* mask, int mode, int b, in
 // ======================================================================================================================
 // forward
 // ======================================================================================================================
-template <typename T, int HDP>
+template <typename T, int HDP, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, T* __restrict__ o,
                                                           float* __restrict__ lse, const mico_attn_params p) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
                 s[tn][r] = e;
                 lloc += e;
             }
-        if (p.drop_p > 0.f) {   // dropout on the probabilities: the row sum above stays the undropped one
+        if (DROP) {   // dropout on the probabilities (compile-time variant: the ViT towers never pay its registers): the row sum above stays the undropped one
             const unsigned thr = drop_threshold(p.drop_p);
             const float ik = 1.f / (1.f - p.drop_p);
             const unsigned long long rowbase = (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 // ======================================================================================================================
 // backward, kernel 1: dQ (and delta = rowsum(dO * O)) - one workgroup per 64-query block, loops over key tiles
 // ======================================================================================================================
-template <typename T, int HDP>
+template <typename T, int HDP, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                              const T* __restrict__ v, const T* __restrict__ o,
                                                              const T* __restrict__ d_o, const float* __restrict__ lse,
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
                     if (p.mask_mode) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk);
                     const float pr = __expf(x - lse_i);
                     float dpe = dp[tn][r];
-                    if (p.drop_p > 0.f)
+                    if (DROP)
                         dpe *= drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
                                          drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
                     ds = pr * (dpe - dl) * p.scale;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
 // ======================================================================================================================
 // backward, kernel 2: dK, dV - one workgroup per 64-key block, loops over query tiles
 // ======================================================================================================================
-template <typename T, int HDP>
+template <typename T, int HDP, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                               const T* __restrict__ v, const T* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
                     if (p.mask_mode) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk);
                     pv = __expf(x - lv[r]);
                     float dm = 1.f;
-                    if (p.drop_p > 0.f)
+                    if (DROP)
                         dm = drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
                                        drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
                     ds = pv * (dp[ti][r] * dm - dv4[r]) * p.scale;
@@ -497,7 +497,7 @@ extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (rc) return rc;
     const dim3 grid((p->Sq + 63) / 64, p->H, p->B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, MICO_LAUNCH((attn_fwd_kernel<T, HDP>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p)));
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_fwd_kernel<T, HDP, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p); else MICO_LAUNCH((attn_fwd_kernel<T, HDP, false>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p); }));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
@@ -511,9 +511,9 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     hipStream_t st = (hipStream_t)stream;
     const dim3 block(256);
     const dim3 gq((p->Sq + 63) / 64, p->H, p->B), gk((p->Sk + 63) / 64, p->H, p->B);
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p)));
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP, true>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p); else MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP, false>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p); }));
     MICO_LAUNCH_CHECK();
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p)));
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP, true>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p); else MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP, false>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p); }));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
