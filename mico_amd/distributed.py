@@ -181,15 +181,32 @@ class GradBucketReducer:
         for bi, bucket in enumerate(self.buckets):
             for p in bucket:
                 self._where[p] = bi
+        self._early = set()          # ids of parameters whose gradient was already reduced inside a backward (arena slices)
+        self._early_handles = []
         if is_dist():
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+            from . import runtime
+            runtime.set_grad_slice_hook(self._reduce_slice)
         self.reset()
+
+    def _reduce_slice(self, flat, params):
+        """runtime.grad_slice_hook: `flat` is the final gradient of `params` (one contiguous arena slice, e.g. a ViT block):
+        all-reduce it in place right away - no bucket copy, and it overlaps with the backward of the earlier blocks."""
+        if _nccl():
+            h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
+            self._early_handles.append((h, None, flat))
+        else:
+            h = dist.all_reduce(flat, async_op=True)
+            self._early_handles.append((h, flat, flat))
+        self._early.update(id(p) for p in params)
 
     def reset(self):
         self._pending = {bi: len(b) for bi, b in enumerate(self.buckets)}
         self._launched = set()
         self._handles = []
+        self._early = set()
+        self._early_handles = []
 
     def _hook(self, p):
         bi = self._where[p]
@@ -199,7 +216,7 @@ class GradBucketReducer:
 
     def _launch(self, bi):
         self._launched.add(bi)
-        grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
+        grads = [p.grad for p in self.buckets[bi] if p.grad is not None and id(p) not in self._early]
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
@@ -215,6 +232,10 @@ class GradBucketReducer:
             for bi in range(len(self.buckets)):
                 if bi not in self._launched:
                     self._launch(bi)
+        for h, flat, _keep in self._early_handles:
+            h.wait()
+            if flat is not None:     # gloo has no AVG: sum, then scale
+                flat.div_(W)
         for h, flat, grads in self._handles:
             h.wait()
             flat.div_(W)

@@ -55,6 +55,13 @@ class GradArena:
             self.views[i] = self.flat[o:o + numel].view(self.shapes[i])
         return self.views[i]
 
+    def span(self, i0, i1):
+        """flat slice covering parameters i0 .. i1-1 (every one of them gets a view)."""
+        for i in range(i0, i1):
+            self.get(i)
+        end = self.offsets[i1] if i1 < len(self.offsets) else self.flat.numel()
+        return self.flat[self.offsets[i0]:end]
+
     def result(self):
         return tuple(self.views)
 
@@ -88,6 +95,31 @@ class TowerSpec:
         self.rope = rope   # (cos, sin) fp32 [np, hd] device tensors or None
         self.kpad3 = (3 * self.P * self.P + 63) // 64 * 64
         self.kpad1 = (self.P * self.P + 63) // 64 * 64
+        self._ranges = None
+
+    def block_param_ranges(self):
+        """{block index: (first, last + 1) position in `names`} - a block's parameters are contiguous in registration order."""
+        if self._ranges is None:
+            r = {}
+            for k, n in enumerate(self.names):
+                if n.startswith("blocks."):
+                    b = int(n.split(".")[1])
+                    lo, hi = r.get(b, (k, k))
+                    assert hi == k, "block parameters are expected to be contiguous"
+                    r[b] = (lo, k + 1)
+            self._ranges = r
+        return self._ranges
+
+    def non_block_param_ranges(self):
+        br = sorted(self.block_param_ranges().values())
+        out, prev = [], 0
+        for lo, hi in br:
+            if lo > prev:
+                out.append((prev, lo))
+            prev = hi
+        if prev < len(self.names):
+            out.append((prev, len(self.names)))
+        return out
 
 
 def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None):
@@ -278,8 +310,11 @@ def _tower_forward(spec, groups, dp_scale, params, save):
     return out.view(Bf, N, D), saved
 
 
-def _tower_backward(spec, params, saved, dout, grads):
-    """Backward of one _tower_forward(save=True) pass; parameter gradients are accumulated into the shared `grads` list."""
+def _tower_backward(spec, params, saved, dout, grads, final=True):
+    """Backward of one _tower_forward(save=True) pass; parameter gradients are accumulated into the shared `grads` arena.
+    final: no later pass adds to these gradients (last chunk) - finished blocks are then announced to runtime.grad_slice_hook."""
+    hook = runtime.grad_slice_hook() if final else None
+    block_range = spec.block_param_ranges()
     dt = saved["dt"]
     P = lambda n: params[spec.idx[n]]
     dev = dout.device
@@ -391,6 +426,9 @@ def _tower_backward(spec, params, saved, dout, grads):
                               rows_per_frame=N)
             del dqkv, dao, dln1, g16
         del a
+        if hook is not None:      # every gradient of block i is final: its arena slice can be reduced now
+            i0, i1 = block_range[i]
+            hook(grads.span(i0, i1), params[i0:i1])
     # ---------------- patch embedding ----------------
     dpos = torch.zeros(N * D, dtype=torch.float32, device=dev)
     ops.colsum(g, dpos, rows=Bf, cols=N * D, ld=N * D)
@@ -412,6 +450,9 @@ def _tower_backward(spec, params, saved, dout, grads):
         ops.colsum(gp16, G("patch_embed.proj.bias"), scale=inv_s, accumulate=True)
         f0 += nf
     saved["saved_rows"] = None
+    if hook is not None:              # what is left: embeddings, cls / pos, final norm (before and after the block parameters)
+        for i0, i1 in spec.non_block_param_ranges():
+            hook(grads.span(i0, i1), params[i0:i1])
 
 
 def _slice_groups(groups, c0, c1):
@@ -480,7 +521,7 @@ class EvaTowerFn(torch.autograd.Function):
                 c1 = min(Bf, c0 + chunk)
                 sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
                 _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True)
-                _tower_backward(spec, params, saved, dout[c0:c1], grads)
+                _tower_backward(spec, params, saved, dout[c0:c1], grads, final=(c1 == Bf))
                 del saved
         return (None, None, None) + grads.result()
 

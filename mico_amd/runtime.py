@@ -170,3 +170,18 @@ def tower_chunk_override():
 def set_tower_chunk(frames):
     global _tower_chunk
     _tower_chunk = int(frames) if frames else None
+
+
+_grad_slice_hook = None
+
+
+def set_grad_slice_hook(fn):
+    """fn(flat_slice, params) or None.  The ViT tower's backward calls it with a contiguous slice of its gradient arena as soon as
+    the gradients of a block are final, long before autograd hands the (views of the) gradients to the parameters: the
+    data-parallel reducer starts that block's all-reduce there, overlapped with the rest of the backward."""
+    global _grad_slice_hook
+    _grad_slice_hook = fn
+
+
+def grad_slice_hook():
+    return _grad_slice_hook

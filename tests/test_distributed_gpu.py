@@ -37,7 +37,9 @@ def _worker(rank, world, port, ret):
         b = 3
         inputs = [synth_inputs(dict(b=b, vision=1, audio=1, S=12), seed=50 + r) for r in range(world)]
         mine = {k: v.to(dev) for k, v in inputs[rank].items()}
-        red = GradBucketReducer(m.parameters(), bucket_bytes=64 << 20)
+        probe = {"tower block": m.vision_encoder.visual.blocks[1].attn.proj.weight,
+                 "tower tail": m.vision_encoder.visual.patch_embed.proj.bias,
+                 "bert": m.multimodal_encoder.bert.encoder.layer[3].output.dense.weight, "head": m.contra_head_va.weight}
         # fixed negatives (global indices) and token masks so both evaluations draw the same "random" numbers
         inj = {"tva": dict(neg_cond_idx=torch.tensor([(rank * b + i + 1) % (world * b) for i in range(b)]),
                            neg_text_idx=torch.tensor([(rank * b + i + 2) % (world * b) for i in range(b)]))}
@@ -47,11 +49,24 @@ def _worker(rank, world, port, ret):
         inj["cap"] = dict(masked_ids=mi, labels=lab)
         batch = dict(mine)
         batch["_injected"] = inj
+        # pass 1 without the reducer: this rank's own gradients (the model is in eval mode: the step is deterministic)
+        m.zero_grad(set_to_none=True)
+        sum(m(dict(batch), "ret%tva_cap%tva").values()).backward()
+        local = {k: p.grad.detach().float().clone() for k, p in probe.items()}
+        # pass 2 with it: tower blocks are all-reduced from inside the tower backward (arena slices), the rest through buckets
+        red = GradBucketReducer(m.parameters(), bucket_bytes=64 << 20)
         m.zero_grad(set_to_none=True)
         out = m(batch, "ret%tva_cap%tva")
         sum(out.values()).backward()
+        assert len(red._early) > 10, "the tower's blocks must have been reduced through the arena-slice hook"
         red.finish()
         torch.cuda.synchronize()
+        for k, p in probe.items():
+            both = [torch.empty_like(local[k]) for _ in range(world)]
+            dist.all_gather(both, local[k])
+            mean = (both[0] + both[1]) / 2
+            err = (p.grad.float() - mean).abs().max() / mean.abs().max().clamp_min(1e-20)
+            assert err < 1e-5, (k, float(err))
         res = {k: float(v) for k, v in out.items()}
         g = m.contra_head_va.weight.grad.detach().float().cpu().clone()
         g2 = m.vision_encoder.visual.blocks[0].mlp.w1.weight.grad.detach().float().cpu().clone()
