@@ -88,7 +88,7 @@ class AdamW(torch.optim.Optimizer):
                     mir = runtime.weight_mirror(p)
                     if mir is not None:
                         d.w16, d.ld16, d.lo_off, d.cols, d.w16_dtype = mir
-                        refreshed.add(id(p))
+                        refreshed.add(runtime.param_uid(p))
                     else:
                         d.w16, d.ld16, d.lo_off, d.cols, d.w16_dtype = None, 0, 0, 1, 0
                 table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)

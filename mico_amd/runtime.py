@@ -6,6 +6,7 @@ compatible with the reference); a 16-bit copy of every GEMM weight is (re)materi
 version counter changes, i.e. once per optimiser step.
 """
 import contextlib
+import weakref
 
 import torch
 
@@ -48,6 +49,20 @@ def precision(dtype):
         CFG.compute_dtype = old
 
 
+_UID = [0]
+
+
+def param_uid(p):
+    """Process-unique id of a parameter OBJECT (stored on it).  id(p) / data_ptr / _version can all repeat once a model has been
+    freed and another allocated - a cache keyed on them could hand a new model the previous model's 16-bit weights."""
+    u = getattr(p, "_mico_uid", None)
+    if u is None:
+        _UID[0] += 1
+        u = _UID[0]
+        p._mico_uid = u
+    return u
+
+
 _W16 = {}
 _COPIES = {}      # id(param) -> {cache key: (buffer, first row, kp, split, channel_sum)}: every 16-bit copy derived from it
 _ENTRY_SRC = {}   # cache key -> ids of the parameters the entry was built from
@@ -56,25 +71,47 @@ _ENTRY_SRC = {}   # cache key -> ids of the parameters the entry was built from
 def w16(key, params, build):
     """16-bit derived weight, cached on (key, dtype) and invalidated by the source parameters' version counters."""
     dt = CFG.compute_dtype
-    ver = tuple((p.data_ptr(), p._version) for p in params)
+    ver = tuple((param_uid(p), p.data_ptr(), p._version) for p in params)
     hit = _W16.get((key, dt))
     if hit is not None and hit[0] == ver:
         return hit[1]
+    _prune_dead()
     with torch.no_grad():
         t = build(dt)
     _W16[(key, dt)] = (ver, t)
+    _ENTRY_REFS[(key, dt)] = [weakref.ref(p) for p in params]
     return t
+
+
+_ENTRY_REFS = {}
+
+
+def _prune_dead():
+    """drop the cached copies of parameters that no longer exist (a freed model would otherwise pin GBs of 16-bit weights)"""
+    dead = [k for k, refs in _ENTRY_REFS.items() if any(r() is None for r in refs)]
+    for k in dead:
+        _W16.pop(k, None)
+        _ENTRY_REFS.pop(k, None)
+        _ENTRY_SRC.pop(k, None)
+    if dead:
+        gone = set(dead)
+        for uid in list(_COPIES):
+            for k in [k for k in _COPIES[uid] if k in gone]:
+                del _COPIES[uid][k]
+            if not _COPIES[uid]:
+                del _COPIES[uid]
 
 
 def clear_weight_cache():
     _W16.clear()
     _COPIES.clear()
     _ENTRY_SRC.clear()
+    _ENTRY_REFS.clear()
 
 
 def _live_copies(p):
     out = []
-    for key, c in _COPIES.get(id(p), {}).items():
+    for key, c in _COPIES.get(param_uid(p), {}).items():
         hit = _W16.get(key)
         if key[1] == CFG.compute_dtype and hit is not None and hit[1] is c[0]:
             out.append((key, c))
@@ -103,6 +140,7 @@ def after_optimizer_step(refreshed_ids):
         if src is None or not all(i in refreshed_ids for i in src):
             del _W16[key]
             _ENTRY_SRC.pop(key, None)
+            _ENTRY_REFS.pop(key, None)
 
 
 def cast_weight(w, dt, k_pad=None, n_pad=None):
@@ -144,15 +182,15 @@ def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False):
             resid = torch.zeros((N, kp), dtype=torch.float32, device=w.device)
             resid[:, :K] = w2 - hi32[:, :K]
             ops.cast_f32_to_16(resid, out[:N, kp:], cols=kp, cols_pad=kp)
-        key = ((tag, id(plist[0]), k_pad, n_pad, split), dt)
+        key = ((tag, param_uid(plist[0]), k_pad, n_pad, split), dt)
         r0 = 0
         for p in plist:   # every source parameter occupies a row range of this buffer (see weight_mirror)
-            _COPIES.setdefault(id(p), {})[key] = (out, r0, kp, do_split, channel_sum)
+            _COPIES.setdefault(param_uid(p), {})[key] = (out, r0, kp, do_split, channel_sum)
             r0 += p.shape[0]
-        _ENTRY_SRC[key] = [id(p) for p in plist]
+        _ENTRY_SRC[key] = [param_uid(p) for p in plist]
         return out
 
-    buf = w16((tag, id(plist[0]), k_pad, n_pad, split), plist, build)
+    buf = w16((tag, param_uid(plist[0]), k_pad, n_pad, split), plist, build)
     if getattr(buf, "_mico_split", False):
         kp = buf.shape[1] // 2
         return buf[:, :kp], (kp, [0, 0], [0, kp])

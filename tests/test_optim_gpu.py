@@ -59,8 +59,8 @@ def test_weight_mirrors_refreshed_in_step(cuda):
             changed = 0
             for key, (_, buf) in kept.items():
                 src = runtime._ENTRY_SRC[key]
-                plist = [p for p in m.parameters() if id(p) in src]
-                plist.sort(key=lambda p: src.index(id(p)))
+                plist = [p for p in m.parameters() if runtime.param_uid(p) in src]
+                plist.sort(key=lambda p: src.index(runtime.param_uid(p)))
                 w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in plist], 0)
                 n, k = w.shape
                 kp = buf.shape[1] // 2 if getattr(buf, "_mico_split", False) else buf.shape[1]
