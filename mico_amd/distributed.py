@@ -193,6 +193,8 @@ class GradBucketReducer:
     def _reduce_slice(self, flat, params):
         """runtime.grad_slice_hook: `flat` is the final gradient of `params` (one contiguous arena slice, e.g. a ViT block):
         all-reduce it in place right away - no bucket copy, and it overlaps with the backward of the earlier blocks."""
+        if not is_dist():     # the process group is gone (a reducer outliving its group): nothing to reduce
+            return
         if _nccl():
             h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
             self._early_handles.append((h, None, flat))
