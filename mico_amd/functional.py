@@ -771,7 +771,12 @@ SITE_SELF_OUT, SITE_CROSS_OUT, SITE_FFN_OUT, SITE_SELF_P, SITE_CROSS_P, SITE_EMB
 class BertFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, input_ids, add_mask, cond, drop, *params):
-        """drop: None (eval) or (p_hidden, p_attention, seed) - train-mode dropout of bert.py:148,267,295,373."""
+        """drop: None (eval), (p_hidden, p_attention, seed) - train-mode dropout of bert.py:148,267,295,373 - or a dict
+        {"kv_cache": {...}} (inference only): the per-layer cross-attention K/V projections of `cond` are stored in / taken from
+        that dict, so a decode loop projects its (constant) condition tokens once instead of at every step."""
+        kv_cache = None
+        if isinstance(drop, dict):
+            kv_cache, drop = drop["kv_cache"], None
         dt = runtime.compute_dtype()
         ph, pa, dseed = drop if drop is not None else (0.0, 0.0, 0)
         hd_drop = (lambda site: (ph, dseed, site)) if ph > 0 else (lambda site: None)
@@ -833,9 +838,13 @@ class BertFn(torch.autograd.Function):
                 a["x16a"] = x16[:, :D]
                 q = _empty((rows, D), dt, dev)
                 _fwd_gemm(x16, "w1", [P(ca + "query.weight")], q, bias=P(ca + "query.bias"))
-                bkv = torch.cat((P(ca + "key.bias").detach(), P(ca + "value.bias").detach()))
-                kv = _empty((b * E, 2 * D), dt, dev)
-                _fwd_gemm(cond16, "bkv", [P(ca + "key.weight"), P(ca + "value.weight")], kv, bias=bkv)
+                kv = kv_cache.get(li) if kv_cache is not None else None
+                if kv is None or kv.shape[0] != b * E:
+                    bkv = torch.cat((P(ca + "key.bias").detach(), P(ca + "value.bias").detach()))
+                    kv = _empty((b * E, 2 * D), dt, dev)
+                    _fwd_gemm(cond16, "bkv", [P(ca + "key.weight"), P(ca + "value.weight")], kv, bias=bkv)
+                    if kv_cache is not None:
+                        kv_cache[li] = kv
                 cc = _empty((rows, D), dt, dev)
                 lse_c = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))

@@ -103,7 +103,9 @@ class BertModel(nn.Module):
                                      self.config["hidden_size"], self.config["intermediate_size"], self.config["layer_norm_eps"])
         return self._spec, [p for _, p in named]
 
-    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, **_):
+    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, kv_cache=None, **_):
+        """kv_cache (dict, inference only): holds the cross-attention K/V projections of `encoder_hidden_states` across calls -
+        the caller guarantees the condition tokens do not change between the calls that share the dict."""
         if input_ids is None:
             raise ValueError("You have to specify input_ids")
         if attention_mask is None:
@@ -115,6 +117,10 @@ class BertModel(nn.Module):
             # nn.Dropout sites of bert.py:148,267,295,373: masks come from a counter hash of (seed, site, element), one seed per pass
             seed = self.dropout_seed_source() if self.dropout_seed_source is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)))
             drop = (float(ph), float(pa), int(seed))
+        if kv_cache is not None:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                raise RuntimeError("kv_cache is an inference feature: call under torch.no_grad()")
+            drop = {"kv_cache": kv_cache}
         seq = Fn.BertFn.apply(spec, input_ids, extended_attention_mask(attention_mask), encoder_hidden_states, drop, *params)
         return _Out(last_hidden_state=seq)
 
@@ -225,11 +231,12 @@ class BertForMaskedLM(nn.Module):
                 "encoder_hidden_states": encoder_hidden_states}
 
     @torch.no_grad()
-    def next_token_logits(self, input_ids, attention_mask, encoder_hidden_states):
+    def next_token_logits(self, input_ids, attention_mask, encoder_hidden_states, kv_cache=None):
         """One decode step of the reference protocol: logits [rows, vocab] of the appended [MASK] position.  Only that row
-        goes through the 768x30522 LM head (the reference evaluates it for every position and slices, bert.py:1085)."""
+        goes through the 768x30522 LM head (the reference evaluates it for every position and slices, bert.py:1085); with a
+        kv_cache dict the cross-attention K/V of the condition tokens are projected once per decode, not once per step."""
         inp = self.prepare_inputs_for_generation(input_ids, attention_mask, encoder_hidden_states)
-        seq = self.bert(inp["input_ids"], inp["attention_mask"], inp["encoder_hidden_states"]).last_hidden_state
+        seq = self.bert(inp["input_ids"], inp["attention_mask"], inp["encoder_hidden_states"], kv_cache=kv_cache).last_hidden_state
         last = seq[:, -1:, :].contiguous()
         return Fn.LMLogitsFn.apply(last, *[p.detach() for p in self._head_params()])[:, 0, :]
 
@@ -255,8 +262,11 @@ class BertForMaskedLM(nn.Module):
         beam_scores = beam_scores.view(-1)
         hyps = [_BeamHypotheses(nb, length_penalty) for _ in range(B)]
         done = [False] * B
+        # every beam of a sample attends to the same condition tokens and beams are only ever reordered within their sample, so
+        # the per-layer cross-attention K/V of `enc` are step-invariant: projected at the first step, reused afterwards
+        kv_cache = {} if enc is not None else None
         while True:
-            logits = self.next_token_logits(ids, mask, enc).float()
+            logits = self.next_token_logits(ids, mask, enc, kv_cache).float()
             scores = torch.log_softmax(logits, dim=-1) + beam_scores[:, None]
             V = scores.shape[-1]
             top_s, top_i = torch.topk(scores.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
