@@ -470,8 +470,9 @@ def _slice_groups(groups, c0, c1):
 def tower_chunk_frames(spec, n_frames, device):
     """Frames per tower pass.  Saved activations cost depth * N * (20 D + 4 hidden) bytes per frame (542 MB for ViT-g/14:
     two fp32 stream copies, LN outputs, qkv, attention output, the two MLP intermediates); when all frames do not fit in
-    the memory budget the tower runs in chunks: forward without saving, and in the backward each chunk is recomputed with
-    saving and differentiated (+1 tower forward) - BASELINE configs[3] has 14 frames per sample, 896 per GPU at b = 64."""
+    the memory budget the tower runs in chunks: forward without saving (except the last chunk, whose activations are kept), and
+    in the backward the other chunks are recomputed with saving and differentiated - BASELINE configs[3] has 14 frames per
+    sample, 896 per GPU at b = 64."""
     if torch.device(device).type != "cuda":
         from ._lib import MicoHipError
         raise MicoHipError("the ViT tower runs on an MI355X device only (parameters are on %s): mico_amd has no CPU path" % device)
@@ -484,7 +485,9 @@ def tower_chunk_frames(spec, n_frames, device):
     budget = int(0.70 * free)
     if n_frames * per_frame <= budget:
         return n_frames
-    return max(1, budget // per_frame)
+    most = max(1, budget // per_frame)
+    n_chunks = -(-n_frames // most)
+    return -(-n_frames // n_chunks)      # equal chunks: the one whose activations are kept is then as large as the others
 
 
 class EvaTowerFn(torch.autograd.Function):
@@ -499,12 +502,16 @@ class EvaTowerFn(torch.autograd.Function):
             ctx.chunked = None
             return out
         outs = []
-        for c0 in range(0, Bf, chunk):
+        ctx.saved = None
+        starts = list(range(0, Bf, chunk))
+        for c0 in starts:
             c1 = min(Bf, c0 + chunk)
             sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
-            o, _ = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=False)
+            keep = c0 == starts[-1]      # the last chunk's activations fit by construction: keep them, the backward starts there
+            o, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=keep)
+            if keep:
+                ctx.saved = saved
             outs.append(o)
-        ctx.saved = None
         ctx.chunked = (groups, dp_scale, chunk, Bf)
         return torch.cat(outs, dim=0)
 
@@ -517,11 +524,15 @@ class EvaTowerFn(torch.autograd.Function):
             ctx.saved = None
         else:
             groups, dp_scale, chunk, Bf = ctx.chunked
-            for c0 in range(0, Bf, chunk):
+            starts = list(range(0, Bf, chunk))
+            for c0 in reversed(starts):      # last chunk first: its activations were kept by the forward, the others are recomputed
                 c1 = min(Bf, c0 + chunk)
-                sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
-                _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True)
-                _tower_backward(spec, params, saved, dout[c0:c1], grads, final=(c1 == Bf))
+                if c0 == starts[-1]:
+                    saved, ctx.saved = ctx.saved, None
+                else:
+                    sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
+                    _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True)
+                _tower_backward(spec, params, saved, dout[c0:c1], grads, final=(c0 == starts[0]))
                 del saved
         return (None, None, None) + grads.result()
 
