@@ -40,6 +40,17 @@ class AudioProcessor(object):
         _lib.check(rc, "mico_fbank_windows")
         return out
 
+    def _host_fbank(self, torchaudio, wav_file):
+        """16 kHz waveform scaled to int16 range -> Kaldi log-mel filterbank (25 ms frames, 10 ms shift), optionally resized along
+        the mel axis (audioprocessor.py:34-43); third-party arithmetic, kept on the host."""
+        wave, rate = torchaudio.load(wav_file)
+        wave = wave if rate == 16000 else torchaudio.transforms.Resample(rate, 16000)(wave)
+        fb = torchaudio.compliance.kaldi.fbank(wave * 2 ** 15, num_mel_bins=self.melbins, sample_frequency=16000, frame_length=25,
+                                               frame_shift=10)
+        if fb.size(1) != self.resize_melbin_num:
+            fb = torch.nn.functional.interpolate(fb[None, None], size=(fb.size(0), self.resize_melbin_num), mode="bilinear")[0, 0]
+        return fb
+
     def __call__(self, wav_file):
         if not os.path.exists(wav_file):
             print("not have audios", wav_file)
@@ -50,16 +61,7 @@ class AudioProcessor(object):
             raise ImportError("AudioProcessor.__call__ needs torchaudio for decoding and the Kaldi filterbank; pass a filterbank "
                               "to from_fbank() instead") from e
         try:
-            waveform, sr = torchaudio.load(wav_file)
-            if sr != 16000:
-                waveform = torchaudio.transforms.Resample(sr, 16000)(waveform)
-            waveform = waveform * 2 ** 15
-            fbank = torchaudio.compliance.kaldi.fbank(waveform, num_mel_bins=self.melbins, sample_frequency=16000, frame_length=25,
-                                                      frame_shift=10)
-            if fbank.size(1) != self.resize_melbin_num:
-                fbank = torch.nn.functional.interpolate(fbank.reshape(1, 1, *fbank.shape[-2:]), size=(fbank.size(0), self.resize_melbin_num),
-                                                        mode="bilinear").reshape(fbank.size(0), self.resize_melbin_num)
-            return self.from_fbank(fbank)
+            return self.from_fbank(self._host_fbank(torchaudio, wav_file))
         except Exception as e:   # audioprocessor.py:74-76
             print(e)
             return

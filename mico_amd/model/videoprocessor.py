@@ -13,11 +13,18 @@ from .imageprocessor import image_stats
 
 
 def split(frame_name_lists, sample_num):
-    """videoprocessor.py:11-15 / audioprocessor.py:8-12."""
-    if len(frame_name_lists) < sample_num:
-        frame_name_lists += [frame_name_lists[-1]] * (sample_num - len(frame_name_lists))
-    k, m = divmod(len(frame_name_lists), sample_num)
-    return [frame_name_lists[i * k + min(i, m):(i + 1) * k + min(i + 1, m)] for i in list(range(sample_num))]
+    """videoprocessor.py:11-15 / audioprocessor.py:8-12: sample_num contiguous groups whose sizes differ by at most one (the
+    first len % sample_num groups get the extra element); a short list is first padded with its last element."""
+    items = list(frame_name_lists)
+    while len(items) < sample_num:
+        items.append(items[-1])
+    base, extra = divmod(len(items), sample_num)
+    groups, start = [], 0
+    for g in range(sample_num):
+        size = base + (1 if g < extra else 0)
+        groups.append(items[start:start + size])
+        start += size
+    return groups
 
 
 def sample_indices(groups, training):
