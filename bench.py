@@ -177,10 +177,16 @@ def main():
     samples = b * world * args.steps
     value = samples / elapsed
     summ = timer.summary()
-    names = {(0, 0): "gemm_kernel<T,false,false,Big> (y = x W^T, forward)", (0, 1): "gemm_kernel<T,false,true,Big> (dx = dy W)",
-             (1, 1): "gemm_pc_kernel<T,true,true,32> (dW = dy^T x, producer/consumer waves)"}
-    per_variant = {names[k]: dict(launches=v["launches"], avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / v["ms"] / 1e9)
-                   for k, v in summ.items()}
+    kern = {0: "gemm_kernel<T,{ta},{tb},TileCfg<128,128,2,2,64,2>>", 1: "gemm_kernel<T,{ta},{tb},TileCfg<256,256,2,4,32,4>>",
+            2: "gemm_pc_kernel<T,{ta},{tb},32>"}
+    role = {(0, 0): "y = x W^T (forward)", (0, 1): "dx = dy W", (1, 1): "dW = dy^T x", (1, 0): "x^T W"}
+
+    def kname(key):
+        ta, tb, kk = key
+        return kern[kk].format(ta=str(bool(ta)).lower(), tb=str(bool(tb)).lower()) + " : " + role[(ta, tb)]
+
+    per_variant = {kname(k): dict(launches=v["launches"], avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / v["ms"] / 1e9)
+                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
     tot_flops = sum(v["flops"] for v in summ.values())
     tot_ms = sum(v["ms"] for v in summ.values())
     dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
@@ -192,11 +198,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
     if os.path.exists(tpath) and world == 1:
         tj = json.load(open(tpath))
-        for key in {(0, 0): ("NN_big",), (0, 1): ("dX_big",), (1, 1): ("dW_pc", "dW_big")}[dom[0]]:
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-                break
-    roofline = dict(bound="mfma", kernel=names[dom[0]], achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+        key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc"}[dom[0][2]]
+        if key in tj:
+            traffic = tj[key]["hbm_bytes_per_launch"]
+    roofline = dict(bound="mfma", kernel=kname(dom[0]), achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
                     launches=dom[1]["launches"],
                     avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],

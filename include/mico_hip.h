@@ -92,6 +92,9 @@ typedef struct mico_gemm_epilogue {
     int drop_site;
 } mico_gemm_epilogue;
 
+/* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256
+ * producer/consumer (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
+int mico_gemm_last_kernel(void);
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,
               void* C, int64_t ldc, int c_dtype,

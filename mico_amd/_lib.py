@@ -44,6 +44,7 @@ class AttnParams(C.Structure):
 PROTOTYPES = {
     "mico_version": [],
     "mico_last_error_string": [],
+    "mico_gemm_last_kernel": [],
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,

@@ -807,7 +807,9 @@ int mico_set_err(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int mico_version(void) { return 102; }
+thread_local int g_mico_last_gemm_kernel = 0;
+extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
+extern "C" int mico_version(void) { return 103; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
@@ -888,6 +890,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
     MICO_CHECK(g.e.drop_p >= 0.f && g.e.drop_p < 1.f, "mico_gemm: drop_p must be in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
+    g_mico_last_gemm_kernel = pc ? 2 : (big ? 1 : 0);
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
     else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));

@@ -35,7 +35,7 @@ class KernelTimer:
 
     def __init__(self, variants=((0, 0), (0, 1), (1, 1))):
         self.variants = set(variants)
-        self.records = []   # (variant, flops, start_event, end_event)
+        self.records = []   # ((ta, tb, kernel), flops, start_event, end_event); kernel: 0 small tile, 1 8-wave, 2 producer/consumer
 
     def summary(self):
         out = {}
@@ -99,7 +99,7 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
                               dt_code(out.dtype), C.byref(e), split_k, dt_code(dtype), _st())
     if timed:
         e1.record()
-        timer.records.append(((int(ta), int(tb)), 2.0 * M * N * K, e0, e1))
+        timer.records.append(((int(ta), int(tb), int(_lib.lib().mico_gemm_last_kernel())), 2.0 * M * N * K, e0, e1))
     check(rc, "mico_gemm")
     return out
 
