@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
     const int i = q0 + wave * 16 + (lane & 15);   // this lane's query row
     const int g = lane >> 4;
+    const bool wave_live = q0 + wave * 16 < p.Sq;  // wave-uniform: this wave owns at least one real query row
 
     s16x8 qf[C::KS];
     row_frags<T, HDP>(qf, qb, p.q_rs, i, p.Sq, p.hd, lane);
@@ -164,17 +165,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
             tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, tm_a);
             tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, tm_b);
         }
-        // S^T = K Q^T
+        // S^T = K Q^T.  Only the 16-key sub-tiles that hold real keys are computed: N = 257 (ViT-g/14) ends in a tile with one
+        // valid sub-tile, and a full fifth tile cost 15 % of the kernel (tools/attn_bench.py, 257 vs 256 tokens).
+        const bool edge = (t == nt - 1) && (p.Sk & 63);   // workgroup-uniform: only the ragged last key tile needs bounds
+        const int ntn = edge ? ((p.Sk - t * 64 + 15) >> 4) : 4;
         f32x4 s[4];
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
             s[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tn < ntn && wave_live) {
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) s[tn] = T16<T>::mfma(lds_row_frag<HDP>(kt, tn * 16, ks, lane), qf[ks], s[tn]);
+                for (int ks = 0; ks < C::KS; ++ks) s[tn] = T16<T>::mfma(lds_row_frag<HDP>(kt, tn * 16, ks, lane), qf[ks], s[tn]);
+            }
         }
         // online softmax in the exp2 domain (v_exp_f32 is 2^x): scores are pre-multiplied by scale * log2(e)
         float mloc = NEG_BIG;
-        const bool edge = (t == nt - 1) && (p.Sk & 63);   // workgroup-uniform: only the ragged last key tile needs bounds
         if (!p.mask_mode && !edge) {
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
         // O^T += V^T P^T
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            if (2 * s2 >= ntn || !wave_live) continue;    // no real key in this 32-key half / no real query in this wave
             const s16x8 pf = pack_pair<T>(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
             for (int td = 0; td < C::TD; ++td) oacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(vt, td, s2, lane), pf, oacc[td]);
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
     const T* dob = d_o + (int64_t)b * p.o_bs + h * p.hd;
     const int i = q0 + wave * 16 + (lane & 15);
     const int g = lane >> 4;
+    const bool wave_live = q0 + wave * 16 < p.Sq;
 
     s16x8 qf[C::KS], dof[C::KS];
     row_frags<T, HDP>(qf, qb, p.q_rs, i, p.Sq, p.hd, lane);
@@ -307,15 +314,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
             tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, tm_a);
             tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, tm_b);
         }
+        const int ntn = (t == nt - 1 && (p.Sk & 63)) ? ((p.Sk - t * 64 + 15) >> 4) : 4;   // 16-key sub-tiles holding real keys
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
             s[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dp[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tn < ntn && wave_live) {
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                s[tn] = T16<T>::mfma(lds_row_frag<HDP>(kt, tn * 16, ks, lane), qf[ks], s[tn]);
-                dp[tn] = T16<T>::mfma(lds_row_frag<HDP>(vt, tn * 16, ks, lane), dof[ks], dp[tn]);
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    s[tn] = T16<T>::mfma(lds_row_frag<HDP>(kt, tn * 16, ks, lane), qf[ks], s[tn]);
+                    dp[tn] = T16<T>::mfma(lds_row_frag<HDP>(vt, tn * 16, ks, lane), dof[ks], dp[tn]);
+                }
             }
         }
 #pragma unroll
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
             }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            if (2 * s2 >= ntn || !wave_live) continue;
             const s16x8 df = pack_pair<T>(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
             for (int td = 0; td < C::TD; ++td) dqacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(kt, td, s2, lane), df, dqacc[td]);
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
     const T* dob = d_o + (int64_t)b * p.o_bs + h * p.hd;
     const int j = k0 + wave * 16 + (lane & 15);   // this lane's key row
     const int g = lane >> 4;
+    const bool wave_live = k0 + wave * 16 < p.Sk;   // wave-uniform: this wave owns at least one real key
     const int64_t stat_base = ((int64_t)b * p.H + h) * p.Sq;
 
     s16x8 kf[C::KS], vf[C::KS];
@@ -408,16 +420,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
             const int ii = (t + 1) * 64 + tid;
             if (tid < 64 && ii < p.Sq) { st_l = lse[stat_base + ii]; st_d = delta[stat_base + ii]; }
         }
-        // S = Q K^T, dP = dO V^T  (lane: key j = lane&15, query rows ti*16 + g*4 + r)
+        // S = Q K^T, dP = dO V^T  (lane: key j = lane&15, query rows ti*16 + g*4 + r); only 16-query sub-tiles with real queries
+        const int nti = (t == nt - 1 && (p.Sq & 63)) ? ((p.Sq - t * 64 + 15) >> 4) : 4;
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             s[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dp[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ti < nti && wave_live) {
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                s[ti] = T16<T>::mfma(lds_row_frag<HDP>(qt, ti * 16, ks, lane), kf[ks], s[ti]);
-                dp[ti] = T16<T>::mfma(lds_row_frag<HDP>(dot, ti * 16, ks, lane), vf[ks], dp[ti]);
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    s[ti] = T16<T>::mfma(lds_row_frag<HDP>(qt, ti * 16, ks, lane), kf[ks], s[ti]);
+                    dp[ti] = T16<T>::mfma(lds_row_frag<HDP>(dot, ti * 16, ks, lane), vf[ks], dp[ti]);
+                }
             }
         }
         f32x4 pr[4];
@@ -446,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            if (2 * s2 >= nti || !wave_live) continue;
             const s16x8 pf = pack_pair<T>(pr[2 * s2], pr[2 * s2 + 1]);
             const s16x8 df = pack_pair<T>(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll

@@ -49,5 +49,7 @@ def run(name, B, H, Sq, Sk, hd, fused, iters=10):
 
 if __name__ == "__main__":
     run("vit_g", 320, 16, 257, 257, 88, True)
+    run("vit_g_256", 320, 16, 256, 256, 88, True)     # what the 257th token (ragged fifth tile in both directions) costs
+    run("vit_g_272", 320, 16, 272, 272, 88, True)
     run("bert_cross", 192, 12, 77, 1285, 64, False)
     run("bert_self", 192, 12, 77, 77, 64, True)
