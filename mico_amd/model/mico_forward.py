@@ -163,9 +163,20 @@ def forward(self, batch, task, compute_loss=True):
                     out[f"feat_cond_{st}"] = _feat_cond(self, enc, st[1:])
                     out[f"condition_feats_{st}"] = _condition_feats(self, enc, st[1:])
         elif t.startswith("cap"):
-            if not compute_loss:
-                raise NotImplementedError("caption generation is SURVEY.md section 8 row f1")
-            out.update(_forward_cap(self, batch, enc, subtasks))
+            if compute_loss:
+                out.update(_forward_cap(self, batch, enc, subtasks))
+            else:   # evaluation dict of vast.py:513-547: beam-search captions per sub-task (captioner_mode sampling is not provided)
+                if getattr(self.config, "captioner_mode", False):
+                    raise NotImplementedError("captioner_mode (top-k sampling) is not provided; beam search is")
+                tk = self.multimodal_encoder.tokenizer
+                for st in subtasks:
+                    cond = _condition_feats(self, enc, st[1:])
+                    init = torch.full((cond.shape[0], 1), tk.bos_token_id, dtype=torch.long, device=cond.device)
+                    ids = self.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(cond.shape[0], 1, 1),
+                                                           encoder_hidden_states=cond, max_new_tokens=self.max_caption_len,
+                                                           num_beams=self.beam_size, eos_token_id=tk.sep_token_id,
+                                                           pad_token_id=tk.pad_token_id, length_penalty=0.6)
+                    out[f"generated_captions_{st}"] = tk.batch_decode(ids[:, 1:], skip_special_tokens=True)
         else:
             raise NotImplementedError(t)
     return out

@@ -48,3 +48,21 @@ def test_generate_matches_oracle(cuda, num_beams, sep_bias, max_new):
         assert ids.tolist() == ref.tolist()
     with pytest.raises(TypeError):
         m.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(3, 1, 1), do_sample=True)
+
+
+def test_forward_cap_evaluation_dict(cuda):
+    """MiCo.forward(batch, "cap%tv", compute_loss=False) -> {"generated_captions_tv": [str] * b} (vast.py:513-547), same ids as the
+    oracle's beam search on the oracle's condition tensor."""
+    from mico_amd.weights import synth_inputs
+    torch.set_num_threads(16)
+    m, sd = build_model("evaclip02_base", 1, device=cuda, max_caption_len=6)
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    inp = synth_inputs(dict(b=2, vision=2, S=8), seed=8)
+    with torch.no_grad():
+        enc = O.encode_batch(sdo, O.ARCHS["evaclip02_base"], inp)
+        ref = O.generate_beam(sdo, O.condition_feats(enc, "v"), 6, 3, 0.6)
+    with runtime.precision(torch.float16), torch.no_grad():
+        out = m({k: v.to(cuda) for k, v in inp.items()}, "cap%tv", compute_loss=False)
+    want = m.multimodal_encoder.tokenizer.batch_decode(ref[:, 1:], skip_special_tokens=True)
+    assert out == {"generated_captions_tv": want}
