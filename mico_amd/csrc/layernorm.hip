@@ -242,6 +242,7 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
                                   int rows_per_frame, float* x_copy, float drop_p, unsigned drop_seed, int drop_site,
                                   int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
+    if (rows <= 0) return MICO_OK;   // an empty batch is a no-op (its tensors have no storage to point to)
     MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
     MICO_CHECK(x_dtype == MICO_F32 || x_dtype == dtype, "mico_layernorm_fwd: x_dtype must be fp32 or dtype");
@@ -263,6 +264,7 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
                                   float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
                                   int cols, const int* frame_map, int rows_per_frame, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
+    if (rows <= 0) return MICO_OK;
     if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_bwd: frame_map needs rows_per_frame > 0");
     MICO_CHECK(dy && x && gamma && mean && rstd, "mico_layernorm_bwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 2048, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 2048 (got %d)", cols);
