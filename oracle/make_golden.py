@@ -435,6 +435,23 @@ def processor_fixture():
     print("wrote processors.pt")
 
 
+def subtitle_fixture():
+    """The subtitle branch of the facade (mico.py:245-248: hidden_trans_subtitle_multimodal + subtitle type embedding) and the
+    subtitle-bearing contrastive heads (contra_head_s / _vs / _vas, mico.py:385-394) of the reference, depth-1 B/16 model with the
+    deterministic synthetic weights."""
+    m = ref_import.build_mico("evaclip02_base", depth=1)
+    fill(m)
+    g = torch.Generator().manual_seed(41)
+    sub_out = torch.randn(2, 7, 768, generator=g)
+    pooled = {k: torch.randn(2, d, generator=g) for k, d in (("s", 768), ("vs", 768 + 768), ("vas", 768 + 768 + 768))}
+    with torch.no_grad():
+        out = dict(sub_in=sub_out, cond_s=m.get_multimodal_forward_input_subtitle(sub_out).clone(), pooled=pooled)
+        for k in pooled:
+            out["head_" + k] = getattr(m, "contra_head_" + k)(pooled[k]).clone()
+    torch.save(out, os.path.join(OUT, "subtitle_b16.pt"))
+    print("wrote subtitle_b16.pt")
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -471,6 +488,8 @@ def main(which):
         optimizer_fixture()
     if want("proc"):
         processor_fixture()
+    if want("sub"):
+        subtitle_fixture()
 
 
 if __name__ == "__main__":

@@ -195,3 +195,16 @@ def test_full_depth_vit_g(cuda):
         e_feat = rel_err(feat, fx["feat_v"])
         print(f"full g/14 {dtype}: token rows {e_rows:.2e}  feat_v {e_feat:.2e}  amax {out.abs().max().item():.3f}/{fx['amax'].item():.3f}")
         assert e_rows < tol and e_feat < 2 * tol
+
+
+def test_subtitle_branch_and_heads(cuda):
+    """get_multimodal_forward_input_subtitle (16-bit MFMA projection: the 1e-3 gate in the fp16 parity configuration) and the
+    subtitle-bearing contrastive heads (exact-fp32 kernels) against the reference (golden subtitle_b16.pt)."""
+    fx = golden("subtitle_b16.pt")
+    m, _ = build_model("evaclip02_base", 1, device=cuda)
+    with runtime.precision(torch.float16), torch.no_grad():
+        cond = m.get_multimodal_forward_input_subtitle(fx["sub_in"].to(cuda))
+        assert cond.shape == fx["cond_s"].shape and rel_err(cond, fx["cond_s"]) < 1e-3
+        for k, x in fx["pooled"].items():
+            y = getattr(m, "contra_head_" + k)(x.to(cuda))
+            assert rel_err(y, fx["head_" + k]) < 1e-5, k
