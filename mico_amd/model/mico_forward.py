@@ -16,8 +16,9 @@ from .. import distributed as D
 from .. import functional as Fn
 
 COND_MODALITY = {"v": "vision", "a": "audio", "d": "depth"}
-FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "va": "contra_head_va", "vd": "contra_head_id"}
-SUBTASKS = ("tv", "ta", "td", "tva", "tvd")
+FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "s": "contra_head_s", "va": "contra_head_va",
+               "vd": "contra_head_id", "vs": "contra_head_vs", "vas": "contra_head_vas"}
+SUBTASKS = ("tv", "ta", "td", "ts", "tva", "tvd", "tvs", "tvas")    # vast.py's tv / ta / tva / tvs / tvas + MiCo's depth heads
 
 
 def _tokens(self, batch):
@@ -59,6 +60,16 @@ def encode_batch(self, batch):
             enc["output_" + m] = o
             enc["pooled_" + m] = Fn.cls_pool(o)
             enc["condition_feats_" + m] = self._pack(COND_MODALITY[m], o)
+    if "subtitle_ids" in batch or "raw_subtitles" in batch:   # vast.py:96-104,168-174: subtitles through the text BERT
+        if "subtitle_ids" not in batch:
+            dev = self.contra_temp.device
+            tok = self.multimodal_encoder.tokenizer(batch["raw_subtitles"], padding="max_length", truncation=True,
+                                                    max_length=self.max_subtitle_len, return_tensors="pt")
+            batch["subtitle_ids"], batch["subtitle_mask"] = tok.input_ids.to(dev), tok.attention_mask.to(dev)
+        sub = self.multimodal_encoder.bert(input_ids=batch["subtitle_ids"], attention_mask=batch["subtitle_mask"]).last_hidden_state
+        enc["output_s"] = sub
+        enc["pooled_s"] = self.pool_text_for_contra(sub)
+        enc["condition_feats_s"] = self.get_multimodal_forward_input_subtitle(sub)
     if "input_ids" in batch or "raw_captions" in batch or "caption_tokens" in batch:
         ids, am = _tokens(self, batch)
         seq = self.multimodal_encoder.bert(input_ids=ids, attention_mask=am).last_hidden_state

@@ -368,6 +368,13 @@ def encode_batch(sd, arch, batch, pool_video=False, drop_path_scale=None):
         out["output_" + m] = o
         out["pooled_" + m] = pool_for_contra(o)
         out["condition_feats_" + m] = multimodal_input(sd, COND_MODALITY[m], o, pool_video)
+    if "subtitle_ids" in batch:   # vast.py:168-174, 196-199, 236-238: subtitles go through the text BERT, CLS pooled
+        sub_seq = bert_forward(sd, batch["subtitle_ids"], batch["subtitle_mask"])
+        out["output_s"] = sub_seq
+        out["pooled_s"] = sub_seq[:, 0]
+        y = layer_norm(F.linear(sub_seq, sd["hidden_trans_subtitle_multimodal.0.weight"], sd["hidden_trans_subtitle_multimodal.0.bias"]),
+                       sd["hidden_trans_subtitle_multimodal.1.weight"], sd["hidden_trans_subtitle_multimodal.1.bias"], BERT_EPS)
+        out["condition_feats_s"] = y + sd["subtitle_type_embeddings"]          # mico.py:245-248
     if "input_ids" in batch:
         seq = bert_forward(sd, batch["input_ids"], batch["attention_mask"])
         out["caption_output"] = seq
@@ -375,8 +382,8 @@ def encode_batch(sd, arch, batch, pool_video=False, drop_path_scale=None):
     return out
 
 
-FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "va": "contra_head_va",
-               "vd": "contra_head_id"}
+FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "s": "contra_head_s", "va": "contra_head_va",
+               "vd": "contra_head_id", "vs": "contra_head_vs", "vas": "contra_head_vas"}
 
 
 def feat_cond(sd, enc, cond):

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from common import golden, rel_err, build_model, grad_digest_check
 from mico_amd import runtime
 from mico_amd.weights import synth_inputs
+from oracle import mico_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -208,3 +209,41 @@ def test_subtitle_branch_and_heads(cuda):
         for k, x in fx["pooled"].items():
             y = getattr(m, "contra_head_" + k)(x.to(cuda))
             assert rel_err(y, fx["head_" + k]) < 1e-5, k
+
+
+def test_subtitle_subtasks(cuda):
+    """vast.py's subtitle sub-tasks (ts / tvs / tvas): subtitles through the text BERT, CLS-pooled for the contrastive heads
+    (contra_head_s / _vs / _vas) and projected + type-embedded as cross-attention condition tokens, concatenated after the vision
+    and audio tokens.  Features and the ITC / ITM / CAP losses against the oracle (fp16 parity configuration)."""
+    import random
+    torch.set_num_threads(16)
+    m, sd = build_model("evaclip02_base", 2, device=cuda)
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    b = 3
+    inp = synth_inputs(dict(b=b, vision=2, audio=1, S=10), seed=21)
+    sub = synth_inputs(dict(b=b, S=7), seed=22)
+    inp["subtitle_ids"], inp["subtitle_mask"] = sub["input_ids"], sub["attention_mask"]
+    idx = torch.arange(b).roll(1)
+    mi, lab = O.token_masker(inp["input_ids"], 0.6, random.Random(1))
+    task = "ret%tvas%tvs%ts_cap%tvas"
+    inj = {st: dict(neg_cond_idx=idx, neg_text_idx=idx.roll(1)) for st in ("tvas", "tvs", "ts")}
+    inj["cap"] = dict(masked_ids=mi, labels=lab)
+    with torch.no_grad():
+        ref, ref_enc = O.mico_forward(sdo, O.ARCHS["evaclip02_base"], inp, task, dict(itm_ratio=0.1), injected=inj)
+    batch = to_dev(inp, cuda)
+    batch["_injected"] = inj
+    with runtime.precision(torch.float16), torch.no_grad():
+        enc = m.encode_batch(dict(batch))
+        for c in ("s", "vs", "vas"):
+            assert rel_err(m._feat_cond(enc, c), O.feat_cond(sdo, ref_enc, c)) < 1e-3, c
+            assert rel_err(m._condition_feats(enc, c), O.condition_feats(ref_enc, c)) < 1e-3, c
+        out = m(batch, task)
+    for k, v in ref.items():
+        e = abs(out[k].item() - v.item()) / max(abs(v.item()), 1e-6)
+        assert e < 2e-3, (k, out[k].item(), v.item())
+    # raw subtitles are tokenised to max_subtitle_len
+    raw = dict(to_dev(synth_inputs(dict(b=2, vision=1, S=10), seed=5), cuda), raw_subtitles=["a dog barks", "people talking loudly"])
+    with runtime.precision(torch.float16), torch.no_grad():
+        e2 = m.encode_batch(raw)
+    assert e2["condition_feats_s"].shape == (2, m.max_subtitle_len, 768)
