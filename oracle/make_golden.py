@@ -234,7 +234,7 @@ def loss_fixture(m, tag, b=4):
     named = dict(m.named_parameters())
     gnames = [n.format("w3" if "vision_encoder.visual.blocks.1.mlp.w3.weight" in named else "fc2") for n in gnames]
 
-    for W in (1, 2):
+    for W in (1, 2, 4):
         inputs = [synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234 + r) for r in range(W)]
         encs = [encode(i) for i in inputs]
         world = dict(feat_t_all=torch.cat([e["feat_t"] for e in encs]).detach(),
@@ -256,8 +256,8 @@ def loss_fixture(m, tag, b=4):
                  grads={n: grad_digest(named[n].grad) for n in gnames},
                  world={k: v.detach().clone() for k, v in world.items() if not k.startswith("cond_")},
                  feat_t=encs[0]["feat_t"].detach().clone(), feat_va=encs[0]["feat_va"].detach().clone())
-        if W == 2:   # the remote rank's condition rows that may be fetched as negatives (recomputed from seeds in tests)
-            r["remote_cond_va_sum"] = encs[1]["cond_va"].detach().sum((1, 2))
+        if W >= 2:   # the remote ranks' condition rows that may be fetched as negatives (recomputed from seeds in tests)
+            r["remote_cond_va_sum"] = torch.cat([e["cond_va"].detach().sum((1, 2)) for e in encs[1:]])
         fx[f"W{W}"] = r
         print(tag, "W", W, {k: float(v) for k, v in losses.items()})
     torch.save(fx, os.path.join(OUT, f"loss_{tag}.pt"))

@@ -136,7 +136,7 @@ def test_facade(setup, cuda):
             m.config.pool_video = False
 
 
-@pytest.mark.parametrize("W", [1, 2])
+@pytest.mark.parametrize("W", [1, 2, 4])
 def test_alignment_loss(setup, cuda, W):
     vtype, tag, m, sd = setup
     fx = golden(f"loss_{tag}.pt")
@@ -147,10 +147,10 @@ def test_alignment_loss(setup, cuda, W):
     batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
     batch["_injected"]["cap"] = r["inj"]["cap"]
     with runtime.precision(torch.float16):
-        if W == 2:
+        if W >= 2:
             with torch.no_grad():
-                enc1 = m.encode_batch(dict(inputs[1]))
-                remote = {c: m._condition_feats(enc1, c).detach() for c in ("v", "va")}
+                encs = [m.encode_batch(dict(i)) for i in inputs[1:]]
+                remote = {c: torch.cat([m._condition_feats(e, c).detach() for e in encs]) for c in ("v", "va")}
             world = dict(rank=0, feat_t_all=r["world"]["feat_t_all"].to(cuda), ids_all=r["world"]["ids_all"].to(cuda),
                          mask_all=r["world"]["mask_all"].to(cuda))
             for c in ("v", "va"):

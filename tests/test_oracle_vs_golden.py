@@ -103,7 +103,7 @@ def test_facade(setup):
                 assert rel_err(score, r[f"itm_score_{k}"]) < 1e-4
 
 
-@pytest.mark.parametrize("W", [1, 2])
+@pytest.mark.parametrize("W", [1, 2, 4])
 def test_alignment_loss(setup, W):
     vtype, tag, sd, arch = setup
     fx = golden(f"loss_{tag}.pt")
@@ -113,18 +113,20 @@ def test_alignment_loss(setup, W):
         p.grad = None
     inputs = [synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234 + k) for k in range(W)]
     world = None
-    if W == 2:
+    enc_remote = None
+    if W >= 2:
         with torch.no_grad():
-            enc1 = O.encode_batch(sd, arch, inputs[1])
+            encs = [O.encode_batch(sd, arch, i) for i in inputs[1:]]
+        enc_remote = {"condition_feats_" + c: torch.cat([O.condition_feats(e, c) for e in encs]) for c in ("v", "va")}
         world = dict(feat_t_all=r["world"]["feat_t_all"], ids_all=r["world"]["ids_all"], mask_all=r["world"]["mask_all"])
         for c in ("v", "va"):
             world[f"feat_{c}_all"] = r["world"][f"feat_{c}_all"]
-        assert rel_err(O.condition_feats(enc1, "va").sum((1, 2)), r["remote_cond_va_sum"]) < 1e-4
+        assert rel_err(enc_remote["condition_feats_va"].sum((1, 2)), r["remote_cond_va_sum"]) < 1e-4
     injected = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
     injected["cap"] = r["inj"]["cap"]
     cfg = dict(itm_ratio=fx["meta"]["itm_ratio"])
-    if W == 2:   # gathered condition memory = [local (with grad) | remote (constant)]
-        out, enc = _loss_w2(sd, arch, inputs[0], cfg, world, injected, O.encode_batch(sd, arch, inputs[1]))
+    if W >= 2:   # gathered condition memory = [local (with grad) | remote ranks (constant)]
+        out, enc = _loss_w2(sd, arch, inputs[0], cfg, world, injected, enc_remote)
     else:
         out, enc = O.mico_forward(sd, arch, inputs[0], fx["meta"]["task"], cfg, injected=injected)
     for k, v in r["losses"].items():
@@ -138,7 +140,7 @@ def test_alignment_loss(setup, W):
 def _loss_w2(sd, arch, inp, cfg, world, injected, enc_remote):
     enc = O.encode_batch(sd, arch, inp)
     for c in ("v", "va"):
-        world[f"cond_{c}_all"] = torch.cat((O.condition_feats(enc, c), O.condition_feats(enc_remote, c).detach()))
+        world[f"cond_{c}_all"] = torch.cat((O.condition_feats(enc, c), enc_remote["condition_feats_" + c].detach()))
     ids, am = inp["input_ids"], inp["attention_mask"]
     l_itc, l_itm = [], []
     for st in ("tva", "tv"):
