@@ -14,6 +14,18 @@ namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
 
+#ifdef MICO_ATTN_PHASES   // timing build (tools/probes/attn_phases.py): per-wave cycle counts of the forward kernel's phases
+__device__ unsigned long long g_attn_phase[4096 * 8];
+#define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[slot] += n_ - ph_t; ph_t = n_; } while (0)
+#define PH_STORE do { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+        if (lane == 0 && wave == 0 && wg_ < 4096) for (int e_ = 0; e_ < 8; ++e_) g_attn_phase[wg_ * 8 + e_] = ph_acc[e_]; } while (0)
+#else
+#define PH_DECL
+#define PH(slot)
+#define PH_STORE
+#endif
+
 template <int HDP> struct Cfg {
     // LDS row stride: 256 B = 16 chunk slots (<= 12 used) with the 16-byte chunk index XOR-ed by 2*(row & 7).  With that key
     // both access modes of a tile are bank-conflict free: ds_read_b128 row fragments (16 rows x 2 adjacent chunk columns per
@@ -107,14 +119,8 @@ __device__ __forceinline__ s16x8 pack_pair(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(s16x8, v);
 }
 
-__device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups that share lane&15
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
+__device__ __forceinline__ float group_max(float v) { return xor32_max(xor16_max(v)); }   // across the 4 lane groups that share lane&15
+__device__ __forceinline__ float group_sum(float v) { return xor32_sum(xor16_sum(v)); }
 
 __device__ __forceinline__ float mask_val(const float* mask, int mode, int b, int i, int j, int Sq, int Sk) {
     if (mode == 1) return mask[(int64_t)b * Sk + j];
@@ -125,7 +131,10 @@ __device__ __forceinline__ float mask_val(const float* mask, int mode, int b, in
 // ======================================================================================================================
 // forward
 // ======================================================================================================================
-template <typename T, int HDP, bool DROP>
+// RB = 16-row query blocks per wave.  With RB = 1 every K / V^T fragment read from LDS feeds one MFMA, and the kernel is bound by
+// LDS bandwidth at twice the MFMA time (24.5 KB of LDS reads per 24 MFMAs per wave and key tile); RB = 2 (long self-attention:
+// the ViT towers) reuses each fragment for two query blocks and stages every K/V tile for 128 instead of 64 queries.
+template <typename T, int HDP, bool DROP, int RB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, T* __restrict__ o,
                                                           float* __restrict__ lse, const mico_attn_params p) {
@@ -134,21 +143,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     LDS_AS char* kt = (LDS_AS char*)smem;
     LDS_AS char* vt = kt + C::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * RB);
     const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
     const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
     const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
-    const int i = q0 + wave * 16 + (lane & 15);   // this lane's query row
+    const int i0 = q0 + wave * (16 * RB) + (lane & 15);   // this lane's query rows: i0 + rb * 16
     const int g = lane >> 4;
-    const bool wave_live = q0 + wave * 16 < p.Sq;  // wave-uniform: this wave owns at least one real query row
+    const bool wave_live = q0 + wave * (16 * RB) < p.Sq;  // wave-uniform: this wave owns at least one real query row
 
-    s16x8 qf[C::KS];
-    row_frags<T, HDP>(qf, qb, p.q_rs, i, p.Sq, p.hd, lane);
-
-    f32x4 oacc[C::TD];
+    s16x8 qf[RB][C::KS];
+    f32x4 oacc[RB][C::TD];
+    float m_run[RB], l_run[RB];   // running max (log2 domain) and sum
 #pragma unroll
-    for (int t = 0; t < C::TD; ++t) oacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = NEG_BIG, l_run = 0.f;   // running max (log2 domain) and sum
+    for (int rb = 0; rb < RB; ++rb) {
+        row_frags<T, HDP>(qf[rb], qb, p.q_rs, i0 + rb * 16, p.Sq, p.hd, lane);
+#pragma unroll
+        for (int t = 0; t < C::TD; ++t) oacc[rb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_run[rb] = NEG_BIG;
+        l_run[rb] = 0.f;
+    }
     const float sc2 = p.scale * 1.4426950408889634f;
 
     const int nt = (p.Sk + 63) / 64;
@@ -156,96 +169,468 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     s16x8 kr[C::NCH], vr[C::NCH];
     tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, tm_a);
     tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, tm_b);
+    PH_DECL;
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
+        PH(0);
         tile_commit<HDP>(kr, kt, tm_a);
         tile_commit<HDP>(vr, vt, tm_b);
+        PH(1);
         __syncthreads();
+        PH(2);
         if (t + 1 < nt) {
             tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, tm_a);
             tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, tm_b);
         }
+        PH(3);
         // S^T = K Q^T.  Only the 16-key sub-tiles that hold real keys are computed: N = 257 (ViT-g/14) ends in a tile with one
         // valid sub-tile, and a full fifth tile cost 15 % of the kernel (tools/attn_bench.py, 257 vs 256 tokens).
         const bool edge = (t == nt - 1) && (p.Sk & 63);   // workgroup-uniform: only the ragged last key tile needs bounds
         const int ntn = edge ? ((p.Sk - t * 64 + 15) >> 4) : 4;
-        f32x4 s[4];
+        f32x4 s[RB][4];
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
-            s[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (tn < ntn && wave_live) {
 #pragma unroll
-                for (int ks = 0; ks < C::KS; ++ks) s[tn] = T16<T>::mfma(lds_row_frag<HDP>(kt, tn * 16, ks, lane), qf[ks], s[tn]);
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    const s16x8 a = lds_row_frag<HDP>(kt, tn * 16, ks, lane);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) s[rb][tn] = T16<T>::mfma(a, qf[rb][ks], s[rb][tn]);
+                }
             }
         }
-        // online softmax in the exp2 domain (v_exp_f32 is 2^x): scores are pre-multiplied by scale * log2(e)
-        float mloc = NEG_BIG;
-        if (!p.mask_mode && !edge) {
+        s16x8 pf[RB][2];
+        PH(4);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                s[tn] *= sc2;
-                mloc = fmaxf(fmaxf(mloc, fmaxf(s[tn][0], s[tn][1])), fmaxf(s[tn][2], s[tn][3]));
+        for (int rb = 0; rb < RB; ++rb) {
+            const int i = i0 + rb * 16;
+            // online softmax in the exp2 domain (v_exp_f32 is 2^x): scores are pre-multiplied by scale * log2(e)
+            float mloc = NEG_BIG;
+            if (!p.mask_mode && !edge) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    s[rb][tn] *= sc2;
+                    mloc = fmaxf(fmaxf(mloc, fmaxf(s[rb][tn][0], s[rb][tn][1])), fmaxf(s[rb][tn][2], s[rb][tn][3]));
+                }
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = t * 64 + tn * 16 + g * 4 + r;
+                        float x = s[rb][tn][r] * sc2;
+                        if (j < p.Sk) {
+                            if (p.mask_mode && i < p.Sq) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk) * 1.4426950408889634f;
+                        } else {
+                            x = NEG_BIG;
+                        }
+                        s[rb][tn][r] = x;
+                        mloc = fmaxf(mloc, x);
+                    }
             }
-        } else {
+            const float m_new = fmaxf(m_run[rb], group_max(mloc));
+            const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+            float lloc = 0.f;
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = t * 64 + tn * 16 + g * 4 + r;
-                    float x = s[tn][r] * sc2;
-                    if (j < p.Sk) {
-                        if (p.mask_mode && i < p.Sq) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk) * 1.4426950408889634f;
-                    } else {
-                        x = NEG_BIG;
-                    }
-                    s[tn][r] = x;
-                    mloc = fmaxf(mloc, x);
+                    const float e = __builtin_amdgcn_exp2f(s[rb][tn][r] - m_new);
+                    s[rb][tn][r] = e;
+                    lloc += e;
                 }
-        }
-        const float m_new = fmaxf(m_run, group_max(mloc));
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lloc = 0.f;
+            if (DROP) {   // dropout on the probabilities (compile-time variant: the ViT towers never pay its registers): the row sum above stays the undropped one
+                const unsigned thr = drop_threshold(p.drop_p);
+                const float ik = 1.f / (1.f - p.drop_p);
+                const unsigned long long rowbase = (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+                for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[tn][r] - m_new);
-                s[tn][r] = e;
-                lloc += e;
+                    for (int r = 0; r < 4; ++r)
+                        s[rb][tn][r] *= drop_mult(p.drop_seed, p.drop_site, rowbase + (t * 64 + tn * 16 + g * 4 + r), thr, ik);
             }
-        if (DROP) {   // dropout on the probabilities (compile-time variant: the ViT towers never pay its registers): the row sum above stays the undropped one
-            const unsigned thr = drop_threshold(p.drop_p);
-            const float ik = 1.f / (1.f - p.drop_p);
-            const unsigned long long rowbase = (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
+            l_run[rb] = l_run[rb] * alpha + group_sum(lloc);
+            m_run[rb] = m_new;
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s[tn][r] *= drop_mult(p.drop_seed, p.drop_site, rowbase + (t * 64 + tn * 16 + g * 4 + r), thr, ik);
+            for (int t2 = 0; t2 < C::TD; ++t2) oacc[rb][t2] *= alpha;
+            pf[rb][0] = pack_pair<T>(s[rb][0], s[rb][1]);
+            pf[rb][1] = pack_pair<T>(s[rb][2], s[rb][3]);
         }
-        l_run = l_run * alpha + group_sum(lloc);
-        m_run = m_new;
-#pragma unroll
-        for (int t2 = 0; t2 < C::TD; ++t2) oacc[t2] *= alpha;
+        PH(5);
         // O^T += V^T P^T
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             if (2 * s2 >= ntn || !wave_live) continue;    // no real key in this 32-key half / no real query in this wave
-            const s16x8 pf = pack_pair<T>(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
-            for (int td = 0; td < C::TD; ++td) oacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(vt, td, s2, lane), pf, oacc[td]);
+            for (int td = 0; td < C::TD; ++td) {
+                const s16x8 a = lds_tr_frag<HDP>(vt, td, s2, lane);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) oacc[rb][td] = T16<T>::mfma(a, pf[rb][s2], oacc[rb][td]);
+            }
+        }
+        PH(6);
+    }
+    PH_STORE;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int i = i0 + rb * 16;
+        if (i < p.Sq) {
+            const float inv = 1.f / l_run[rb];
+            T* ob = o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd;
+#pragma unroll
+            for (int td = 0; td < C::TD; ++td) {
+                const int d = td * 16 + g * 4;
+                if (d < p.hd)
+                    *(s16x4*)(ob + d) = pack4<T>(oacc[rb][td][0] * inv, oacc[rb][td][1] * inv, oacc[rb][td][2] * inv, oacc[rb][td][3] * inv);
+            }
+            if (g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (m_run[rb] + __log2f(l_run[rb])) * 0.6931471805599453f;
         }
     }
-    if (i < p.Sq) {
-        const float inv = 1.f / l_run;
-        T* ob = o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd;
+}
+
+// ======================================================================================================================
+// forward, K/V-resident variant for unmasked self-attention with Sq, Sk <= 272 (the ViT towers: 257 tokens at patch 14, 197 at
+// patch 16).  Persistent 8-wave workgroups, one per CU, each walking over (b, h) items: all of K and V of the head are staged into
+// LDS once (2 x 288 rows x 256 B), then the key loop runs without a single barrier, every wave owning two 16-query blocks (rows
+// wave*32 ..), while the NEXT item's K/V are already on their way into registers.  The tiled kernel above stages every key tile
+// once per 64 queries behind two barriers and is bound by exactly that (tools/probes/attn_phases.py: of 5700 cycles per key tile
+// 2150 are barriers, global-load issue and the register -> LDS commit; a fifth tile holding the 257th key and another workgroup
+// holding the 257th query cost as much as full ones; a non-persistent resident kernel lost a third of its time to the dispatch
+// gap and the exposed staging).  The ragged ends of N = 257:
+//  * keys: steps cover 64 keys, the last one 80 when 1..16 keys are left over (5 sub-tiles instead of a fifth step);
+//  * queries 256..271 are a 17th block that no wave has room for: it is split over the KEYS instead - wave w adds sub-tiles
+//    2w, 2w+1 (wave 7 also the 17th) as a third, small query block to the step that holds them - and the eight partial
+//    (max, sum, O) triples are merged through the then idle K region of LDS.
+// ======================================================================================================================
+constexpr int RES_KR = 288;   // resident key rows (272 rounded up to the 32 keys one transposed V fragment spans)
+
+// One step over NSUB 16-key sub-tiles starting at LDS row pointers ktile / vtile (global key index key0), restricted to sub-tiles
+// [lo, hi).  mode 0: all NSUB sub-tiles in range and inside Sk; 1: as 0 but the last sub-tile is ragged; 2: general.
+template <typename T, int HDP, int RB, int NSUB>
+__device__ __forceinline__ void res_tile_step(LDS_AS const char* ktile, LDS_AS const char* vtile, const int key0, const int lo,
+                                              const int hi, const int mode, const s16x8 (&qf)[RB][Cfg<HDP>::KS],
+                                              f32x4 (&oacc)[RB][Cfg<HDP>::TD], float (&m_run)[RB], float (&l_run)[RB],
+                                              const int Sk, const float sc2, const int lane,
+                                              const int (&rf)[Cfg<HDP>::KS], const int (&tf)[Cfg<HDP>::TD]) {
+    using C = Cfg<HDP>;
+    constexpr int NH = (NSUB + 1) / 2;
+    const int g = lane >> 4;
+    f32x4 s[RB][NH * 2];
+#pragma unroll
+    for (int tn = 0; tn < NH * 2; ++tn) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tn < NSUB && tn >= lo && tn < hi) {
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const s16x8 a = *(LDS_AS const s16x8*)(ktile + rf[ks] + tn * 16 * C::RS);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) s[rb][tn] = T16<T>::mfma(a, qf[rb][ks], s[rb][tn]);
+            }
+        }
+    }
+    s16x8 pf[RB][NH];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        float mloc = NEG_BIG;
+#pragma unroll
+        for (int tn = 0; tn < NH * 2; ++tn) {
+            if (tn >= NSUB) {
+                s[rb][tn] = (f32x4){NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
+            } else if (mode == 0 || (mode == 1 && tn < NSUB - 1)) {
+                s[rb][tn] *= sc2;
+                mloc = fmaxf(fmaxf(mloc, fmaxf(s[rb][tn][0], s[rb][tn][1])), fmaxf(s[rb][tn][2], s[rb][tn][3]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = key0 + tn * 16 + g * 4 + r;
+                    const float x = (tn >= lo && tn < hi && j < Sk) ? s[rb][tn][r] * sc2 : NEG_BIG;
+                    s[rb][tn][r] = x;
+                    mloc = fmaxf(mloc, x);
+                }
+            }
+        }
+        const float m_new = fmaxf(m_run[rb], group_max(mloc));
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        float lloc = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NH * 2; ++tn) {
+            if (tn >= NSUB) {
+                s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[rb][tn][r] - m_new);
+                    s[rb][tn][r] = e;
+                    lloc += e;
+                }
+            }
+        }
+        l_run[rb] = l_run[rb] * alpha + group_sum(lloc);
+        m_run[rb] = m_new;
+#pragma unroll
+        for (int t2 = 0; t2 < C::TD; ++t2) oacc[rb][t2] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < NH; ++s2) pf[rb][s2] = pack_pair<T>(s[rb][2 * s2], s[rb][2 * s2 + 1]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NH; ++s2) {
+        if (2 * s2 + 1 < lo || 2 * s2 >= hi) continue;   // no sub-tile of this 32-key half in range
 #pragma unroll
         for (int td = 0; td < C::TD; ++td) {
-            const int d = td * 16 + g * 4;
-            if (d < p.hd) *(s16x4*)(ob + d) = pack4<T>(oacc[td][0] * inv, oacc[td][1] * inv, oacc[td][2] * inv, oacc[td][3] * inv);
+            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vtile + tf[td] + s2 * 32 * C::RS));
+            const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vtile + tf[td] + s2 * 32 * C::RS + 16 * C::RS));
+            const s16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) oacc[rb][td] = T16<T>::mfma(a, pf[rb][s2], oacc[rb][td]);
         }
-        if (g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (m_run + __log2f(l_run)) * 0.6931471805599453f;
     }
+}
+
+template <int HDP> struct ResCfg {
+    static constexpr int NXMAX = HDP <= 96 ? 4 : 3;    // query rows beyond 256 (their partials live in the LDS left over by K/V)
+    static constexpr int PST = HDP + 2;                // floats per partial row: O[HDP], max, sum
+};
+
+template <typename T, int HDP>
+__global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                              const T* __restrict__ v, T* __restrict__ o,
+                                                              float* __restrict__ lse, const mico_attn_params p) {
+    using C = Cfg<HDP>;
+    using R = ResCfg<HDP>;
+    constexpr int CPR = HDP / 8;                  // 16-byte chunks per row
+    constexpr int NLD = 256 * CPR / 512;          // chunks per thread and matrix for rows 0..255
+    __shared__ __attribute__((aligned(16))) char smem[2 * RES_KR * C::RS + 8 * R::NXMAX * R::PST * 4];
+    LDS_AS char* kt = (LDS_AS char*)smem;
+    LDS_AS char* vt = kt + RES_KR * C::RS;
+    LDS_AS float* part = (LDS_AS float*)(vt + RES_KR * C::RS);   // [wave][NXMAX][PST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const float sc2 = p.scale * 1.4426950408889634f;
+    const int nitems = p.B * p.H;
+
+    // rows 256..287 start as zeros; rows Sk..287 stay zero for the whole kernel (the commits below only write rows < max(Sk, 256))
+    for (int c = tid; c < 32 * 16; c += 512) {
+        *(LDS_AS s16x8*)(kt + 256 * C::RS + c * 16) = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        *(LDS_AS s16x8*)(vt + 256 * C::RS + c * 16) = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    // this thread's chunks: rows 0..255 -> NLD per matrix; rows 256.. -> at most one
+    const int xrow = 256 + tid / CPR, xch = tid - (tid / CPR) * CPR;
+    const bool xlive = xrow < p.Sk && xch * 8 < p.hd;
+    const int xoff = xrow * C::RS + ((xch ^ ((xrow & 7) << 1)) << 4);
+
+    // lane-dependent, tile-relative LDS byte offsets of the row fragments (per k-step) and transposed fragments (per 16 head dims);
+    // sub-tile and 32-key-half displacements are immediates on top (the swizzle key only depends on row & 7)
+    int rf[C::KS], tf[C::TD];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) rf[ks] = (lane & 15) * C::RS + (((ks * 4 + g) ^ ((lane & 7) << 1)) << 4);
+    {
+        const int pp = lane & 15, r8 = g * 4 + (pp >> 2);
+#pragma unroll
+        for (int td = 0; td < C::TD; ++td) tf[td] = r8 * C::RS + (((td * 2 + ((pp >> 1) & 1)) ^ ((r8 & 7) << 1)) << 4) + (pp & 1) * 8;
+    }
+    // key steps: 64 keys each; the last one takes 80 when that saves a step
+    const int nst = (p.Sk + 15) >> 4;
+    constexpr bool WIDE = HDP <= 64;   // the 80-key step needs 24 more registers than hd 96 / 128 leave next to the prefetch
+    const bool wide_last = WIDE && nst > 4 && (nst & 3) == 1;
+    const int nsteps = wide_last ? (nst >> 2) : ((nst + 3) >> 2);
+    // the 17th query block: this wave's key sub-tiles [4*xt + xlo, 4*xt + xhi)
+    const int nx = p.Sq - 256;
+    const int xt = wave >> 1, xlo = (wave & 1) * 2;
+    const int xhi = wave == 7 ? nst - 12 : min(xlo + 2, nst - 4 * xt);   // wave 7: sub-tiles 14.. incl. the 17th (5-wide step template)
+
+    // buffer loads: 32-bit per-thread byte offsets (item invariant) against a per-item descriptor; dead chunks (row >= Sk, head-dim
+    // padding) point out of bounds and come back as zeros
+    unsigned kvo[NLD + 1];   // K and V share the offsets (the launcher requires k_rs == v_rs)
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int c = it * 512 + tid;
+        const int row = c / CPR, ch = c - row * CPR;
+        const bool live = row < p.Sk && ch * 8 < p.hd;
+        kvo[it] = live ? (unsigned)(row * p.k_rs * 2 + ch * 16) : 0xFFFFFFF0u;
+    }
+    kvo[NLD] = xlive ? (unsigned)(xrow * p.k_rs * 2 + xch * 16) : 0xFFFFFFF0u;
+    const int kbytes = (int)(((int64_t)(p.Sk - 1) * p.k_rs + p.hd) * 2), vbytes = (int)(((int64_t)(p.Sk - 1) * p.v_rs + p.hd) * 2);
+    // Q row fragments the same way (no divergent branches around the loads: the wait counts stay static)
+    const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2);
+    unsigned qvo[3][C::KS];
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int row = (rb < 2 ? wave * 32 + rb * 16 : 256) + (lane & 15), d = ks * 32 + g * 8;
+            qvo[rb][ks] = (row < p.Sq && d < p.hd) ? (unsigned)(row * p.q_rs * 2 + d * 2) : 0xFFFFFFF0u;
+        }
+    s16x8 kr[NLD + 1], vr[NLD + 1];
+    // The 2 (NLD + 1) loads of an item are issued in four parts spread over the key steps of the previous item: back to back
+    // they stall every wave for ~3000 cycles on the address/data path of the CU (tools/probes/attn_phases.py) and leave the
+    // waves staggered by that much.
+    auto prefetch_part = [&](int item, int part_id) {
+        const int b = item / p.H, h = item - b * p.H;
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * p.k_bs + h * p.hd), 0, kbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * p.v_bs + h * p.hd), 0, vbytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it <= NLD; ++it) {
+            if (it * 4 / (NLD + 1) != part_id) continue;
+            kr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, kvo[it], 0, 0));
+            vr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, kvo[it], 0, 0));
+        }
+    };
+    s16x8 qf[2][C::KS], qx[1][C::KS];
+    auto load_q = [&](int item) {
+        const int b = item / p.H, h = item - b * p.H;
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)b * p.q_bs + h * p.hd), 0, qbytes, 0x00020000);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            qf[0][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qvo[0][ks], 0, 0));
+            qf[1][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qvo[1][ks], 0, 0));
+            qx[0][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qvo[2][ks], 0, 0));
+        }
+    };
+    // merge of the eight key-slices of query rows 256.. of item `it` (partials in LDS) -> O rows and lse
+    auto merge = [&](int it) {
+        const int b = it / p.H, h = it - b * p.H;
+        for (int e = tid; e < nx * (HDP / 4); e += 512) {
+            const int row = e / (HDP / 4), d = (e - row * (HDP / 4)) * 4;
+            float M = NEG_BIG;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) M = fmaxf(M, part[(w * R::NXMAX + row) * R::PST + HDP]);
+            float L = 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                LDS_AS const float* pr = part + (w * R::NXMAX + row) * R::PST;
+                const float f = __builtin_amdgcn_exp2f(pr[HDP] - M);
+                L += pr[HDP + 1] * f;
+                acc[0] += pr[d] * f; acc[1] += pr[d + 1] * f; acc[2] += pr[d + 2] * f; acc[3] += pr[d + 3] * f;
+            }
+            const float inv = 1.f / L;
+            const int i = 256 + row;
+            if (d < p.hd) *(s16x4*)(o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd + d) = pack4<T>(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+            if (d == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (M + __log2f(L)) * 0.6931471805599453f;
+        }
+    };
+    // consecutive workgroups sit on different XCDs: give each XCD a contiguous range of items, so that the heads of one frame
+    // (interleaved pieces of the same QKV rows) meet in one L2
+    const int nwg = gridDim.x;
+    int item = (int)blockIdx.x;
+    int item_step = nwg;
+    if ((nwg & 7) == 0 && nitems % nwg == 0) {
+        const int per_wg = nitems / nwg;
+        item = ((int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3)) * per_wg;
+        item_step = 1;
+    }
+    const int item_end = item_step == 1 ? item + nitems / nwg : nitems;
+    if (item < item_end) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) prefetch_part(item, pt);
+        load_q(item);
+    }
+
+    int prev = -1;
+    PH_DECL;
+    for (; item < item_end; item += item_step) {
+        PH(7);
+        const int b = item / p.H, h = item - b * p.H;
+        const int next = item + item_step < item_end ? item + item_step : item;   // the last item re-fetches itself (static wait counts)
+        __syncthreads();   // every wave is done with the previous item's K/V and has written its partials
+        PH(0);
+        if (nx > 0 && prev >= 0) merge(prev);
+        PH(1);
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int c = it * 512 + tid;
+            const int row = c / CPR, ch = c - row * CPR;
+            const int off = row * C::RS + ((ch ^ ((row & 7) << 1)) << 4);
+            *(LDS_AS s16x8*)(kt + off) = kr[it];
+            *(LDS_AS s16x8*)(vt + off) = vr[it];
+        }
+        if (xlive) {
+            *(LDS_AS s16x8*)(kt + xoff) = kr[NLD];
+            *(LDS_AS s16x8*)(vt + xoff) = vr[NLD];
+        }
+        PH(2);
+        __syncthreads();
+        PH(3);
+        prefetch_part(next, 0);
+        PH(4);
+        if (nx > 0) {   // this wave's key slice of query rows 256..: partial (max, sum, O) -> LDS, merged at the next item's top
+            f32x4 ox[1][C::TD];
+            float mx[1] = {NEG_BIG}, lx[1] = {0.f};
+#pragma unroll
+            for (int t = 0; t < C::TD; ++t) ox[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xhi > xlo)
+                res_tile_step<T, HDP, 1, 5>(kt + xt * C::TILE, vt + xt * C::TILE, xt * 64, xlo, xhi, 2, qx, ox, mx, lx, p.Sk, sc2, lane, rf, tf);
+            if ((lane & 15) < nx) {
+                LDS_AS float* pr = part + (wave * R::NXMAX + (lane & 15)) * R::PST;
+                if (g == 0) { pr[HDP] = mx[0]; pr[HDP + 1] = lx[0]; }
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[td * 16 + g * 4 + r] = ox[0][td][r];
+            }
+        }
+        prev = item;
+        PH(5);
+        const bool main_live = wave * 32 < p.Sq;   // wave-uniform: this wave owns query rows of the main pass
+        const int i0 = wave * 32 + (lane & 15);
+        f32x4 oacc[2][C::TD];
+        float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < C::TD; ++t) {
+            oacc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            oacc[1][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // The step loop is unrolled by hand (at most 5 steps) with the prefetch parts as unconditional straight-line code in between:
+        // loads issued under control flow come back through copies at the loop back-edge, i.e. behind an s_waitcnt vmcnt(0).
+        auto key_step = [&](int t) {
+            if (!main_live || t >= nsteps) return;
+            LDS_AS const char* ktile = kt + t * C::TILE;
+            LDS_AS const char* vtile = vt + t * C::TILE;
+            if (WIDE && t == nsteps - 1 && wide_last) {
+                res_tile_step<T, HDP, 2, 5>(ktile, vtile, t * 64, 0, 5, (p.Sk & 15) ? 1 : 0, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
+            } else {
+                const int ntn = min(4, nst - 4 * t);
+                res_tile_step<T, HDP, 2, 4>(ktile, vtile, t * 64, 0, ntn, (ntn == 4 && t * 64 + 64 <= p.Sk) ? 0 : 2, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
+            }
+        };
+        key_step(0);
+        prefetch_part(next, 1);
+        key_step(1);
+        prefetch_part(next, 2);
+        key_step(2);
+        prefetch_part(next, 3);
+        key_step(3);
+        key_step(4);
+        load_q(next);   // qf / qx are dead from here on: the next item's query fragments take their registers
+        PH(6);
+        if (main_live) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int i = i0 + rb * 16;
+                if (i < p.Sq) {
+                    const float inv = 1.f / l_run[rb];
+                    T* ob = o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd;
+#pragma unroll
+                    for (int td = 0; td < C::TD; ++td) {
+                        const int d = td * 16 + g * 4;
+                        if (d < p.hd)
+                            *(s16x4*)(ob + d) = pack4<T>(oacc[rb][td][0] * inv, oacc[rb][td][1] * inv, oacc[rb][td][2] * inv, oacc[rb][td][3] * inv);
+                    }
+                    if (g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (m_run[rb] + __log2f(l_run[rb])) * 0.6931471805599453f;
+                }
+            }
+        }
+    }
+    if (nx > 0 && prev >= 0) {
+        __syncthreads();
+        merge(prev);
+    }
+#ifdef MICO_ATTN_PHASES
+    if (lane == 0 && wave == 0 && blockIdx.x < 4096) for (int e_ = 0; e_ < 8; ++e_) g_attn_phase[blockIdx.x * 8 + e_] = ph_acc[e_];
+#endif
 }
 
 // ======================================================================================================================
@@ -506,14 +891,43 @@ int check_params(const mico_attn_params* p, const char* who) {
         else { constexpr int HDP = 128; __VA_ARGS__; }   \
     } while (0)
 
+#ifdef MICO_ATTN_PHASES
+extern "C" int mico_debug_attn_phases(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_phase), sizeof(unsigned long long) * n);
+}
+#endif
+
 extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const mico_attn_params* p,
                              int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype) && q && k && v && o && lse, "mico_attn_fwd: bad args");
     int rc = check_params(p, "mico_attn_fwd");
     if (rc) return rc;
-    const dim3 grid((p->Sq + 63) / 64, p->H, p->B), block(256);
+    const dim3 block(256);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_fwd_kernel<T, HDP, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p); else MICO_LAUNCH((attn_fwd_kernel<T, HDP, false>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p); }));
+    // two query blocks per wave for long unmasked attention without dropout (the ViT towers); one for the short BERT sequences
+    static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;   // A/B switch for tools/attn_bench.py, tools/probes/attn_phases.py
+    // K/V-resident persistent kernel: unmasked self-attention of the ViT towers (hd 128 would spill next to the prefetch registers)
+    if (!no_res && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 && p->Sq <= 256 + ResCfg<96>::NXMAX) {
+        static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int nitems = p->B * p->H;
+        const dim3 grid(nitems < n_cu ? nitems : n_cu);
+        DISPATCH_T16(dtype, {
+            if (p->hd <= 64) MICO_LAUNCH((attn_fwd_res_kernel<T, 64>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p);
+            else MICO_LAUNCH((attn_fwd_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p);
+        });
+        MICO_LAUNCH_CHECK();
+        return MICO_OK;
+    }
+    const bool two = p->Sq > 128 && p->drop_p <= 0.f && p->mask_mode == 0;
+    const int qpw = two ? 128 : 64;
+    const dim3 grid((p->Sq + qpw - 1) / qpw, p->H, p->B);
+#define ATTN_FWD_LAUNCH(DROP, RB) MICO_LAUNCH((attn_fwd_kernel<T, HDP, DROP, RB>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p)
+    DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, {
+        if (two) ATTN_FWD_LAUNCH(false, 2);
+        else if (p->drop_p > 0.f) ATTN_FWD_LAUNCH(true, 1);
+        else ATTN_FWD_LAUNCH(false, 1);
+    }));
+#undef ATTN_FWD_LAUNCH
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

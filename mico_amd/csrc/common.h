@@ -126,16 +126,40 @@ __device__ __forceinline__ float drop_mult(unsigned seed, int site, unsigned lon
 }
 __host__ __device__ __forceinline__ unsigned drop_threshold(float p) { return (unsigned)(p * 16777216.f); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane steps without the LDS crossbar (ds_bpermute costs ~100 cycles of latency per step on the critical path of every
+// row reduction): DPP adds inside a row of 16 lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows - called with the
+// same value in both registers a swap leaves {own half, partner half}, whose combination is the xor-16 / xor-32 exchange.
+// (inline asm: hipcc 7.2 lowers the second result of __builtin_amdgcn_permlane{16,32}_swap to the first one's register; the
+// s_nop covers the VALU-write -> swap-read hazard the compiler would otherwise pad)
+#define MICO_XLANE(NAME, INSN, OP)                                                  \
+    __device__ __forceinline__ float NAME(float v) {                                 \
+        float a = v, b = v;                                                          \
+        asm volatile("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));               \
+        return OP;                                                                   \
+    }
+MICO_XLANE(xor16_sum, "v_permlane16_swap_b32", a + b)
+MICO_XLANE(xor32_sum, "v_permlane32_swap_b32", a + b)
+MICO_XLANE(xor16_max, "v_permlane16_swap_b32", fmaxf(a, b))
+MICO_XLANE(xor32_max, "v_permlane32_swap_b32", fmaxf(a, b))
+#undef MICO_XLANE
+#define MICO_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+__device__ __forceinline__ float row16_sum(float v) {   // every lane ends with the sum over its row of 16 lanes
+    v += MICO_DPP_F32(v, 0xb1);    // quad_perm [1,0,3,2]
+    v += MICO_DPP_F32(v, 0x4e);    // quad_perm [2,3,0,1]
+    v += MICO_DPP_F32(v, 0x124);   // row_ror:4
+    v += MICO_DPP_F32(v, 0x128);   // row_ror:8
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, MICO_DPP_F32(v, 0xb1));
+    v = fmaxf(v, MICO_DPP_F32(v, 0x4e));
+    v = fmaxf(v, MICO_DPP_F32(v, 0x124));
+    v = fmaxf(v, MICO_DPP_F32(v, 0x128));
     return v;
 }
+#undef MICO_DPP_F32
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // Transposed LDS read (ds_read_b64_tr_b16): within each 16-lane group, lane p supplies the address of 4
 // contiguous 16-bit elements [row p>>2][cols (p&3)*4..+3] of a 4x16 block; lane i receives column i (4 rows).

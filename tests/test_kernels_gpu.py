@@ -134,6 +134,34 @@ def _attn_ref(q, k, v, scale, mask):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,hd", [(65, 64), (129, 88), (197, 64), (256, 88), (257, 88), (257, 64), (260, 64), (261, 88), (272, 88)])
+def test_attention_self_rowwise(cuda, dtype, S, hd):
+    """Unmasked self-attention at every row-count class of the K/V-resident kernel (<= 256 rows: main pass only; 257..272: the
+    17th query block split over the keys; 273: back on the tiled kernel) - checked ROW BY ROW (a global norm would hide one bad
+    token among 257), together with the log-sum-exp the backward consumes."""
+    from mico_amd import ops
+    torch.manual_seed(S)
+    B, H = 2, 3
+    D = H * hd
+    qkv = (0.7 * torch.randn(B, S, 3 * D, device=cuda)).to(dtype)
+    qkv[:, S - 1, 2 * D:] *= 30      # a dropped last key (the ragged 17th sub-tile) must not hide in the noise
+    qkv[:, 0, 2 * D:] *= 30
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    scale = hd ** -0.5
+    qf, kf, vf = (t.float().reshape(B, S, H, hd) for t in (q, k, v))
+    sc = torch.einsum("bihd,bjhd->bhij", qf, kf) * scale
+    ref = torch.einsum("bhij,bjhd->bihd", sc.softmax(-1), vf).reshape(B, S, D)
+    o = torch.full((B, S, D), float("nan"), device=cuda, dtype=dtype)
+    lse = torch.full((B, H, S), float("nan"), device=cuda)
+    ops.attn_fwd(q, k, v, o, lse, B=B, H=H, Sq=S, Sk=S, hd=hd, scale=scale, q_strides=(S * 3 * D, 3 * D),
+                 k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
+    torch.cuda.synchronize()
+    row_err = (o.float() - ref).norm(dim=-1) / ref.norm(dim=-1)
+    assert torch.isfinite(row_err).all() and row_err.max() < tol(dtype, 4), (row_err.max(), row_err.argmax())
+    assert (lse - sc.logsumexp(-1)).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["vit_g", "vit_b", "bert_self2d", "bert_self3d", "bert_cross"])
 def test_attention(cuda, dtype, case):
     from mico_amd import ops
