@@ -308,7 +308,10 @@ constexpr int RES_KR = 288;   // resident key rows (272 rounded up to the 32 key
 
 // One step over NSUB 16-key sub-tiles starting at LDS row pointers ktile / vtile (global key index key0), restricted to sub-tiles
 // [lo, hi).  mode 0: all NSUB sub-tiles in range and inside Sk; 1: as 0 but the last sub-tile is ragged; 2: general.
-template <typename T, int HDP, int RB, int NSUB>
+// ALL: every sub-tile is in range (lo = 0, hi = NSUB) - no per-sub-tile branches, so each of the two MFMA phases is one basic block and
+// the compiler can run its LDS fragment reads many MFMAs ahead (with the branches it waited on nearly every read: ~30 exposed LDS
+// latencies per step, tools/probes/attn_phases.py: 4400 cycles per step against ~1500 of issue work).
+template <typename T, int HDP, int RB, int NSUB, bool ALL>
 __device__ __forceinline__ void res_tile_step(LDS_AS const char* ktile, LDS_AS const char* vtile, const int key0, const int lo,
                                               const int hi, const int mode, const s16x8 (&qf)[RB][Cfg<HDP>::KS],
                                               f32x4 (&oacc)[RB][Cfg<HDP>::TD], float (&m_run)[RB], float (&l_run)[RB],
@@ -318,16 +321,41 @@ __device__ __forceinline__ void res_tile_step(LDS_AS const char* ktile, LDS_AS c
     constexpr int NH = (NSUB + 1) / 2;
     const int g = lane >> 4;
     f32x4 s[RB][NH * 2];
+    if (ALL) {   // fragments of sub-tile tn + 1 are requested before the MFMAs of sub-tile tn are issued; the order is pinned
+        s16x8 an[C::KS];
 #pragma unroll
-    for (int tn = 0; tn < NH * 2; ++tn) {
+        for (int ks = 0; ks < C::KS; ++ks) an[ks] = *(LDS_AS const s16x8*)(ktile + rf[ks]);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (tn < NSUB && tn >= lo && tn < hi) {
+        for (int tn = 0; tn < NH * 2; ++tn) {
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                const s16x8 a = *(LDS_AS const s16x8*)(ktile + rf[ks] + tn * 16 * C::RS);
+            for (int rb = 0; rb < RB; ++rb) s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tn >= NSUB) continue;
+            s16x8 ac[C::KS];
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) s[rb][tn] = T16<T>::mfma(a, qf[rb][ks], s[rb][tn]);
+            for (int ks = 0; ks < C::KS; ++ks) ac[ks] = an[ks];
+            if (tn + 1 < NSUB) {
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) an[ks] = *(LDS_AS const s16x8*)(ktile + rf[ks] + (tn + 1) * 16 * C::RS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) s[rb][tn] = T16<T>::mfma(ac[ks], qf[rb][ks], s[rb][tn]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < NH * 2; ++tn) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tn < NSUB && tn >= lo && tn < hi) {
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    const s16x8 a = *(LDS_AS const s16x8*)(ktile + rf[ks] + tn * 16 * C::RS);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) s[rb][tn] = T16<T>::mfma(a, qf[rb][ks], s[rb][tn]);
+                }
             }
         }
     }
@@ -343,10 +371,12 @@ __device__ __forceinline__ void res_tile_step(LDS_AS const char* ktile, LDS_AS c
                 s[rb][tn] *= sc2;
                 mloc = fmaxf(fmaxf(mloc, fmaxf(s[rb][tn][0], s[rb][tn][1])), fmaxf(s[rb][tn][2], s[rb][tn][3]));
             } else {
+                // one uniform limit per sub-tile and a lane compare per element (per-element uniform conditions end up as spilled
+                // SGPR pairs read back lane by lane)
+                const int lim = (ALL || (tn >= lo && tn < hi)) ? Sk - key0 - tn * 16 - g * 4 : 0;   // this lane's keys r < lim are real
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = key0 + tn * 16 + g * 4 + r;
-                    const float x = (tn >= lo && tn < hi && j < Sk) ? s[rb][tn][r] * sc2 : NEG_BIG;
+                    const float x = r < lim ? s[rb][tn][r] * sc2 : NEG_BIG;
                     s[rb][tn][r] = x;
                     mloc = fmaxf(mloc, x);
                 }
@@ -375,16 +405,36 @@ __device__ __forceinline__ void res_tile_step(LDS_AS const char* ktile, LDS_AS c
 #pragma unroll
         for (int s2 = 0; s2 < NH; ++s2) pf[rb][s2] = pack_pair<T>(s[rb][2 * s2], s[rb][2 * s2 + 1]);
     }
+    auto vfrag = [&](int idx) -> s16x8 {   // idx = s2 * TD + td
+        const int s2 = idx / C::TD, td = idx - s2 * C::TD;
+        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vtile + tf[td] + s2 * 32 * C::RS));
+        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vtile + tf[td] + s2 * 32 * C::RS + 16 * C::RS));
+        return (s16x8){alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+    };
+    if (ALL) {   // three V^T fragments in flight ahead of the MFMAs
+        constexpr int NF = NH * C::TD, AH = 3;
+        s16x8 ring[AH];
 #pragma unroll
-    for (int s2 = 0; s2 < NH; ++s2) {
-        if (2 * s2 + 1 < lo || 2 * s2 >= hi) continue;   // no sub-tile of this 32-key half in range
+        for (int i = 0; i < AH; ++i) ring[i] = vfrag(i);
 #pragma unroll
-        for (int td = 0; td < C::TD; ++td) {
-            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vtile + tf[td] + s2 * 32 * C::RS));
-            const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vtile + tf[td] + s2 * 32 * C::RS + 16 * C::RS));
-            const s16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+        for (int i = 0; i < NF; ++i) {
+            const s16x8 a = ring[i % AH];
+            if (i + AH < NF) ring[i % AH] = vfrag(i + AH);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) oacc[rb][td] = T16<T>::mfma(a, pf[rb][s2], oacc[rb][td]);
+            for (int rb = 0; rb < RB; ++rb) oacc[rb][i % C::TD] = T16<T>::mfma(a, pf[rb][i / C::TD], oacc[rb][i % C::TD]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int s2 = 0; s2 < NH; ++s2) {
+            if (2 * s2 + 1 < lo || 2 * s2 >= hi) continue;   // no sub-tile of this 32-key half in range
+#pragma unroll
+            for (int td = 0; td < C::TD; ++td) {
+                const s16x8 a = vfrag(s2 * C::TD + td);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) oacc[rb][td] = T16<T>::mfma(a, pf[rb][s2], oacc[rb][td]);
+            }
         }
     }
 }
@@ -443,40 +493,39 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
 
     // buffer loads: 32-bit per-thread byte offsets (item invariant) against a per-item descriptor; dead chunks (row >= Sk, head-dim
     // padding) point out of bounds and come back as zeros
-    unsigned kvo[NLD + 1];   // K and V share the offsets (the launcher requires k_rs == v_rs)
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
+    // (K and V share the offsets: the launcher requires k_rs == v_rs; recomputed per use - a handful of integer operations against 16 registers)
+    auto kv_off = [&](int it) -> unsigned {
+        if (it == NLD) return xlive ? (unsigned)(xrow * p.k_rs * 2 + xch * 16) : 0xFFFFFFF0u;
         const int c = it * 512 + tid;
         const int row = c / CPR, ch = c - row * CPR;
-        const bool live = row < p.Sk && ch * 8 < p.hd;
-        kvo[it] = live ? (unsigned)(row * p.k_rs * 2 + ch * 16) : 0xFFFFFFF0u;
-    }
-    kvo[NLD] = xlive ? (unsigned)(xrow * p.k_rs * 2 + xch * 16) : 0xFFFFFFF0u;
+        return (row < p.Sk && ch * 8 < p.hd) ? (unsigned)(row * p.k_rs * 2 + ch * 16) : 0xFFFFFFF0u;
+    };
     const int kbytes = (int)(((int64_t)(p.Sk - 1) * p.k_rs + p.hd) * 2), vbytes = (int)(((int64_t)(p.Sk - 1) * p.v_rs + p.hd) * 2);
     // Q row fragments the same way (no divergent branches around the loads: the wait counts stay static)
     const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2);
-    unsigned qvo[3][C::KS];
-#pragma unroll
-    for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-            const int row = (rb < 2 ? wave * 32 + rb * 16 : 256) + (lane & 15), d = ks * 32 + g * 8;
-            qvo[rb][ks] = (row < p.Sq && d < p.hd) ? (unsigned)(row * p.q_rs * 2 + d * 2) : 0xFFFFFFF0u;
-        }
+    auto q_off = [&](int rb, int ks) -> unsigned {
+        const int row = (rb < 2 ? wave * 32 + rb * 16 : 256) + (lane & 15), d = ks * 32 + g * 8;
+        return (row < p.Sq && d < p.hd) ? (unsigned)(row * p.q_rs * 2 + d * 2) : 0xFFFFFFF0u;
+    };
     s16x8 kr[NLD + 1], vr[NLD + 1];
-    // The 2 (NLD + 1) loads of an item are issued in four parts spread over the key steps of the previous item: back to back
-    // they stall every wave for ~3000 cycles on the address/data path of the CU (tools/probes/attn_phases.py) and leave the
-    // waves staggered by that much.
+    // The next item's K chunks are requested in four parts spread over the key steps of the current item (back to back they stall every
+    // wave for ~3000 cycles on the address / data path of the CU and leave the waves staggered by that much); its V chunks and query
+    // fragments follow right after the last step, into the registers the score tiles no longer need - they have the output stores, the
+    // barrier and the merge to arrive.
     auto prefetch_part = [&](int item, int part_id) {
         const int b = item / p.H, h = item - b * p.H;
         __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * p.k_bs + h * p.hd), 0, kbytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * p.v_bs + h * p.hd), 0, vbytes, 0x00020000);
 #pragma unroll
         for (int it = 0; it <= NLD; ++it) {
             if (it * 4 / (NLD + 1) != part_id) continue;
-            kr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, kvo[it], 0, 0));
-            vr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, kvo[it], 0, 0));
+            kr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, kv_off(it), 0, 0));
         }
+    };
+    auto load_v = [&](int item) {
+        const int b = item / p.H, h = item - b * p.H;
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * p.v_bs + h * p.hd), 0, vbytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it <= NLD; ++it) vr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, kv_off(it), 0, 0));
     };
     s16x8 qf[2][C::KS], qx[1][C::KS];
     auto load_q = [&](int item) {
@@ -484,9 +533,9 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
         __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)b * p.q_bs + h * p.hd), 0, qbytes, 0x00020000);
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-            qf[0][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qvo[0][ks], 0, 0));
-            qf[1][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qvo[1][ks], 0, 0));
-            qx[0][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qvo[2][ks], 0, 0));
+            qf[0][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off(0, ks), 0, 0));
+            qf[1][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off(1, ks), 0, 0));
+            qx[0][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, q_off(2, ks), 0, 0));
         }
     };
     // merge of the eight key-slices of query rows 256.. of item `it` (partials in LDS) -> O rows and lse
@@ -526,6 +575,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
     if (item < item_end) {
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) prefetch_part(item, pt);
+        load_v(item);
         load_q(item);
     }
 
@@ -562,7 +612,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
 #pragma unroll
             for (int t = 0; t < C::TD; ++t) ox[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (xhi > xlo)
-                res_tile_step<T, HDP, 1, 5>(kt + xt * C::TILE, vt + xt * C::TILE, xt * 64, xlo, xhi, 2, qx, ox, mx, lx, p.Sk, sc2, lane, rf, tf);
+                res_tile_step<T, HDP, 1, 5, false>(kt + xt * C::TILE, vt + xt * C::TILE, xt * 64, xlo, xhi, 2, qx, ox, mx, lx, p.Sk, sc2, lane, rf, tf);
             if ((lane & 15) < nx) {
                 LDS_AS float* pr = part + (wave * R::NXMAX + (lane & 15)) * R::PST;
                 if (g == 0) { pr[HDP] = mx[0]; pr[HDP + 1] = lx[0]; }
@@ -590,10 +640,11 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
             LDS_AS const char* ktile = kt + t * C::TILE;
             LDS_AS const char* vtile = vt + t * C::TILE;
             if (WIDE && t == nsteps - 1 && wide_last) {
-                res_tile_step<T, HDP, 2, 5>(ktile, vtile, t * 64, 0, 5, (p.Sk & 15) ? 1 : 0, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
+                res_tile_step<T, HDP, 2, 5, true>(ktile, vtile, t * 64, 0, 5, (p.Sk & 15) ? 1 : 0, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
             } else {
                 const int ntn = min(4, nst - 4 * t);
-                res_tile_step<T, HDP, 2, 4>(ktile, vtile, t * 64, 0, ntn, (ntn == 4 && t * 64 + 64 <= p.Sk) ? 0 : 2, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
+                if (ntn == 4) res_tile_step<T, HDP, 2, 4, true>(ktile, vtile, t * 64, 0, 4, t * 64 + 64 <= p.Sk ? 0 : 1, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
+                else res_tile_step<T, HDP, 2, 4, false>(ktile, vtile, t * 64, 0, ntn, 2, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
             }
         };
         key_step(0);
@@ -604,6 +655,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
         prefetch_part(next, 3);
         key_step(3);
         key_step(4);
+        load_v(next);
         load_q(next);   // qf / qx are dead from here on: the next item's query fragments take their registers
         PH(6);
         if (main_live) {
@@ -629,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
         merge(prev);
     }
 #ifdef MICO_ATTN_PHASES
-    if (lane == 0 && wave == 0 && blockIdx.x < 4096) for (int e_ = 0; e_ < 8; ++e_) g_attn_phase[blockIdx.x * 8 + e_] = ph_acc[e_];
+    if (lane == 0 && blockIdx.x < 512) for (int e_ = 0; e_ < 8; ++e_) g_attn_phase[(blockIdx.x * 8 + wave) * 8 + e_] = ph_acc[e_];   // per wave
 #endif
 }
 
@@ -750,6 +802,318 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
 }
 
 // ======================================================================================================================
+// backward dQ, K/V-resident variant (same eligibility, work split and ragged-end handling as attn_fwd_res_kernel): persistent 8-wave
+// workgroups, K and V of one (b, h) in LDS, two 16-query blocks per wave, no barrier inside the key loop; the 17th query block is
+// split over the keys and its eight partial dQ tiles are summed through LDS.  No register prefetch of the next item here: the two
+// score tiles (S and dP) take the registers the forward kernel spends on it.
+// ======================================================================================================================
+template <typename T, int HDP, int RB, int NSUB, bool ALL>
+__device__ __forceinline__ void res_dq_step(LDS_AS const char* ktile, LDS_AS const char* vtile, const int key0, const int lo,
+                                            const int hi, const bool full, const s16x8 (&qf)[RB][Cfg<HDP>::KS],
+                                            const s16x8 (&dof)[RB][Cfg<HDP>::KS], f32x4 (&dqacc)[RB][Cfg<HDP>::TD],
+                                            const float (&lse2)[RB], const float (&dl)[RB], const int Sk, const float scale,
+                                            const int lane, const int (&rf)[Cfg<HDP>::KS], const int (&tf)[Cfg<HDP>::TD]) {
+    using C = Cfg<HDP>;
+    constexpr int NH = (NSUB + 1) / 2;
+    const int g = lane >> 4;
+    const float sc2 = scale * 1.4426950408889634f;
+    f32x4 s[RB][NH * 2], dp[RB][NH * 2];
+    if (ALL) {   // K / V fragments of sub-tile tn + 1 are requested before the MFMAs of sub-tile tn are issued; the order is pinned
+        s16x8 an[C::KS], cn[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            an[ks] = *(LDS_AS const s16x8*)(ktile + rf[ks]);
+            cn[ks] = *(LDS_AS const s16x8*)(vtile + rf[ks]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < NH * 2; ++tn) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (tn >= NSUB) continue;
+            s16x8 ac[C::KS], cc[C::KS];
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) { ac[ks] = an[ks]; cc[ks] = cn[ks]; }
+            if (tn + 1 < NSUB) {
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    an[ks] = *(LDS_AS const s16x8*)(ktile + rf[ks] + (tn + 1) * 16 * C::RS);
+                    cn[ks] = *(LDS_AS const s16x8*)(vtile + rf[ks] + (tn + 1) * 16 * C::RS);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    s[rb][tn] = T16<T>::mfma(ac[ks], qf[rb][ks], s[rb][tn]);
+                    dp[rb][tn] = T16<T>::mfma(cc[ks], dof[rb][ks], dp[rb][tn]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < NH * 2; ++tn) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                s[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[rb][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (tn < NSUB && tn >= lo && tn < hi) {
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    const s16x8 a = *(LDS_AS const s16x8*)(ktile + rf[ks] + tn * 16 * C::RS);
+                    const s16x8 c = *(LDS_AS const s16x8*)(vtile + rf[ks] + tn * 16 * C::RS);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        s[rb][tn] = T16<T>::mfma(a, qf[rb][ks], s[rb][tn]);
+                        dp[rb][tn] = T16<T>::mfma(c, dof[rb][ks], dp[rb][tn]);
+                    }
+                }
+            }
+        }
+    }
+    s16x8 df[RB][NH];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int tn = 0; tn < NH * 2; ++tn) {
+            const int lim = full ? 4 : ((tn < NSUB && (ALL || (tn >= lo && tn < hi))) ? Sk - key0 - tn * 16 - g * 4 : 0);   // lane's keys r < lim are real
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(s[rb][tn][r] * sc2 - lse2[rb]);
+                const float d = pr * (dp[rb][tn][r] - dl[rb]) * scale;
+                s[rb][tn][r] = r < lim ? d : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NH; ++s2) df[rb][s2] = pack_pair<T>(s[rb][2 * s2], s[rb][2 * s2 + 1]);
+    }
+    auto kfrag = [&](int idx) -> s16x8 {   // idx = s2 * TD + td
+        const int s2 = idx / C::TD, td = idx - s2 * C::TD;
+        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ktile + tf[td] + s2 * 32 * C::RS));
+        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(ktile + tf[td] + s2 * 32 * C::RS + 16 * C::RS));
+        return (s16x8){alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+    };
+    if (ALL) {
+        constexpr int NF = NH * C::TD, AH = 3;
+        s16x8 ring[AH];
+#pragma unroll
+        for (int i = 0; i < AH; ++i) ring[i] = kfrag(i);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const s16x8 a = ring[i % AH];
+            if (i + AH < NF) ring[i % AH] = kfrag(i + AH);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) dqacc[rb][i % C::TD] = T16<T>::mfma(a, df[rb][i / C::TD], dqacc[rb][i % C::TD]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int s2 = 0; s2 < NH; ++s2) {
+            if (2 * s2 + 1 < lo || 2 * s2 >= hi) continue;
+#pragma unroll
+            for (int td = 0; td < C::TD; ++td) {
+                const s16x8 a = kfrag(s2 * C::TD + td);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) dqacc[rb][td] = T16<T>::mfma(a, df[rb][s2], dqacc[rb][td]);
+            }
+        }
+    }
+}
+
+template <typename T, int HDP>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dq_res_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                 const T* __restrict__ v, const T* __restrict__ o,
+                                                                 const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                                 T* __restrict__ dq, float* __restrict__ delta,
+                                                                 const mico_attn_params p) {
+    using C = Cfg<HDP>;
+    using R = ResCfg<HDP>;
+    constexpr int CPR = HDP / 8;
+    constexpr int NLD = 256 * CPR / 512;
+    __shared__ __attribute__((aligned(16))) char smem[2 * RES_KR * C::RS + 8 * R::NXMAX * R::PST * 4];
+    LDS_AS char* kt = (LDS_AS char*)smem;
+    LDS_AS char* vt = kt + RES_KR * C::RS;
+    LDS_AS float* part = (LDS_AS float*)(vt + RES_KR * C::RS);   // [wave][NXMAX][PST] partial dQ rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int nitems = p.B * p.H;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    for (int c = tid; c < 32 * 16; c += 512) {
+        *(LDS_AS s16x8*)(kt + 256 * C::RS + c * 16) = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        *(LDS_AS s16x8*)(vt + 256 * C::RS + c * 16) = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const int xrow = 256 + tid / CPR, xch = tid - (tid / CPR) * CPR;
+    const bool xlive = xrow < p.Sk && xch * 8 < p.hd;
+    const int xoff = xrow * C::RS + ((xch ^ ((xrow & 7) << 1)) << 4);
+    int rf[C::KS], tf[C::TD];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) rf[ks] = (lane & 15) * C::RS + (((ks * 4 + g) ^ ((lane & 7) << 1)) << 4);
+    {
+        const int pp = lane & 15, r8 = g * 4 + (pp >> 2);
+#pragma unroll
+        for (int td = 0; td < C::TD; ++td) tf[td] = r8 * C::RS + (((td * 2 + ((pp >> 1) & 1)) ^ ((r8 & 7) << 1)) << 4) + (pp & 1) * 8;
+    }
+    const int nst = (p.Sk + 15) >> 4;
+    const int nsteps = (nst + 3) >> 2;
+    const int nx = p.Sq - 256;
+    const int xt = wave >> 1, xlo = (wave & 1) * 2;
+    const int xhi = wave == 7 ? nst - 12 : min(xlo + 2, nst - 4 * xt);
+    const int kbytes = (int)(((int64_t)(p.Sk - 1) * p.k_rs + p.hd) * 2), vbytes = (int)(((int64_t)(p.Sk - 1) * p.v_rs + p.hd) * 2);
+    const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2), obytes = (int)(((int64_t)(p.Sq - 1) * p.o_rs + p.hd) * 2);
+
+    // sum of the eight key-slices of dQ rows 256.. of item `it`
+    auto merge = [&](int it) {
+        const int b = it / p.H, h = it - b * p.H;
+        for (int e = tid; e < nx * (HDP / 4); e += 512) {
+            const int row = e / (HDP / 4), d = (e - row * (HDP / 4)) * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                LDS_AS const float* pr = part + (w * R::NXMAX + row) * R::PST;
+                acc[0] += pr[d]; acc[1] += pr[d + 1]; acc[2] += pr[d + 2]; acc[3] += pr[d + 3];
+            }
+            if (d < p.hd) *(s16x4*)(dq + (int64_t)b * p.q_bs + (int64_t)(256 + row) * p.q_rs + h * p.hd + d) = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+        }
+    };
+    const int nwg = gridDim.x;
+    int item = (int)blockIdx.x;
+    int item_step = nwg;
+    if ((nwg & 7) == 0 && nitems % nwg == 0) {
+        const int per_wg = nitems / nwg;
+        item = ((int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3)) * per_wg;
+        item_step = 1;
+    }
+    const int item_end = item_step == 1 ? item + nitems / nwg : nitems;
+
+    int prev = -1;
+    for (; item < item_end; item += item_step) {
+        const int b = item / p.H, h = item - b * p.H;
+        const int64_t stat_base = ((int64_t)b * p.H + h) * p.Sq;
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * p.k_bs + h * p.hd), 0, kbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * p.v_bs + h * p.hd), 0, vbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)b * p.q_bs + h * p.hd), 0, qbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(o + (int64_t)b * p.o_bs + h * p.hd), 0, obytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(d_o + (int64_t)b * p.o_bs + h * p.hd), 0, obytes, 0x00020000);
+        // ---- K, V -> registers -> LDS; this wave's query-side operands: rows wave*32 + {0, 16} + (lane & 15), and rows 256.. ----------
+        // (O is only needed for delta = rowsum(dO * O): it is fetched after the K/V staging registers are free again)
+        s16x8 qf[2][C::KS], dof[2][C::KS], qx[1][C::KS], dox[1][C::KS];
+        float dl[2], lse2[2], dlx[1], lsx[1];
+        auto row_of = [&](int rb) { return (rb < 2 ? wave * 32 + rb * 16 : 256) + (lane & 15); };
+        {
+            s16x8 kr[NLD + 1], vr[NLD + 1];
+#pragma unroll
+            for (int it = 0; it <= NLD; ++it) {
+                const int c = it * 512 + tid;
+                const int row = it < NLD ? c / CPR : xrow, ch = it < NLD ? c - (c / CPR) * CPR : xch;
+                const bool live = it < NLD ? (row < p.Sk && ch * 8 < p.hd) : xlive;
+                const unsigned off = live ? (unsigned)(row * p.k_rs * 2 + ch * 16) : 0xFFFFFFF0u;
+                kr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+                vr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+            }
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    const int row = row_of(rb), d = ks * 32 + g * 8;
+                    const bool live = row < p.Sq && d < p.hd;
+                    const s16x8 qv = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, live ? (unsigned)(row * p.q_rs * 2 + d * 2) : 0xFFFFFFF0u, 0, 0));
+                    const s16x8 dv = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rd, live ? (unsigned)(row * p.o_rs * 2 + d * 2) : 0xFFFFFFF0u, 0, 0));
+                    if (rb < 2) { qf[rb][ks] = qv; dof[rb][ks] = dv; } else { qx[0][ks] = qv; dox[0][ks] = dv; }
+                }
+            __syncthreads();   // every wave is done with the previous item's K/V and has written its partials
+            if (nx > 0 && prev >= 0) merge(prev);
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int c = it * 512 + tid;
+                const int row = c / CPR, ch = c - row * CPR;
+                const int off = row * C::RS + ((ch ^ ((row & 7) << 1)) << 4);
+                *(LDS_AS s16x8*)(kt + off) = kr[it];
+                *(LDS_AS s16x8*)(vt + off) = vr[it];
+            }
+            if (xlive) {
+                *(LDS_AS s16x8*)(kt + xoff) = kr[NLD];
+                *(LDS_AS s16x8*)(vt + xoff) = vr[NLD];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const int row = row_of(rb);
+            float acc = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const int d = ks * 32 + g * 8;
+                const unsigned oo = (row < p.Sq && d < p.hd) ? (unsigned)(row * p.o_rs * 2 + d * 2) : 0xFFFFFFF0u;
+                const s16x8 ov = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, oo, 0, 0));
+                float a8[8], c8[8];
+                unpack8<T>(ov, a8);
+                unpack8<T>(rb < 2 ? dof[rb][ks] : dox[0][ks], c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += a8[e] * c8[e];
+            }
+            acc = group_sum(acc);
+            float l = 0.f;
+            if (row < p.Sq) {
+                l = lse[stat_base + row];
+                if (g == 0 && (rb < 2 || wave == 0)) delta[stat_base + row] = acc;
+            }
+            if (rb < 2) { dl[rb] = acc; lse2[rb] = l * LOG2E; } else { dlx[0] = acc; lsx[0] = l * LOG2E; }
+        }
+        __syncthreads();
+        // ---- dQ rows 256..: this wave's key slice -> partial tile in LDS, summed at the next item's top ---------------------------
+        if (nx > 0) {
+            f32x4 ox[1][C::TD];
+#pragma unroll
+            for (int t = 0; t < C::TD; ++t) ox[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xhi > xlo)
+                res_dq_step<T, HDP, 1, 5, false>(kt + xt * C::TILE, vt + xt * C::TILE, xt * 64, xlo, xhi, false, qx, dox, ox, lsx, dlx, p.Sk, p.scale, lane, rf, tf);
+            if ((lane & 15) < nx) {
+                LDS_AS float* pr = part + (wave * R::NXMAX + (lane & 15)) * R::PST;
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[td * 16 + g * 4 + r] = ox[0][td][r];
+            }
+        }
+        prev = item;
+        if (wave * 32 >= p.Sq) continue;   // wave-uniform
+        f32x4 dqacc[2][C::TD];
+#pragma unroll
+        for (int t = 0; t < C::TD; ++t) {
+            dqacc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dqacc[1][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int t = 0; t < nsteps; ++t) {
+            const int ntn = min(4, nst - 4 * t);
+            if (ntn == 4) res_dq_step<T, HDP, 2, 4, true>(kt + t * C::TILE, vt + t * C::TILE, t * 64, 0, 4, t * 64 + 64 <= p.Sk, qf, dof, dqacc, lse2, dl, p.Sk, p.scale, lane, rf, tf);
+            else res_dq_step<T, HDP, 2, 4, false>(kt + t * C::TILE, vt + t * C::TILE, t * 64, 0, ntn, false, qf, dof, dqacc, lse2, dl, p.Sk, p.scale, lane, rf, tf);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int i = wave * 32 + rb * 16 + (lane & 15);
+            if (i < p.Sq) {
+                T* dqb = dq + (int64_t)b * p.q_bs + (int64_t)i * p.q_rs + h * p.hd;
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td) {
+                    const int d = td * 16 + g * 4;
+                    if (d < p.hd) *(s16x4*)(dqb + d) = pack4<T>(dqacc[rb][td][0], dqacc[rb][td][1], dqacc[rb][td][2], dqacc[rb][td][3]);
+                }
+            }
+        }
+    }
+    if (nx > 0 && prev >= 0) {
+        __syncthreads();
+        merge(prev);
+    }
+}
+
+// ======================================================================================================================
 // backward, kernel 2: dK, dV - one workgroup per 64-key block, loops over query tiles
 // ======================================================================================================================
 template <typename T, int HDP, bool DROP>
@@ -791,7 +1155,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
     float st_l = 0.f, st_d = 0.f;
     tile_fetch<T, HDP>(qr, qb, p.q_rs, 0, p.Sq, tm_a);
     tile_fetch<T, HDP>(dor, dob, p.o_rs, 0, p.Sq, tm_b);
-    if (tid < 64 && tid < p.Sq) { st_l = lse[stat_base + tid]; st_d = delta[stat_base + tid]; }
+    // LDS carries lse * log2(e) and delta * scale: the element loop below is then fma - exp2 - fma - mul
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    if (tid < 64 && tid < p.Sq) { st_l = lse[stat_base + tid] * LOG2E; st_d = delta[stat_base + tid] * p.scale; }
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
         tile_commit<HDP>(qr, qt, tm_a);
@@ -803,7 +1170,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
             tile_fetch<T, HDP>(dor, dob, p.o_rs, (t + 1) * 64, p.Sq, tm_b);
             st_l = 0.f; st_d = 0.f;
             const int ii = (t + 1) * 64 + tid;
-            if (tid < 64 && ii < p.Sq) { st_l = lse[stat_base + ii]; st_d = delta[stat_base + ii]; }
+            if (tid < 64 && ii < p.Sq) { st_l = lse[stat_base + ii] * LOG2E; st_d = delta[stat_base + ii] * p.scale; }
         }
         // S = Q K^T, dP = dO V^T  (lane: key j = lane&15, query rows ti*16 + g*4 + r); only 16-query sub-tiles with real queries
         const int nti = (t == nt - 1 && (p.Sq & 63)) ? ((p.Sq - t * 64 + 15) >> 4) : 4;
@@ -821,27 +1188,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
             }
         }
         f32x4 pr[4];
+        // workgroup-uniform fast path: unmasked, no dropout, all 64 queries of the tile and all 64 keys of the block real (16 of the 25
+        // tile pairs at N = 257): 4 VALU operations per score instead of ~14 - these kernels are bound by VALU + MFMA issue
+        const bool fast = !DROP && !p.mask_mode && t * 64 + 64 <= p.Sq && k0 + 64 <= p.Sk;
+        if (fast) {
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + ti * 16 + g * 4);
-            const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + ti * 16 + g * 4);
+            for (int ti = 0; ti < 4; ++ti) {
+                const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + ti * 16 + g * 4);
+                const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + ti * 16 + g * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = t * 64 + ti * 16 + g * 4 + r;
-                float pv = 0.f, ds = 0.f;
-                if (i < p.Sq && j < p.Sk) {
-                    float x = s[ti][r] * p.scale;
-                    if (p.mask_mode) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk);
-                    pv = __expf(x - lv[r]);
-                    float dm = 1.f;
-                    if (DROP)
-                        dm = drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
-                                       drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
-                    ds = pv * (dp[ti][r] * dm - dv4[r]) * p.scale;
-                    pv *= dm;      // dV sees the dropped probabilities
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[ti][r], sc2, -lv[r]));
+                    pr[ti][r] = pv;
+                    s[ti][r] = pv * fmaf(dp[ti][r], p.scale, -dv4[r]);
                 }
-                pr[ti][r] = pv;
-                s[ti][r] = ds;
+            }
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + ti * 16 + g * 4);
+                const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + ti * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = t * 64 + ti * 16 + g * 4 + r;
+                    float pv = 0.f, ds = 0.f;
+                    if (i < p.Sq && j < p.Sk) {
+                        float x = s[ti][r] * sc2;
+                        if (p.mask_mode) x += mask_val(p.mask, p.mask_mode, b, i, j, p.Sq, p.Sk) * LOG2E;
+                        pv = __builtin_amdgcn_exp2f(x - lv[r]);
+                        float dm = 1.f;
+                        if (DROP)
+                            dm = drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
+                                           drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
+                        ds = pv * fmaf(dp[ti][r] * dm, p.scale, -dv4[r]);
+                        pv *= dm;      // dV sees the dropped probabilities
+                    }
+                    pr[ti][r] = pv;
+                    s[ti][r] = ds;
+                }
             }
         }
 #pragma unroll
@@ -941,6 +1325,18 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     hipStream_t st = (hipStream_t)stream;
     const dim3 block(256);
     const dim3 gq((p->Sq + 63) / 64, p->H, p->B), gk((p->Sk + 63) / 64, p->H, p->B);
+    static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;
+    const bool res = !no_res && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 &&
+                     p->Sq <= 256 + ResCfg<96>::NXMAX;
+    if (res) {
+        static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int nitems = p->B * p->H;
+        const dim3 grid(nitems < n_cu ? nitems : n_cu);
+        DISPATCH_T16(dtype, {
+            if (p->hd <= 64) MICO_LAUNCH((attn_bwd_dq_res_kernel<T, 64>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p);
+            else MICO_LAUNCH((attn_bwd_dq_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p);
+        });
+    } else
     DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP, true>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p); else MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP, false>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p); }));
     MICO_LAUNCH_CHECK();
     DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP, true>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p); else MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP, false>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p); }));

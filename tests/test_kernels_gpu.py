@@ -159,6 +159,21 @@ def test_attention_self_rowwise(cuda, dtype, S, hd):
     row_err = (o.float() - ref).norm(dim=-1) / ref.norm(dim=-1)
     assert torch.isfinite(row_err).all() and row_err.max() < tol(dtype, 4), (row_err.max(), row_err.argmax())
     assert (lse - sc.logsumexp(-1)).abs().max() < 2e-3
+    # backward, row by row as well (dQ rows 256.. are summed from eight key slices, dK / dV of key 256 likewise)
+    qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (qf, kf, vf))
+    refo = torch.einsum("bhij,bjhd->bihd", (torch.einsum("bihd,bjhd->bhij", qr, kr) * scale).softmax(-1), vr)
+    do = torch.randn(B, S, D, device=cuda).to(dtype)
+    refo.backward(do.float().reshape(B, S, H, hd))
+    dqkv = torch.full_like(qkv, float("nan"))
+    delta = torch.empty(B, H, S, device=cuda)
+    ops.attn_bwd(q, k, v, o, do, lse, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], delta, B=B, H=H, Sq=S, Sk=S, hd=hd,
+                 scale=scale, q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D),
+                 o_strides=(S * D, D))
+    torch.cuda.synchronize()
+    for name, got, want in (("dq", dqkv[..., :D], qr.grad), ("dk", dqkv[..., D:2 * D], kr.grad), ("dv", dqkv[..., 2 * D:], vr.grad)):
+        want = want.reshape(B, S, D)
+        err = (got.float() - want).norm(dim=-1) / (want.norm(dim=-1) + 1e-3 * want.norm(dim=-1).mean())
+        assert torch.isfinite(err).all() and err.max() < tol(dtype, 8), (name, err.max(), err.argmax())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

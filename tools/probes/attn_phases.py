@@ -42,6 +42,10 @@ for (B, H, S, hd) in ((320, 16, 256, 88), (320, 16, 257, 88)):
     tot = t.sum(1)
     print(f"S={S}: kernel {e0.elapsed_time(e1) * 1e3:.0f} us; {len(t)} workgroups sampled; cycles per workgroup (wave 0) mean {tot.mean():.0f} "
           f"(min {tot.min():.0f}, max {tot.max():.0f})")
-    res = S <= 260 and not os.environ.get("MICO_ATTN_NORES")   # K/V-resident persistent kernel: per workgroup totals over its items
+    res = S <= 260 and not os.environ.get("MICO_ATTN_NORES")
+    if res:   # the resident kernel records every wave of the first 512 workgroups: rows = (workgroup, wave)
+        tw = np.frombuffer(buf, dtype=np.uint64).reshape(512, 8, 8).astype(np.float64)[:256]
+        for w in range(8):
+            print(f"   wave {w}: " + "  ".join(f"{tw[:, w, i].mean() / (B * H / 256):.0f}" for i in range(8)))   # K/V-resident persistent kernel: per workgroup totals over its items
     items = B * H / 256 if res else 1
     print("   " + "  ".join(f"{nm} {t[:, i].mean() / items:.0f}" for i, nm in enumerate(res_names if res else names)) + ("   (cycles per item)" if res else ""))
