@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
+    ap.add_argument("--gemm-detail", action="store_true", help="print a per-shape table of the timed GEMM launches to stderr")
     ap.add_argument("--optimizer", action="store_true",
                     help="also run the AdamW step (mico_amd.optim, SURVEY section 8 row f4) inside the timed step: a full training step, "
                          "beyond the metric's fwd+bwd definition")
@@ -165,6 +166,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.GEMM_TIMER = None
+    if args.gemm_detail and rank == 0:
+        import sys
+        tab = {}
+        for (var, flops, e0, e1), det in zip(timer.records, timer.detail):
+            d = tab.setdefault((var, det[1], det[2], det[3], det[4]), [0, 0.0, 0.0, 0])
+            d[0] += 1; d[1] += flops; d[2] += e0.elapsed_time(e1); d[3] += det[0]
+        print(f"{'(ta,tb,kernel)':>14s} {'N':>6s} {'K':>6s} {'epilogue':>10s} {'split':>5s} {'launches':>8s} {'avg M':>8s} {'avg us':>8s} {'TFLOP/s':>8s} {'ms/step':>8s}", file=sys.stderr)
+        for key, d in sorted(tab.items(), key=lambda kv: -kv[1][2]):
+            print(f"{str(key[0]):>14s} {key[1]:6d} {key[2]:6d} {key[3]:>10s} {key[4]:5d} {d[0]:8d} {d[3] / d[0]:8.0f} {d[2] / d[0] * 1e3:8.1f} "
+                  f"{d[1] / d[2] / 1e9:8.1f} {d[2] / args.steps:8.2f}", file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

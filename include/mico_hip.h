@@ -154,6 +154,10 @@ typedef struct mico_attn_params {
     float drop_p;
     unsigned drop_seed;
     int drop_site;
+    /* > 0: batch entry b reads the K/V of batch entry b % kv_batch_mod (k_bs / v_bs strides) - shared cross-attention memory: the
+     * ITM triplet [own | hard-negative | own] of vast.py:438-447 is one [own | hard-negative] K/V buffer with kv_batch_mod = 2 b.
+     * dK / dV are still written per batch entry b (the caller adds the aliased parts).  0: every batch entry has its own K/V. */
+    int kv_batch_mod;
 } mico_attn_params;
 
 int mico_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,

@@ -27,7 +27,7 @@ class GemmEpilogue(C.Structure):
         ("remap_group", c_int), ("remap_skip", c_int), ("remap_offset", c_int), ("alpha", c_f), ("accumulate", c_int),
         ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
         ("row_map", c_vp), ("rows_per_map", c_int),
-        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int),
+        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("kv_batch_mod", c_int),
     ]
 
 
@@ -36,7 +36,7 @@ class AttnParams(C.Structure):
         ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int), ("hd", c_int),
         ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64), ("v_bs", c_i64), ("v_rs", c_i64),
         ("o_bs", c_i64), ("o_rs", c_i64), ("scale", c_f), ("mask", c_vp), ("mask_mode", c_int),
-        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int),
+        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("kv_batch_mod", c_int),
     ]
 
 

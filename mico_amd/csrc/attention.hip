@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * RB);
     const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
-    const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
-    const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+    const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;   // shared K/V memory (see mico_attn_params)
+    const T* kb = k + (int64_t)kvb * p.k_bs + h * p.hd;
+    const T* vb = v + (int64_t)kvb * p.v_bs + h * p.hd;
     const int i0 = q0 + wave * (16 * RB) + (lane & 15);   // this lane's query rows: i0 + rb * 16
     const int g = lane >> 4;
     const bool wave_live = q0 + wave * (16 * RB) < p.Sq;  // wave-uniform: this wave owns at least one real query row
@@ -701,8 +702,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
     const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
-    const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
-    const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+    const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;   // shared K/V memory (see mico_attn_params)
+    const T* kb = k + (int64_t)kvb * p.k_bs + h * p.hd;
+    const T* vb = v + (int64_t)kvb * p.v_bs + h * p.hd;
     const T* ob = o + (int64_t)b * p.o_bs + h * p.hd;
     const T* dob = d_o + (int64_t)b * p.o_bs + h * p.hd;
     const int i = q0 + wave * 16 + (lane & 15);
@@ -1131,8 +1133,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
     const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
-    const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
-    const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+    const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;   // shared K/V memory (see mico_attn_params)
+    const T* kb = k + (int64_t)kvb * p.k_bs + h * p.hd;
+    const T* vb = v + (int64_t)kvb * p.v_bs + h * p.hd;
     const T* dob = d_o + (int64_t)b * p.o_bs + h * p.hd;
     const int j = k0 + wave * 16 + (lane & 15);   // this lane's key row
     const int g = lane >> 4;
@@ -1263,6 +1266,7 @@ int check_params(const mico_attn_params* p, const char* who) {
                "%s: strides must be multiples of 8 elements", who);
     MICO_CHECK(p->mask_mode >= 0 && p->mask_mode <= 2 && (p->mask_mode == 0 || p->mask), "%s: bad mask", who);
     MICO_CHECK(p->drop_p >= 0.f && p->drop_p < 1.f, "%s: drop_p must be in [0, 1)", who);
+    MICO_CHECK(p->kv_batch_mod >= 0, "%s: kv_batch_mod must be >= 0", who);
     return MICO_OK;
 }
 
@@ -1291,7 +1295,7 @@ extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* 
     // two query blocks per wave for long unmasked attention without dropout (the ViT towers); one for the short BERT sequences
     static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;   // A/B switch for tools/attn_bench.py, tools/probes/attn_phases.py
     // K/V-resident persistent kernel: unmasked self-attention of the ViT towers (hd 128 would spill next to the prefetch registers)
-    if (!no_res && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 && p->Sq <= 256 + ResCfg<96>::NXMAX) {
+    if (!no_res && p->kv_batch_mod == 0 && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 && p->Sq <= 256 + ResCfg<96>::NXMAX) {
         static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int nitems = p->B * p->H;
         const dim3 grid(nitems < n_cu ? nitems : n_cu);
@@ -1326,7 +1330,7 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     const dim3 block(256);
     const dim3 gq((p->Sq + 63) / 64, p->H, p->B), gk((p->Sk + 63) / 64, p->H, p->B);
     static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;
-    const bool res = !no_res && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 &&
+    const bool res = !no_res && p->kv_batch_mod == 0 && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 &&
                      p->Sq <= 256 + ResCfg<96>::NXMAX;
     if (res) {
         static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();

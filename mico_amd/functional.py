@@ -779,10 +779,71 @@ def _fwd_gemm(x, key, plist, out, **kw):
 SITE_SELF_OUT, SITE_CROSS_OUT, SITE_FFN_OUT, SITE_SELF_P, SITE_CROSS_P, SITE_EMB = 0, 1, 2, 3, 4, 100000
 
 
+class CrossKVFn(torch.autograd.Function):
+    """Cross-attention K/V projections of the condition tokens for ALL layers, computed once per step and shared by every BERT pass
+    that attends to the same tokens with the same weights: the ITM triplet [own | hard negative | own] (vast.py:438-447) contains
+    the batch's own condition tokens twice and the captioning pass (vast.py:486-512) a third time - the reference projects them in
+    every pass (bert.py:206-215).  Returns (kv_own, kv_neg): per-layer [L][n E, 2 D] 16-bit views of ONE buffer laid out
+    [L][own | neg], so that a BERT pass over the triplet reads it through mico_attn_params.kv_batch_mod.
+    The gradients handed back by BertFn for these two outputs stay in the engine's 16-bit gradient scale (runtime.grad_scale());
+    this function removes it - the one place where a scaled gradient crosses autograd, between two of our own functions."""
+
+    @staticmethod
+    def forward(ctx, spec, cond_own, cond_neg, *kvparams):
+        # kvparams: per layer key.weight, key.bias, value.weight, value.bias
+        dt = runtime.compute_dtype()
+        dev = cond_own.device
+        n, E, D = cond_own.shape
+        sets = 2 if cond_neg is not None else 1
+        cond16 = _empty((sets * n * E, D), dt, dev)
+        ops.cast_f32_to_16(cond_own.contiguous().view(n * E, D), cond16[:n * E])
+        if cond_neg is not None:
+            ops.cast_f32_to_16(cond_neg.contiguous().view(n * E, D), cond16[n * E:])
+        kv = _empty((spec.L, sets * n * E, 2 * D), dt, dev)
+        for li in range(spec.L):
+            wk, bk, wv, bv = kvparams[4 * li: 4 * li + 4]
+            _fwd_gemm(cond16, "bkv", [wk, wv], kv[li], bias=torch.cat((bk.detach(), bv.detach())))
+        ctx.spec, ctx.kvparams, ctx.cond16, ctx.shape, ctx.sets = spec, kvparams, cond16, (n, E, D), sets
+        ctx.needs = (cond_own.requires_grad, cond_neg is not None and cond_neg.requires_grad)
+        if sets == 2:
+            return kv[:, :n * E], kv[:, n * E:]
+        return kv, None
+
+    @staticmethod
+    def backward(ctx, dkv_own, dkv_neg):
+        spec, kvparams, cond16 = ctx.spec, ctx.kvparams, ctx.cond16
+        n, E, D = ctx.shape
+        dev = cond16.device
+        inv_s = 1.0 / runtime.grad_scale()
+        parts = [(dkv_own, cond16[:n * E])]
+        if ctx.sets == 2:
+            parts.append((dkv_neg, cond16[n * E:]))
+        dconds = [torch.zeros((n * E, D), dtype=torch.float32, device=dev) if (need and d is not None) else None
+                  for need, (d, _) in zip(ctx.needs, parts)] + [None] * (2 - len(parts))
+        grads = []
+        for li in range(spec.L):
+            wk, bk, wv, bv = kvparams[4 * li: 4 * li + 4]
+            dw = torch.zeros((2 * D, D), dtype=torch.float32, device=dev)
+            db = torch.zeros(2 * D, dtype=torch.float32, device=dev)
+            for pi, (dkv, c16) in enumerate(parts):
+                if dkv is None:
+                    continue
+                d = dkv[li]
+                linear_wgrad(d, c16, dw, inv_s)
+                ops.colsum(d, db, scale=inv_s, accumulate=True)
+                if dconds[pi] is not None:
+                    ops.gemm(d, _fused_w("bkv", [wk, wv]), dconds[pi], tb=True, M=n * E, N=D, K=2 * D, alpha=inv_s, accumulate=True)
+            grads += [dw[:D], db[:D], dw[D:], db[D:]]
+        dc = [d.view(n, E, D) if d is not None else None for d in dconds]
+        return (None, dc[0], dc[1]) + tuple(grads)
+
+
 class BertFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec, input_ids, add_mask, cond, drop, *params):
-        """drop: None (eval), (p_hidden, p_attention, seed) - train-mode dropout of bert.py:148,267,295,373 - or a dict
+    def forward(ctx, spec, input_ids, add_mask, cond, drop, kv_own, kv_neg, *params):
+        """kv_own / kv_neg (CrossKVFn outputs, [L][n E, 2 D]) instead of cond: the cross-attention K/V memory is given; a batch of
+        n entries reads kv_own, one of 3 n entries is the ITM triplet [own | neg | own] and reads [kv_own | kv_neg] modulo 2 n.
+        drop: None (eval), (p_hidden, p_attention, seed) - train-mode dropout of bert.py:148,267,295,373 - or a dict
         {"kv_cache": {...}} (inference only): the per-layer cross-attention K/V projections of `cond` are stored in / taken from
         that dict, so a decode loop projects its (constant) condition tokens once instead of at every step."""
         kv_cache = None
@@ -809,6 +870,14 @@ class BertFn(torch.autograd.Function):
                           mean=mean_e, rstd=rstd_e, split16=split0, dtype=dt, drop=hd_drop(SITE_EMB))
         cond16 = None
         E = 0
+        kv_mod = 0
+        if kv_own is not None:
+            assert cond is None and kv_cache is None
+            n_own = b if kv_neg is None else b // 3
+            E = kv_own.shape[1] // n_own
+            if kv_neg is not None:   # the triplet reads one [own | neg] buffer modulo 2 n: the two views must be adjacent per layer
+                assert b == 3 * n_own and kv_neg.data_ptr() == kv_own.data_ptr() + n_own * E * 2 * D * kv_own.element_size()
+                kv_mod = 2 * n_own
         if cond is not None:
             E = cond.shape[1]
             cond16 = _empty((b * E, D), dt, dev)
@@ -844,13 +913,15 @@ class BertFn(torch.autograd.Function):
             _fwd_gemm(co, "w1", [wo], u, bias=P(p + "attention.output.dense.bias"), resid=x32, drop=hd_drop(li * 8 + SITE_SELF_OUT))
             x32, x16, m1, r1 = ln_out(u, p + "attention.output.")
             a.update(qkv=qkv, co=co, lse=lse, u=u, m1=m1, r1=r1)
-            if cond16 is not None:
+            if cond16 is not None or kv_own is not None:
                 ca = p + "crossattention.self."
                 a["x16a"] = x16[:, :D]
                 q = _empty((rows, D), dt, dev)
                 _fwd_gemm(x16, "w1", [P(ca + "query.weight")], q, bias=P(ca + "query.bias"))
                 kv = kv_cache.get(li) if kv_cache is not None else None
-                if kv is None or kv.shape[0] != b * E:
+                if kv_own is not None:
+                    kv = kv_own[li]      # with kv_mod: the first n E rows of the layer's [own | neg] buffer
+                elif kv is None or kv.shape[0] != b * E:
                     bkv = torch.cat((P(ca + "key.bias").detach(), P(ca + "value.bias").detach()))
                     kv = _empty((b * E, 2 * D), dt, dev)
                     _fwd_gemm(cond16, "bkv", [P(ca + "key.weight"), P(ca + "value.weight")], kv, bias=bkv)
@@ -860,7 +931,7 @@ class BertFn(torch.autograd.Function):
                 lse_c = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 ops.attn_fwd(q, kv, kv[:, D:], cc, lse_c, B=b, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None,
-                             drop=at_drop(li * 8 + SITE_CROSS_P), **stc)
+                             drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod, **stc)
                 u2 = _empty((rows, D), torch.float32, dev)
                 _fwd_gemm(cc, "w1", [P(p + "crossattention.output.dense.weight")], u2,
                           bias=P(p + "crossattention.output.dense.bias"), resid=x32, drop=hd_drop(li * 8 + SITE_CROSS_OUT))
@@ -881,6 +952,7 @@ class BertFn(torch.autograd.Function):
         ctx.misc = (ids, emb, mean_e, rstd_e, cond16, mask, b, S, E)
         ctx.drop = drop
         ctx.cond_needs_grad = cond is not None and cond.requires_grad
+        ctx.kv_shared = (kv_own is not None, kv_neg is not None, kv_mod)
         return x32.view(b, S, D)
 
     @staticmethod
@@ -904,6 +976,11 @@ class BertFn(torch.autograd.Function):
 
         g = dseq.contiguous().view(rows, D).float().clone()
         dcond = torch.zeros((b * E, D), dtype=torch.float32, device=dev) if cond16 is not None else None
+        shared, has_neg, kv_mod = ctx.kv_shared
+        n_own = (b // 3 if has_neg else b) if shared else 0
+        # gradients of the shared K/V memory, still in the 16-bit gradient scale (CrossKVFn.backward removes it)
+        dkv_own = _empty((spec.L, n_own * E, 2 * D), dt, dev) if shared else None
+        dkv_neg = _empty((spec.L, n_own * E, 2 * D), dt, dev) if has_neg else None
 
         def ln_bwd(gin, u, m_, r_, pre, site):
             """d(LN input) fp32 (in place into gin: the residual branch's gradient) and its scaled 16-bit copy for the dense
@@ -935,7 +1012,7 @@ class BertFn(torch.autograd.Function):
             ops.colsum(dh, G(p + "intermediate.dense.bias"), scale=inv_s, accumulate=True)
             ops.gemm(dh, _fused_w("w1", [P(p + "intermediate.dense.weight")]), g, tb=True, M=rows, N=D, K=I, alpha=inv_s, resid=g)
             # ---- cross attention ----
-            if cond16 is not None:
+            if cond16 is not None or shared:
                 ca = p + "crossattention.self."
                 d16 = ln_bwd(g, a["u2"], a["m2"], a["r2"], p + "crossattention.output.", li * 8 + SITE_CROSS_OUT)
                 linear_wgrad(d16, a["cc"], G(p + "crossattention.output.dense.weight"), inv_s)
@@ -943,20 +1020,26 @@ class BertFn(torch.autograd.Function):
                 dcc = _empty((rows, D), dt, dev)
                 ops.gemm(d16, _fused_w("w1", [P(p + "crossattention.output.dense.weight")]), dcc, tb=True, M=rows, N=D, K=D)
                 dq = _empty((rows, D), dt, dev)
-                dkv = _empty((b * E, 2 * D), dt, dev)
+                dkv = dkv_own[li] if (shared and not has_neg) else _empty((b * E, 2 * D), dt, dev)
                 delta = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 kv = a["kv"]
                 ops.attn_bwd(a["q"], kv, kv[:, D:], a["cc"], dcc, a["lse_c"], dq, dkv, dkv[:, D:], delta, B=b, H=H, Sq=S, Sk=E,
-                             hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), **stc)
+                             hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod, **stc)
                 linear_wgrad(dq, a["x16a"], G(ca + "query.weight"), inv_s)
                 ops.colsum(dq, G(ca + "query.bias"), scale=inv_s, accumulate=True)
-                dwkv = torch.zeros((2 * D, D), dtype=torch.float32, device=dev)
-                linear_wgrad(dkv, cond16, dwkv, inv_s)
-                split_rows(dwkv, [ca + "key.weight", ca + "value.weight"])
-                dbkv = torch.zeros(2 * D, dtype=torch.float32, device=dev)
-                ops.colsum(dkv, dbkv, scale=inv_s)
-                split_rows(dbkv, [ca + "key.bias", ca + "value.bias"])
+                if shared:   # dK/dV per batch entry -> per K/V set: the triplet's first and third thirds read the same (own) set
+                    ne = n_own * E
+                    if has_neg:
+                        torch.add(dkv[:ne], dkv[2 * ne:], out=dkv_own[li])
+                        dkv_neg[li].copy_(dkv[ne:2 * ne])
+                else:
+                    dwkv = torch.zeros((2 * D, D), dtype=torch.float32, device=dev)
+                    linear_wgrad(dkv, cond16, dwkv, inv_s)
+                    split_rows(dwkv, [ca + "key.weight", ca + "value.weight"])
+                    dbkv = torch.zeros(2 * D, dtype=torch.float32, device=dev)
+                    ops.colsum(dkv, dbkv, scale=inv_s)
+                    split_rows(dbkv, [ca + "key.bias", ca + "value.bias"])
                 if ctx.cond_needs_grad:
                     wkv = _fused_w("bkv", [P(ca + "key.weight"), P(ca + "value.weight")])
                     ops.gemm(dkv, wkv, dcond, tb=True, M=b * E, N=D, K=2 * D, alpha=inv_s, accumulate=True)
@@ -993,7 +1076,7 @@ class BertFn(torch.autograd.Function):
         ops.embed_scatter_add(ids, g, G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"), dtype0, S)
         G("embeddings.token_type_embeddings.weight")[0].add_(dtype0)
         dc = dcond.view(b, E, D) if (dcond is not None and ctx.cond_needs_grad) else None
-        return (None, None, None, dc, None) + grads.result()
+        return (None, None, None, dc, None, dkv_own, dkv_neg) + grads.result()
 
 
 # ======================================================================================================================

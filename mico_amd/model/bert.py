@@ -103,9 +103,22 @@ class BertModel(nn.Module):
                                      self.config["hidden_size"], self.config["intermediate_size"], self.config["layer_norm_eps"])
         return self._spec, [p for _, p in named]
 
-    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, kv_cache=None, **_):
+    def project_cross_kv(self, cond_own, cond_neg=None):
+        """Cross-attention K/V memory of condition tokens for all layers, to be shared by several passes of one training step
+        (`cross_kv=` of forward): (kv_own, kv_neg) for the batch's own tokens [b, E, D] and, optionally, ITM hard negatives.
+        Differentiable with respect to the tokens and the key / value projections (functional.CrossKVFn)."""
+        spec, params = self._bert_spec()
+        kvp = []
+        for li in range(spec.L):
+            ca = f"encoder.layer.{li}.crossattention.self."
+            kvp += [params[spec.idx[ca + n]] for n in ("key.weight", "key.bias", "value.weight", "value.bias")]
+        return Fn.CrossKVFn.apply(spec, cond_own, cond_neg, *kvp)
+
+    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, kv_cache=None, cross_kv=None, **_):
         """kv_cache (dict, inference only): holds the cross-attention K/V projections of `encoder_hidden_states` across calls -
-        the caller guarantees the condition tokens do not change between the calls that share the dict."""
+        the caller guarantees the condition tokens do not change between the calls that share the dict.
+        cross_kv (training): (kv_own, kv_neg) from project_cross_kv instead of encoder_hidden_states; a batch of b entries attends
+        to kv_own, a batch of 3 b entries is the ITM triplet [own | hard negative | own] and needs kv_neg as well."""
         if input_ids is None:
             raise ValueError("You have to specify input_ids")
         if attention_mask is None:
@@ -121,7 +134,15 @@ class BertModel(nn.Module):
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 raise RuntimeError("kv_cache is an inference feature: call under torch.no_grad()")
             drop = {"kv_cache": kv_cache}
-        seq = Fn.BertFn.apply(spec, input_ids, extended_attention_mask(attention_mask), encoder_hidden_states, drop, *params)
+        kv_own, kv_neg = (None, None)
+        if cross_kv is not None:
+            if encoder_hidden_states is not None or kv_cache is not None:
+                raise ValueError("cross_kv replaces encoder_hidden_states / kv_cache")
+            kv_own, kv_neg = cross_kv
+            if kv_neg is not None and input_ids.shape[0] % 3:
+                raise ValueError("cross_kv with hard negatives expects the ITM triplet batch [own | negative | own]")
+        seq = Fn.BertFn.apply(spec, input_ids, extended_attention_mask(attention_mask), encoder_hidden_states, drop, kv_own, kv_neg,
+                              *params)
         return _Out(last_hidden_state=seq)
 
 
@@ -204,8 +225,8 @@ class BertForMaskedLM(nn.Module):
         return (pr.transform.dense.weight, pr.transform.dense.bias, pr.transform.LayerNorm.weight, pr.transform.LayerNorm.bias,
                 pr.decoder.weight, pr.bias)
 
-    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, labels=None, **_):
-        seq = self.bert(input_ids, attention_mask, encoder_hidden_states).last_hidden_state
+    def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, labels=None, cross_kv=None, **_):
+        seq = self.bert(input_ids, attention_mask, encoder_hidden_states, cross_kv=cross_kv).last_hidden_state
         out = _MLMOut(loss=None, sequence_output=seq)
         hp = self._head_params()
         if labels is not None:

@@ -14,6 +14,7 @@ import torch
 
 from .. import distributed as D
 from .. import functional as Fn
+from .. import runtime
 
 COND_MODALITY = {"v": "vision", "a": "audio", "d": "depth"}
 FUSED_HEADS = {"v": "contra_head_v", "a": "contra_head_a", "d": "contra_head_d", "s": "contra_head_s", "va": "contra_head_va",
@@ -129,13 +130,25 @@ def _forward_ret(self, batch, enc, subtasks):
             cond_neg = D.fetch_rows(cond, neg_c)
         ids1 = torch.cat((ids, ids, ids_all[neg_t]), dim=0)
         am1 = torch.cat((am, am, mask_all[neg_t]), dim=0)
-        cond3 = torch.cat((cond, cond_neg, cond), dim=0)
-        out = self.multimodal_encoder.bert(input_ids=ids1, attention_mask=am1, encoder_hidden_states=cond3).last_hidden_state
+        if _share_cross_kv(self):
+            # the triplet [own | hard negative | own] holds the batch's own condition tokens twice and the captioning pass reads
+            # them again: their K/V projections are computed once per step (functional.CrossKVFn) and kept for _forward_cap
+            kv = self.multimodal_encoder.bert.project_cross_kv(cond, cond_neg)
+            enc.setdefault("_cross_kv", {})[st[1:]] = kv
+            out = self.multimodal_encoder.bert(input_ids=ids1, attention_mask=am1, cross_kv=kv).last_hidden_state
+        else:
+            cond3 = torch.cat((cond, cond_neg, cond), dim=0)
+            out = self.multimodal_encoder.bert(input_ids=ids1, attention_mask=am1, encoder_hidden_states=cond3).last_hidden_state
         logits = self.itm_head(out[:, 0])
         gt = torch.zeros(bs * 3, dtype=torch.long, device=ids.device)
         gt[:bs] = 1
         loss_itm.append(self.itm_ratio * Fn.cross_entropy(logits, gt))
     return {"loss_itc": sum(loss_itc) / len(loss_itc), "loss_itm": sum(loss_itm) / len(loss_itm)}
+
+
+def _share_cross_kv(self):
+    """Share the cross-attention K/V projections between the passes of a training step (runtime.CFG.share_cross_kv)."""
+    return runtime.CFG.share_cross_kv and torch.is_grad_enabled()
 
 
 def _forward_cap(self, batch, enc, subtasks):
@@ -149,6 +162,10 @@ def _forward_cap(self, batch, enc, subtasks):
     m3 = torch.tril(am.unsqueeze(1).expand(-1, S, -1)).contiguous()                       # vast.py:497-499
     losses = []
     for st in subtasks:
+        kv = enc.get("_cross_kv", {}).get(st[1:]) if _share_cross_kv(self) else None
+        if kv is not None:   # the retrieval branch of this step already projected these condition tokens
+            losses.append(self.multimodal_encoder(input_ids=masked_ids, attention_mask=m3, cross_kv=(kv[0], None), labels=labels).loss)
+            continue
         cond = _condition_feats(self, enc, st[1:])
         losses.append(self.multimodal_encoder(input_ids=masked_ids, attention_mask=m3, encoder_hidden_states=cond,
                                               labels=labels).loss)

@@ -36,6 +36,7 @@ class KernelTimer:
     def __init__(self, variants=((0, 0), (0, 1), (1, 1))):
         self.variants = set(variants)
         self.records = []   # ((ta, tb, kernel), flops, start_event, end_event); kernel: 0 small tile, 1 8-wave, 2 producer/consumer
+        self.detail = []    # per record: (M, N, K, epilogue signature) - bench.py --gemm-detail
 
     def summary(self):
         out = {}
@@ -100,6 +101,10 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     if timed:
         e1.record()
         timer.records.append(((int(ta), int(tb), int(_lib.lib().mico_gemm_last_kernel())), 2.0 * M * N * K, e0, e1))
+        sig = "".join(c for c, on in (("b", bias is not None), ("x", aux_out is not None), ("i", aux_in is not None), ("g", act != ACT_NONE),
+                                      ("s", row_scale is not None), ("r", resid is not None), ("m", row_map is not None),
+                                      ("a", accumulate), ("d", drop is not None), ("p", pos is not None)) if on)
+        timer.detail.append((M, N, K, sig + ("/f32" if out.dtype == torch.float32 else ""), split_k))
     check(rc, "mico_gemm")
     return out
 
@@ -142,8 +147,9 @@ def dropout_(x, drop):
     return x
 
 
-def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop=None):
+def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop=None, kv_batch_mod=0):
     p = AttnParams()
+    p.kv_batch_mod = int(kv_batch_mod)
     if drop is not None:
         p.drop_p, p.drop_seed, p.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     p.B, p.H, p.Sq, p.Sk, p.hd = B, H, Sq, Sk, hd
@@ -162,17 +168,19 @@ def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides
     return p
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides, v_strides, o_strides, drop=None):
+def attn_fwd(q, k, v, o, lse, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides, v_strides, o_strides, drop=None,
+             kv_batch_mod=0):
     """q/k/v/o are 16-bit tensors (possibly views into one fused projection buffer); *_strides = (batch, row) in
     elements.  mask: additive fp32 [B,Sk] or [B,Sq,Sk]."""
-    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop)
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop, kv_batch_mod)
     rc = _lib.lib().mico_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), C.byref(p), dt_code(q.dtype), _st())
     check(rc, "mico_attn_fwd")
 
 
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, delta, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides,
-             v_strides, o_strides, drop=None):
-    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop)
+             v_strides, o_strides, drop=None, kv_batch_mod=0):
+    """kv_batch_mod > 0: k / v hold kv_batch_mod batch entries shared modulo (see mico_attn_params); dk / dv are [B, ...] as always."""
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop, kv_batch_mod)
     rc = _lib.lib().mico_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk), _p(dv), _p(delta),
                                   C.byref(p), dt_code(q.dtype), _st())
     check(rc, "mico_attn_bwd")

@@ -21,6 +21,8 @@ class _Cfg:
     # fp16 parity configuration: forward GEMMs use hi/lo split weights (x W_hi + x W_lo in one launch through the kernel's
     # k-segments), which removes the weight-rounding half of the fp16 GEMM error.  Off for bf16 (throughput configuration).
     split_fp16 = True
+    # training: project the cross-attention K/V of a step's condition tokens once (functional.CrossKVFn) instead of in every BERT pass
+    share_cross_kv = True
 
 
 CFG = _Cfg()

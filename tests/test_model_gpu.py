@@ -173,6 +173,45 @@ def test_alignment_loss(setup, cuda, W):
     print(tag, W, f"worst grad err {worst:.2e}")
 
 
+def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
+    """runtime.CFG.share_cross_kv (the step's condition tokens projected to cross-attention K/V once, read by the ITM triplet through
+    kv_batch_mod and again by the captioning pass) against the reference's per-pass projection: same losses, same gradients -
+    in particular of the key / value projections, whose gradient now arrives through functional.CrossKVFn."""
+    vtype, tag, m, sd = setup
+    fx = golden(f"loss_{tag}.pt")
+    r = fx["W1"]
+    b = fx["meta"]["b"]
+    batch0 = to_dev(synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234), cuda)
+    res = {}
+    for share in (False, True):
+        batch = dict(batch0)
+        batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
+        batch["_injected"]["cap"] = r["inj"]["cap"]
+        old = runtime.CFG.share_cross_kv
+        runtime.CFG.share_cross_kv = share
+        try:
+            with runtime.precision(torch.float16):
+                m.zero_grad(set_to_none=True)
+                out = m(batch, fx["meta"]["task"], compute_loss=True)
+                sum(out.values()).backward()
+        finally:
+            runtime.CFG.share_cross_kv = old
+        res[share] = ({k: v.item() for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    for k in res[False][0]:
+        assert abs(res[True][0][k] - res[False][0][k]) <= 2e-4 * max(1.0, abs(res[False][0][k])), k
+    assert set(res[True][1]) == set(res[False][1])
+    worst = ("", 0.0)
+    for n, g0 in res[False][1].items():
+        if n.endswith("self.key.bias"):   # analytically zero (a constant added to every score of a softmax row): rounding noise only
+            continue
+        e = rel_err(res[True][1][n], g0) if g0.abs().max() > 0 else float(res[True][1][n].abs().max())
+        if e > worst[1]:
+            worst = (n, e)
+    print(tag, "shared vs per-pass K/V: worst gradient difference", worst)
+    assert worst[1] < 5e-3, worst
+    assert any("crossattention.self.key.weight" in n for n in res[True][1])
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly on CPU tensors - it never routes through PyTorch/oracle math."""
     from mico_amd._lib import MicoHipError
