@@ -795,6 +795,24 @@ int auto_split(int tiles, int ktiles, int slots, int min_tiles, int fixed) {
     return best;
 }
 
+// Split-K of the small-tile kernel for fp32-accumulate (weight-gradient) problems of one round of workgroups or less - BERT's 768 /
+// 2304 / 3072-wide layers over a few thousand token rows.  There the atomic epilogues of all splits land together at the end and are
+// not hidden behind other workgroups' K loops: measured ~4 us per MB of fp32 atomics (tools/probes/README.md), against ~1 us per
+// 64-deep K-tile of a workgroup that has its CU to itself.  Cost in microseconds; the old rule (as many splits as fill the chip) paid
+// 134 us where one pass takes 85 (3072 x 768 x 4928; in situ 143 -> 107) and 97 where three splits take 81 (768 x 768 x 4928, in situ).
+int small_acc_split(int tiles, int ktiles) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 16 && s <= ktiles; ++s) {
+        const double wgs = (double)tiles * s;
+        const double compute = ((ktiles + s - 1) / s) * 1.0 * (wgs > 256.0 ? wgs / 256.0 : 1.0);
+        const double atomics = s > 1 ? wgs * (128.0 * 128.0 * 4.0 / 1e6) * 4.0 : 0.0;
+        const double cost = compute + atomics;
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 }  // namespace
 
 thread_local char g_mico_err[256] = "";
@@ -842,7 +860,9 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
     // weight-gradient GEMMs (fp32 accumulate, auto split) have few output tiles but a very long reduction: split-K supplies
     // the parallelism, so the big tile pays as soon as K is long
-    const bool long_k_acc = split_k <= 0 && c_dtype == MICO_F32 && g.e.accumulate && K >= 8192 && big_tiles >= 8;
+    // (at least 16 big tiles: BERT's 768 x 768 layers over the step's ~15 k text rows do no better on the 192x256 tiles, whose fp32
+    // atomics then outweigh their K loops, than on the small-tile kernel with small_acc_split(); in situ 156 vs 160 us)
+    const bool long_k_acc = split_k <= 0 && c_dtype == MICO_F32 && g.e.accumulate && K >= 8192 && big_tiles >= 16;
     const bool big = (big_tiles >= 128 || long_k_acc) && N >= 192;
     // the producer/consumer kernel (192x256) takes every large problem; MICO_GEMM_NO_PC (ablation builds) keeps the 8-wave kernel
 #ifdef MICO_GEMM_NO_PC
@@ -863,7 +883,11 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.ntiles = g.ntm * g.ntn;
     const int BKc = pc ? pc_bk(ta, tb) : (big ? Big::BK : Small::BK);
     g.ktiles = (int)((K + BKc - 1) / BKc);
-    if (split_k <= 0) split_k = (c_dtype == MICO_F32 && g.e.accumulate) ? auto_split(g.ntiles, g.ktiles, slots, big ? 1024 / BKc : 16, big ? 768 / BKc : 12) : 1;
+    if (split_k <= 0) {
+        if (!(c_dtype == MICO_F32 && g.e.accumulate)) split_k = 1;
+        else if (!big && g.ntiles <= 512) split_k = small_acc_split(g.ntiles, g.ktiles);
+        else split_k = auto_split(g.ntiles, g.ktiles, slots, big ? 1024 / BKc : 16, big ? 768 / BKc : 12);
+    }
     if (split_k > g.ktiles) split_k = g.ktiles;
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
