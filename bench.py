@@ -225,6 +225,11 @@ def main():
     kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
     nominal = ALG_TFLOP_PER_SAMPLE.get(workload)
     executed = nominal - 8.00 * (1.0 - kept) if nominal else None
+    # shared cross-attention K/V (runtime.CFG.share_cross_kv): the reference projects 4 condition sets per sample and layer (ITM triplet +
+    # captioning pass, 1285 tokens each), the engine 2: 12 layers x 2 sets x 1285 x 2*768*1536 flop x 3 (fwd + dX + dW) = 0.218 TF/sample
+    from mico_amd import runtime as _rt
+    if executed is not None and _rt.CFG.share_cross_kv and args.task == "ret%tva_cap%tva" and not args.eval_mode:
+        executed -= 12 * 2 * 1285 * 2 * 768 * 1536 * 3 / 1e12
     step_tflops = executed * value / world if full else None
     res = {
         "metric": "omni-modal samples/sec (ViT-g/14 fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world,
@@ -245,6 +250,7 @@ def main():
         "samples_per_sec_per_gpu": value / world,
         "step_executed_tflops_per_gpu": step_tflops,
         "tflop_per_sample": {"dense_nominal": nominal, "executed": executed},
+        "cross_kv": "condition K/V projected once per step and shared by the ITM triplet and the captioning pass" if _rt.CFG.share_cross_kv else "per pass",
         "step_mfma_frac": (step_tflops / MFMA_PEAK_TFLOPS) if step_tflops else None,
         "losses": {k: float(v.detach()) for k, v in losses.items()},
         "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
