@@ -46,6 +46,7 @@ const char* mico_last_error_string(void);
  *   v += bias[n]                              (bias  != NULL, fp32 [N])
  *   aux_out[m,n] = T(v)                       (aux_out != NULL: pre-activation copy, 16-bit, ld = ldaux)
  *   act: MICO_ACT_GELU -> v = gelu_erf(v);  MICO_ACT_GELU_GRAD -> v *= gelu'(aux_in[m,n]);
+ *        MICO_ACT_GELU_SAVE_DERIV -> aux_out holds gelu'(v) instead of v, v = gelu_erf(v);  MICO_ACT_MUL_AUX -> v *= aux_in[m,n]
  *        MICO_ACT_SILU_MUL_GRAD etc. see enum
  *   v *= row_scale[m / rows_per_scale]        (row_scale != NULL: DropPath per-sample factor, eva_vit_model.py:121-138)
  *   v += resid[m',n]                          (resid != NULL, fp32, ld = ldc; may alias C)
@@ -56,6 +57,11 @@ const char* mico_last_error_string(void);
 #define MICO_ACT_NONE 0
 #define MICO_ACT_GELU 1      /* v = gelu(v) */
 #define MICO_ACT_GELU_GRAD 2 /* v = v * gelu'(aux_in) */
+/* The pair the MLPs use: the forward GEMM keeps gelu'(pre-activation) instead of the pre-activation itself (aux_out, same bytes), so
+ * the backward epilogue is one multiply - the erf polynomial is ~10 % of a 256x256 tile's time and was paid in both directions.
+ * Dedicated kernel instantiations: SAVE_DERIV needs ta = tb = 0, aux_out and a 16-bit C; MUL_AUX needs ta = 0, tb = 1 and aux_in. */
+#define MICO_ACT_GELU_SAVE_DERIV 3 /* aux_out = T(gelu'(v)); v = gelu(v) */
+#define MICO_ACT_MUL_AUX 4         /* v = v * aux_in */
 
 typedef struct mico_gemm_epilogue {
     const float* bias;      /* [N] or NULL */

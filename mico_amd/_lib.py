@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MICO_HIP_LIB") or os.path.join(_HERE, "libmico_hip.so")   # env override: kernel ablation builds
 
 F16, BF16, F32 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
 
 c_i64, c_int, c_f, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 

@@ -189,7 +189,10 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char
 // that makes the MFMA-layout writes (8-lane groups) and both row-major read-back ownerships below conflict free.
 __device__ __forceinline__ int epi_key(int row) { return (int)((0xF615B0AC843297DEull >> ((row & 15) * 4)) & 15); }
 
-template <typename T, int MB = 4>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
+// ACT: 0 = the activation is a run-time field (every launch but the two below); MICO_ACT_GELU_SAVE_DERIV / MICO_ACT_MUL_AUX = the MLP
+// pair compiled into its own kernel instantiation - as two more run-time branches of the shared epilogue they pushed the 8-wave
+// kernel from 6 to 51 spilled registers and slowed EVERY launch by 10-15 % (tools/probes/README.md).
+template <typename T, int MB = 4, int ACT = 0>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
     // every argument field the epilogue needs, read ONCE into scalars: left as g.e.<field> references the compiler re-loaded
@@ -249,12 +252,27 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         f32x4 v4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + ((((col[v] >> 2)) ^ kr) << 4)) + bias4[v];
-        if (e.aux_out) {   // 16-bit pre-activation copy; present only with 16-bit outputs, i.e. the paired ownership
+        if (e.aux_out) {   // 16-bit copy of the pre-activation (ACT 3: of gelu'); present only with 16-bit outputs, i.e. the paired ownership
             T* ap = (T*)e.aux_out + m * e.ldaux + ncol0;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const s16x4 lo = pack4<T>(v4[2 * u][0], v4[2 * u][1], v4[2 * u][2], v4[2 * u][3]);
-                const s16x4 hi = pack4<T>(v4[2 * u + 1][0], v4[2 * u + 1][1], v4[2 * u + 1][2], v4[2 * u + 1][3]);
+                f32x4 a0 = v4[2 * u], a1 = v4[2 * u + 1];
+                if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) {   // gelu and gelu' share the erf and the Gaussian; v becomes gelu(v) here
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float e2;
+                        float x = a0[k];
+                        float cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
+                        a0[k] = fmaf(x * 0.39894228040143268f, e2, cdf);
+                        v4[2 * u][k] = x * cdf;
+                        x = a1[k];
+                        cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
+                        a1[k] = fmaf(x * 0.39894228040143268f, e2, cdf);
+                        v4[2 * u + 1][k] = x * cdf;
+                    }
+                }
+                const s16x4 lo = pack4<T>(a0[0], a0[1], a0[2], a0[3]);
+                const s16x4 hi = pack4<T>(a1[0], a1[1], a1[2], a1[3]);
                 if (!wide && ok[2 * u + 1]) *(s16x8*)(ap + col[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 else {
                     if (ok[2 * u]) *(s16x4*)(ap + col[2 * u]) = lo;
@@ -262,17 +280,24 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
                 }
             }
         }
-        if (e.act == MICO_ACT_GELU) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) { v4[v][0] = gelu_f(v4[v][0]); v4[v][1] = gelu_f(v4[v][1]); v4[v][2] = gelu_f(v4[v][2]); v4[v][3] = gelu_f(v4[v][3]); }
-        } else if (e.act == MICO_ACT_GELU_GRAD) {
+        if constexpr (ACT == MICO_ACT_MUL_AUX) {
             const T* hp = (const T*)e.aux_in + m * e.ldaux + ncol0;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (ok[v]) {
-                    const f32x4 h = unpack4<T>(*(const s16x4*)(hp + col[v]));
-                    v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
-                }
+                if (ok[v]) v4[v] *= unpack4<T>(*(const s16x4*)(hp + col[v]));
+        } else if constexpr (ACT == 0) {
+            if (e.act == MICO_ACT_GELU) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { v4[v][0] = gelu_f(v4[v][0]); v4[v][1] = gelu_f(v4[v][1]); v4[v][2] = gelu_f(v4[v][2]); v4[v][3] = gelu_f(v4[v][3]); }
+            } else if (e.act == MICO_ACT_GELU_GRAD) {
+                const T* hp = (const T*)e.aux_in + m * e.ldaux + ncol0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (ok[v]) {
+                        const f32x4 h = unpack4<T>(*(const s16x4*)(hp + col[v]));
+                        v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
+                    }
+            }
         }
         if (e.drop_p > 0.f) {
             const unsigned thr = drop_threshold(e.drop_p);
@@ -334,7 +359,7 @@ __device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& g, const f3
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, bool TA, bool TB, typename CFG>
+template <typename T, bool TA, bool TB, typename CFG, int ACT = 0>
 __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, THREADS = CFG::THREADS, MT = CFG::MT;
     constexpr bool PINGPONG = CFG::WAVES == 8;
@@ -533,7 +558,7 @@ __global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
         PHASE_STAMP(4);
 #pragma unroll
         for (int h = 0; h < MT / 4; ++h) {
-            gemm_epilogue_block<T>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
+            gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
             if (h == 0) PHASE_STAMP(5);
         }
     }
@@ -775,6 +800,8 @@ void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
 template <typename T, typename CFG>
 void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles * g.split_k), block(CFG::THREADS);
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
+    if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
     if (!ta && !tb) MICO_LAUNCH((gemm_kernel<T, false, false, CFG>), grid, block, 0, st, g);
     else if (!ta && tb) MICO_LAUNCH((gemm_kernel<T, false, true, CFG>), grid, block, 0, st, g);
     else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true, CFG>), grid, block, 0, st, g);
@@ -908,7 +935,11 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         MICO_CHECK(!g.e.bias && !g.e.aux_out && g.e.act == MICO_ACT_NONE && !g.e.row_scale && !g.e.resid && !g.e.pos && !g.e.remap_group && !g.e.row_map && g.e.drop_p == 0.f,
                    "mico_gemm: split_k > 1 supports only the alpha-scaled accumulate epilogue");
     }
-    if (g.e.act == MICO_ACT_GELU_GRAD) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD needs aux_in");
+    if (g.e.act == MICO_ACT_GELU_GRAD || g.e.act == MICO_ACT_MUL_AUX) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD / MUL_AUX need aux_in");
+    MICO_CHECK(g.e.act >= MICO_ACT_NONE && g.e.act <= MICO_ACT_MUL_AUX, "mico_gemm: unknown act %d", g.e.act);
+    // the MLP pair exists as dedicated instantiations only: forward orientation / dX orientation, no split-K, 16-bit output
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MICO_CHECK(!ta && !tb && g.e.aux_out && c_dtype != MICO_F32, "mico_gemm: GELU_SAVE_DERIV is the forward epilogue (ta = tb = 0, aux_out, 16-bit C)");
+    if (g.e.act == MICO_ACT_MUL_AUX) MICO_CHECK(!ta && tb, "mico_gemm: MUL_AUX is the dX epilogue (ta = 0, tb = 1)");
     if (g.e.row_scale) MICO_CHECK(g.e.rows_per_scale > 0, "mico_gemm: rows_per_scale must be > 0");
     if (g.e.row_map) MICO_CHECK(g.e.rows_per_map > 0 && !g.e.remap_group, "mico_gemm: row_map needs rows_per_map > 0 and no remap_group");
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");

@@ -292,7 +292,7 @@ def _tower_forward(spec, groups, dp_scale, params, save):
             else:
                 h = _empty((M2, Hd), dt, dev)
                 act = _empty((M2, Hd), dt, dev)
-                _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU)
+                _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
                 _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), **epi)
                 a.update(h=h, act=act)
             a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=ln2)
@@ -371,7 +371,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
                 ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                ops.gemm(g16, w16_of(w2), dh, tb=True, M=M2, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
+                ops.gemm(g16, w16_of(w2), dh, tb=True, M=M2, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
                 linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
                 ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
                 ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
@@ -941,7 +941,7 @@ class BertFn(torch.autograd.Function):
             h = _empty((rows, I), dt, dev)
             act = _empty((rows, I), dt, dev)
             _fwd_gemm(x16, "w1", [P(p + "intermediate.dense.weight")], act, bias=P(p + "intermediate.dense.bias"),
-                      aux_out=h, act=ops.ACT_GELU)
+                      aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
             u3 = _empty((rows, D), torch.float32, dev)
             _fwd_gemm(act, "w1", [P(p + "output.dense.weight")], u3, bias=P(p + "output.dense.bias"), resid=x32,
                       drop=hd_drop(li * 8 + SITE_FFN_OUT))
@@ -1007,7 +1007,7 @@ class BertFn(torch.autograd.Function):
             linear_wgrad(d16, a["act"], G(p + "output.dense.weight"), inv_s)
             ops.colsum(d16, G(p + "output.dense.bias"), scale=inv_s, accumulate=True)
             dh = a["act"]
-            ops.gemm(d16, _fused_w("w1", [P(p + "output.dense.weight")]), dh, tb=True, M=rows, N=I, K=D, aux_in=a["h"], act=ops.ACT_GELU_GRAD)
+            ops.gemm(d16, _fused_w("w1", [P(p + "output.dense.weight")]), dh, tb=True, M=rows, N=I, K=D, aux_in=a["h"], act=ops.ACT_MUL_AUX)
             linear_wgrad(dh, a["x16b"], G(p + "intermediate.dense.weight"), inv_s)
             ops.colsum(dh, G(p + "intermediate.dense.bias"), scale=inv_s, accumulate=True)
             ops.gemm(dh, _fused_w("w1", [P(p + "intermediate.dense.weight")]), g, tb=True, M=rows, N=D, K=I, alpha=inv_s, resid=g)

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import F16, BF16, F32, ACT_NONE, ACT_GELU, ACT_GELU_GRAD, GemmEpilogue, AttnParams, MicoHipError, check
+from ._lib import F16, BF16, F32, ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_DERIV, ACT_MUL_AUX, GemmEpilogue, AttnParams, MicoHipError, check
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 

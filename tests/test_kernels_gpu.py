@@ -60,6 +60,18 @@ def test_gemm_epilogues(cuda, dtype):
     hf = h.float()
     gp = 0.5 * (1 + torch.erf(hf / math.sqrt(2))) + hf * torch.exp(-0.5 * hf * hf) / math.sqrt(2 * math.pi)
     assert rel_err(dh, 0.5 * acc * gp) < tol(dtype)
+    # the MLP pair: forward keeps gelu'(pre-activation) instead of the pre-activation, backward multiplies by it
+    gd = torch.empty(M, N, device=cuda, dtype=dtype)
+    a2 = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(A, W, a2, bias=bias, aux_out=gd, act=ops.ACT_GELU_SAVE_DERIV)
+    pre = acc + bias
+    gp32 = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    assert rel_err(a2, F.gelu(pre)) < tol(dtype)
+    assert rel_err(gd, gp32) < tol(dtype)
+    Wt = W.t().contiguous()          # [K, N]: the dX orientation reads its weight reduction-major
+    dh2 = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(A, Wt, dh2, tb=True, M=M, N=N, K=K, aux_in=gd, act=ops.ACT_MUL_AUX, alpha=0.5)
+    assert rel_err(dh2, 0.5 * acc * gd.float()) < tol(dtype)
     # bias + per-sample scale + residual (in place, fp32)
     rows_per = 257
     rs = torch.rand((M + rows_per - 1) // rows_per, device=cuda) + 0.5
