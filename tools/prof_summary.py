@@ -13,7 +13,7 @@ def short(name):
         tag = m.group(2)
         tag = tag.replace("DF16b", "bf16,").replace("DF16_", "f16,").replace("Lb0E", "0,").replace("Lb1E", "1,")
         tag = re.sub(r"Li(\d+)E", r"\1,", tag)
-        return f"{m.group(1)}<{tag.strip(',')[:40]}>"
+        return "%s<%s>" % (m.group(1), tag.strip(",")[:64])
     return name[:100]
 
 
