@@ -192,9 +192,14 @@ __device__ __forceinline__ int epi_key(int row) { return (int)((0xF615B0AC843297
 // ACT: 0 = the activation is a run-time field (every launch but the two below); MICO_ACT_GELU_SAVE_DERIV / MICO_ACT_MUL_AUX = the MLP
 // pair compiled into its own kernel instantiation - as two more run-time branches of the shared epilogue they pushed the 8-wave
 // kernel from 6 to 51 spilled registers and slowed EVERY launch by 10-15 % (tools/probes/README.md).
+constexpr int ACT_LEAN = 5;
 template <typename T, int MB = 4, int ACT = 0>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
+    // ACT == ACT_LEAN: launches that use none of {aux copy, activation, dropout, positional table, patch->token remap} - the qkv / fc2 /
+    // projection forwards and every dX of the towers - get an instantiation with those features compiled out
+    // (the MLP pair's instantiations carry their own activation code and none of the other optional features either)
+    constexpr bool LEAN = ACT != 0;
     // every argument field the epilogue needs, read ONCE into scalars: left as g.e.<field> references the compiler re-loaded
     // them from the kernel-argument segment inside every pass (66 s_load_dwordx8 + waits in the unrolled code)
     const struct {
@@ -244,7 +249,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         const int64_t m = mrow0 + row;
         if (m >= gM) continue;
         int64_t mo = m;
-        if (e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
+        if (!LEAN && e.remap_group) mo = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
         else if (e.row_map) { const int64_t f = m / e.rows_per_map; mo = (int64_t)e.row_map[f] * e.rows_per_map + (m - f * e.rows_per_map); }
         float rscale = 1.f;
         if (e.row_scale) rscale = e.row_scale[(e.row_map ? mo : m) / e.rows_per_scale];
@@ -252,7 +257,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         f32x4 v4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + ((((col[v] >> 2)) ^ kr) << 4)) + bias4[v];
-        if (e.aux_out) {   // 16-bit copy of the pre-activation (ACT 3: of gelu'); present only with 16-bit outputs, i.e. the paired ownership
+        if ((ACT == 0 || ACT == MICO_ACT_GELU_SAVE_DERIV) && e.aux_out) {   // 16-bit copy of the pre-activation (ACT 3: of gelu'); present only with 16-bit outputs, i.e. the paired ownership
             T* ap = (T*)e.aux_out + m * e.ldaux + ncol0;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -299,7 +304,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
                     }
             }
         }
-        if (e.drop_p > 0.f) {
+        if (!LEAN && e.drop_p > 0.f) {
             const unsigned thr = drop_threshold(e.drop_p);
             const float ik = 1.f / (1.f - e.drop_p);
             const unsigned long long i0 = (unsigned long long)m * (unsigned long long)gN + (unsigned long long)ncol0;
@@ -312,7 +317,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         for (int v = 0; v < 4; ++v) {
             v4[v] *= rscale;
             if (!ok[v]) continue;
-            if (e.pos) v4[v] += *(const f32x4*)(e.pos + (mo % e.pos_rows) * gN + ncol0 + col[v]);
+            if (!LEAN && e.pos) v4[v] += *(const f32x4*)(e.pos + (mo % e.pos_rows) * gN + ncol0 + col[v]);
             if (e.resid) v4[v] += *(const f32x4*)(e.resid + mo * gldc + ncol0 + col[v]);
         }
         if (wide) {
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     for (int hb = 0; hb < 3; ++hb) {
         const int64_t mrow = m0 + (hb < 2 ? wm * 64 + hb * 32 : 128 + wm * 32);
         if (g.split_k > 1) gemm_epilogue_atomic<2>(g, &acc[hb * 2], mrow, n0 + wn * 64, lane);
-        else gemm_epilogue_block<T, 2>(g, &acc[hb * 2], lds + wave * 8192, mrow, n0 + wn * 64, lane);
+        else gemm_epilogue_block<T, 2, ACT_LEAN>(g, &acc[hb * 2], lds + wave * 8192, mrow, n0 + wn * 64, lane);   // see `pc` in mico_gemm
     }
 }
 
@@ -802,6 +807,9 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles * g.split_k), block(CFG::THREADS);
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
+    const bool lean = CFG::BM == 256 && g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    if (lean && !ta && !tb) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }
+    if (lean && !ta && tb) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }
     if (!ta && !tb) MICO_LAUNCH((gemm_kernel<T, false, false, CFG>), grid, block, 0, st, g);
     else if (!ta && tb) MICO_LAUNCH((gemm_kernel<T, false, true, CFG>), grid, block, 0, st, g);
     else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true, CFG>), grid, block, 0, st, g);
@@ -901,7 +909,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
 #ifdef MICO_GEMM_PC_ALL
     const bool pc = big;
 #else
-    const bool pc = big && ta && tb;
+    // (its epilogue is the lean instantiation: launches with an aux copy / activation / dropout / pos / remap stay on the 8-wave kernel)
+    const bool pc = big && ta && tb && g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
 #endif
 #endif
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = big ? 256 : 128;
@@ -940,6 +949,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // the MLP pair exists as dedicated instantiations only: forward orientation / dX orientation, no split-K, 16-bit output
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MICO_CHECK(!ta && !tb && g.e.aux_out && c_dtype != MICO_F32, "mico_gemm: GELU_SAVE_DERIV is the forward epilogue (ta = tb = 0, aux_out, 16-bit C)");
     if (g.e.act == MICO_ACT_MUL_AUX) MICO_CHECK(!ta && tb, "mico_gemm: MUL_AUX is the dX epilogue (ta = 0, tb = 1)");
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV || g.e.act == MICO_ACT_MUL_AUX)
+        MICO_CHECK(g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group, "mico_gemm: GELU_SAVE_DERIV / MUL_AUX do not combine with dropout, pos or remap");
     if (g.e.row_scale) MICO_CHECK(g.e.rows_per_scale > 0, "mico_gemm: rows_per_scale must be > 0");
     if (g.e.row_map) MICO_CHECK(g.e.rows_per_map > 0 && !g.e.remap_group, "mico_gemm: row_map needs rows_per_map > 0 and no remap_group");
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
