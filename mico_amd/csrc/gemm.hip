@@ -365,7 +365,8 @@ __device__ __forceinline__ void gemm_epilogue_atomic(const GemmArgs& g, const f3
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, bool TA, bool TB, typename CFG, int ACT = 0>
-__global__ __launch_bounds__(CFG::THREADS) void gemm_kernel(const GemmArgs g) {
+// (two waves per SIMD in every configuration: the 4-wave small-tile kernel otherwise takes 260 registers and ONE workgroup per CU)
+__global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, THREADS = CFG::THREADS, MT = CFG::MT;
     constexpr bool PINGPONG = CFG::WAVES == 8;
     __shared__ __attribute__((aligned(16))) char smem[CFG::LDS_BYTES];
@@ -807,9 +808,10 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles * g.split_k), block(CFG::THREADS);
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
-    const bool lean = CFG::BM == 256 && g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
     if (lean && !ta && !tb) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }
     if (lean && !ta && tb) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }
+    if (lean && ta && tb && CFG::BM == 128) { MICO_LAUNCH((gemm_kernel<T, true, true, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }   // BERT weight gradients
     if (!ta && !tb) MICO_LAUNCH((gemm_kernel<T, false, false, CFG>), grid, block, 0, st, g);
     else if (!ta && tb) MICO_LAUNCH((gemm_kernel<T, false, true, CFG>), grid, block, 0, st, g);
     else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true, CFG>), grid, block, 0, st, g);
