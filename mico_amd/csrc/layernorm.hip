@@ -22,7 +22,9 @@ template <> struct RowIO<bf16> {
     static __device__ __forceinline__ f32x4 load(const bf16* p) { return unpack4<bf16>(*(const s16x4*)p); }
 };
 
-template <typename T, typename XT, int NV>
+// LEAN: the towers' block LayerNorms use neither the post-add table, nor dropout, nor an fp32 output, nor the hi|lo split output
+// (bf16 configuration): compiled without them
+template <typename T, typename XT, int NV, bool LEAN = false>
 __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, T* __restrict__ y16,
                                                            float* __restrict__ y32, float* __restrict__ mean_o,
@@ -36,17 +38,32 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
     const float inv = 1.0f / (float)cols;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    // the next row of this wave is requested before the current one is reduced and stored (one row at a time the wave has no load in
+    // flight during its two reductions and its stores)
+    auto fetch = [&](int64_t row, f32x4 (&dst)[NV]) {
+        if (row >= rows) return;
         int64_t srow = row;
         if (frame_map) { const int64_t f = row / rpf; srow = (int64_t)frame_map[f] * rpf + (row - f * rpf); }
         const XT* xr = x + srow * cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) dst[i] = RowIO<XT>::load(xr + c * 4);
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    f32x4 vn[NV];
+    fetch((int64_t)blockIdx.x * 4 + wave, vn);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += stride) {
         f32x4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = vn[i];
+        fetch(row + stride, vn);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
             if (c < nv) {
-                v[i] = RowIO<XT>::load(xr + c * 4);
                 if (x_copy) *(f32x4*)(x_copy + row * cols + c * 4) = v[i];
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
@@ -66,7 +83,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
             if (mean_o) mean_o[row] = mean;
             if (rstd_o) rstd_o[row] = rstd;
         }
-        const float* pa = post_add ? post_add + (int64_t)((row / post_rpg) % post_groups) * cols : nullptr;
+        const float* pa = (!LEAN && post_add) ? post_add + (int64_t)((row / post_rpg) % post_groups) * cols : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
@@ -76,16 +93,16 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
                 f32x4 o = (v[i] - mean) * rstd * g + b;
                 if (pa) o += *(const f32x4*)(pa + c * 4);
-                if (drop_p > 0.f) {
+                if (!LEAN && drop_p > 0.f) {
                     const unsigned thr = drop_threshold(drop_p);
                     const float ik = 1.f / (1.f - drop_p);
                     const unsigned long long i0 = (unsigned long long)row * cols + c * 4;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] *= drop_mult(drop_seed, drop_site, i0 + k, thr, ik);
                 }
-                if (y32) *(f32x4*)(y32 + row * cols + c * 4) = o;
+                if (!LEAN && y32) *(f32x4*)(y32 + row * cols + c * 4) = o;
                 if (y16) {
-                    if (!split16) {
+                    if (LEAN || !split16) {
                         *(s16x4*)(y16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
                     } else {   // [rows, 2*cols]: hi | lo halves (split-precision GEMM operand)
                         const s16x4 hi = pack4<T>(o[0], o[1], o[2], o[3]);
@@ -218,6 +235,10 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
                    float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16,
                    const int* fmap, int rpf, float* x_copy, float dp, unsigned dseed, int dsite) {
 #define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite)
+    if (!post_add && dp == 0.f && !y32 && !split16 && cols > 1024 && cols <= 1536) {
+        MICO_LAUNCH((ln_fwd_kernel<T, XT, 6, true>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite);
+        return;
+    }
     if (cols <= 1024) LNF(4);
     else if (cols <= 1536) LNF(6);
     else if (cols <= 2048) LNF(8);
