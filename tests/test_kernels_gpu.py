@@ -189,6 +189,38 @@ def test_attention_self_rowwise(cuda, dtype, S, hd):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("drop", [None, (0.1, 1234, 7)])
+def test_attention_shared_kv(cuda, dtype, drop):
+    """mico_attn_params.kv_batch_mod: B = 6 batch entries attending to 4 K/V sets (entry i reads set i % 4 - the ITM triplet
+    [own | negative | own] at b = 2) must equal the same launch over physically replicated K/V, forward and backward (dK / dV per
+    batch entry; the caller adds the aliased ones), with and without attention-probability dropout (same counters: one launch)."""
+    from mico_amd import ops
+    torch.manual_seed(11)
+    B, H, Sq, Sk, hd, nkv = 6, 12, 30, 150, 64, 4
+    D = H * hd
+    q = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    kv = torch.randn(nkv, Sk, 2 * D, device=cuda).to(dtype)
+    kv_rep = kv[torch.arange(B, device=cuda) % nkv].contiguous()
+    do = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    res = []
+    for kvt, mod in ((kv, nkv), (kv_rep, 0)):
+        k, v = kvt[..., :D], kvt[..., D:]
+        st = dict(q_strides=(Sq * D, D), k_strides=(Sk * 2 * D, 2 * D), v_strides=(Sk * 2 * D, 2 * D), o_strides=(Sq * D, D))
+        o = torch.empty(B, Sq, D, device=cuda, dtype=dtype)
+        lse = torch.empty(B, H, Sq, device=cuda)
+        kw = dict(B=B, H=H, Sq=Sq, Sk=Sk, hd=hd, scale=hd ** -0.5, drop=drop, kv_batch_mod=mod, **st)
+        ops.attn_fwd(q, k, v, o, lse, **kw)
+        dq = torch.empty_like(q)
+        dkv = torch.empty(B, Sk, 2 * D, device=cuda, dtype=dtype)
+        delta = torch.empty(B, H, Sq, device=cuda)
+        ops.attn_bwd(q, k, v, o, do, lse, dq, dkv[..., :D], dkv[..., D:], delta, **kw)
+        torch.cuda.synchronize()
+        res.append((o, lse, dq, dkv))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["vit_g", "vit_b", "bert_self2d", "bert_self3d", "bert_cross"])
 def test_attention(cuda, dtype, case):
     from mico_amd import ops
