@@ -1292,7 +1292,7 @@ extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (rc) return rc;
     const dim3 block(256);
     hipStream_t st = (hipStream_t)stream;
-    // two query blocks per wave for long unmasked attention without dropout (the ViT towers); one for the short BERT sequences
+    // two query blocks per wave beyond 64 query rows
     static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;   // A/B switch for tools/attn_bench.py, tools/probes/attn_phases.py
     // K/V-resident persistent kernel: unmasked self-attention of the ViT towers (hd 128 would spill next to the prefetch registers)
     if (!no_res && p->kv_batch_mod == 0 && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 && p->Sq <= 256 + ResCfg<96>::NXMAX) {
@@ -1306,7 +1306,11 @@ extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* 
         MICO_LAUNCH_CHECK();
         return MICO_OK;
     }
-    const bool two = p->Sq > 128 && p->drop_p <= 0.f && p->mask_mode == 0;
+    // (also BERT's 77 text rows without dropout - evaluation, caption decoding: one workgroup with waves of 32 + 32 + 13 rows stages
+    // each key tile once, two workgroups of 64 + 13 rows staged it twice and the second one ran its whole latency chain for 13 rows:
+    // cross-attention forward 0.219 -> 0.164 ms.  With dropout the two-block variant needs 227 registers instead of 116 and is slower
+    // in situ (134 vs 119 us), as is the same change in the dQ kernel (192 vs 124 registers: -10 %): occupancy wins there.)
+    const bool two = p->Sq > 64 && p->drop_p <= 0.f;
     const int qpw = two ? 128 : 64;
     const dim3 grid((p->Sq + qpw - 1) / qpw, p->H, p->B);
 #define ATTN_FWD_LAUNCH(DROP, RB) MICO_LAUNCH((attn_fwd_kernel<T, HDP, DROP, RB>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p)
