@@ -99,8 +99,11 @@ typedef struct mico_gemm_epilogue {
 } mico_gemm_epilogue;
 
 /* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256
- * producer/consumer (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
+ * producer/consumer, 3 = 256x256 one wave per SIMD (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
 int mico_gemm_last_kernel(void);
+/* kernel routing switch for A/B measurements (process-wide; returns the previous value): 0 = default routing, 1 = never the
+ * one-wave-per-SIMD kernel, 2 = the one-wave-per-SIMD kernel takes every large problem it supports */
+int mico_gemm_set_variant(int variant);
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,
               void* C, int64_t ldc, int c_dtype,

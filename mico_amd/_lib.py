@@ -27,7 +27,7 @@ class GemmEpilogue(C.Structure):
         ("remap_group", c_int), ("remap_skip", c_int), ("remap_offset", c_int), ("alpha", c_f), ("accumulate", c_int),
         ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
         ("row_map", c_vp), ("rows_per_map", c_int),
-        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("kv_batch_mod", c_int),
+        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int),
     ]
 
 
@@ -45,6 +45,7 @@ PROTOTYPES = {
     "mico_version": [],
     "mico_last_error_string": [],
     "mico_gemm_last_kernel": [],
+    "mico_gemm_set_variant": [c_int],
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
@@ -108,6 +109,8 @@ def lib():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
     _lib = l
+    if os.environ.get("MICO_GEMM_VARIANT"):      # A/B runs of whole test files / benches without touching their code
+        l.mico_gemm_set_variant(int(os.environ["MICO_GEMM_VARIANT"]))
     return l
 
 

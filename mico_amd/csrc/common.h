@@ -50,6 +50,21 @@ template <> struct T16<f16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+// In-place MFMA with the accumulator pinned to the AGPR half of the register file (one-wave-per-SIMD kernels keep 256 accumulator
+// registers there).  Inline assembly because hipcc 7.2 does not keep 64 loop-carried accumulator tiles in the tied (dst == srcC) form:
+// it emits the three-address form and rotates the tiles through v_accvgpr copies (~300 extra instructions per 128 MFMAs).  Rules for
+// the caller: the compiler does not know this is an MFMA - it still waits for the ds_read that produced a / b (they are plain operands),
+// back-to-back accumulation into the same tile needs no wait states, but the FIRST read of c by other code must be preceded by
+// mfma_acc_fence() (the XDL write -> VALU read wait states).
+template <typename T> __device__ __forceinline__ void mfma_acc(s16x8 a, s16x8 b, f32x4& c);
+template <> __device__ __forceinline__ void mfma_acc<f16>(s16x8 a, s16x8 b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma_acc<bf16>(s16x8 a, s16x8 b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_acc_fence() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+
 template <> struct T16<bf16> {
     typedef bf16x8 v8;
     typedef bf16x4 v4;

@@ -26,7 +26,11 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <type_traits>
 
+#ifndef MICO_W4_DBG
+#define MICO_W4_DBG 0
+#endif
 #ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
                            // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles,
                            // 6 = no epilogue
@@ -41,6 +45,16 @@ extern "C" int mico_debug_phase_times(unsigned long long* out, int n) {
 #define PHASE_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_mico_phase_times[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PHASE_STAMP(slot) do {} while (0)
+#endif
+
+#if MICO_GEMM_ABLATE == 8   // timing build of the one-wave-per-SIMD kernel: cycles at the top-of-iteration wait + barrier vs the whole K loop
+__device__ unsigned long long g_mico_w4_prof[4];
+extern "C" int mico_debug_w4_prof(unsigned long long* out) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mico_w4_prof), sizeof(unsigned long long) * 4);
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mico_w4_prof), z, sizeof(z));
+    return rc;
+}
 #endif
 
 namespace {
@@ -142,6 +156,38 @@ __device__ __forceinline__ s16x8 read_frag_b(LDS_AS const char* tile, int base, 
         LDS_AS const char* a = tile + (base ^ (i << 5));
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a);
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(a + 4 * RB));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+// The same, for kernels that keep LDS-DMA in flight ACROSS their fragment reads (the one-wave-per-SIMD kernel): the transposing read
+// as inline assembly.  hipcc 7.2 puts `s_waitcnt vmcnt(0)` in front of the first __builtin_amdgcn_ds_read_tr16_b64 after every LDS-DMA
+// instruction (it cannot tell the intrinsic's LDS address from the DMA's destination; plain ds_read_b128 loads carry alias information
+// and are left alone) - with DMA interleaved between the reads that drains the queue six times per K-tile (dX 600, dW 360 TFLOP/s).
+// The compiler does not count an asm read either: the CALLER must execute `s_waitcnt lgkmcnt(0)` + sched_barrier between these reads
+// and the first use of the fragments (the kernel's top-of-iteration wait), and the loop's ISA must show no copy of the fragment
+// registers in between (tools/isa_audit.sh).
+template <bool TR, int ROWS, int BK>
+__device__ __forceinline__ s16x8 read_frag_dma(LDS_AS const char* tile, int base, int i) {
+    if constexpr (!TR) {
+        return *(LDS_AS const s16x8*)(tile + base + i * (BK * 2 * 16));
+    } else {
+        constexpr int RB = ROWS * 2;
+        const unsigned a = (unsigned)(uintptr_t)(tile + (base ^ (i << 5)));
+        s16x4 lo, hi;
+#if MICO_W4_DBG == 3
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + (base ^ (i << 5))));
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + (base ^ (i << 5)) + 4 * RB));
+#elif MICO_W4_DBG == 2
+        asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(lo) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(hi) : "v"(a), "n"(4 * RB));
+#else
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(4 * RB));
+#endif
         s16x8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -788,6 +834,304 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     }
 }
 
+
+// ======================================================================================================================
+// EXPERIMENT (round 2), compiled only with -DMICO_GEMM_W4: a one-wave-per-SIMD kernel.  Findings (tools/probes/README.md, "W4"):
+// its MFMA + fragment-read structure runs at 1530-1830 TFLOP/s with the steady-state DMA ablated (the shipped 8-wave kernel: 1160-1480),
+// but every LDS-DMA instruction that fetches real data stalls the issuing wave ~40-60 cycles and an in-order wave that is alone on its
+// SIMD has no partner to keep the matrix pipe busy meanwhile: with DMA it lands where the shipped kernels are (fwd 880-1110, dX 1010-1100,
+// dW 720-900).  The 4-stage variant + transposing reads also showed an unexplained data race on power-of-two row strides.  Not routed.
+// ======================================================================================================================
+#ifdef MICO_GEMM_W4
+// ======================================================================================================================
+// W4 kernel: ONE wave per SIMD.
+// The two kernels above keep two waves per SIMD (256 registers each), so a wave owns 128x64 outputs and every K-tile costs the CU
+// 192 KiB of fragment reads next to the 64 KiB DMA fill - the LDS is as busy as the matrix pipe - and fragments are single-buffered,
+// so every phase exposes its ds_read latency behind a barrier.  At one wave per SIMD the unified register file gives a wave 512
+// registers: 256x256x64 tile, FOUR waves (2x2), each owning 128x128 = 64 accumulator tiles (256 registers) next to TWO fragment
+// sets (2 x 16 fragments = 128 registers).  Per 64-deep K-tile: 128 KiB of fragment reads (-33 %), ONE barrier, and no exposed
+// LDS latency - the schedule is a software pipeline inside each wave:
+//     first half : 64 MFMAs on set 0 (k-step 0 of tile t)   || ds_read set 1 = k-step 1 of tile t
+//     mid        : lgkmcnt(0), vmcnt(0) [tile t+1 landed], s_barrier -> tile t fully read (its stage is free), tile t+1 published
+//     second half: 64 MFMAs on set 1                        || ds_read set 0 = k-step 0 of tile t+1, DMA of tile t+2 -> stage of tile t
+// with the side operations spread one pair per 8 MFMAs (sched_barrier-pinned) so that the in-order wave never leaves the matrix
+// pipe idle behind a burst of VMEM / LDS issues.  Two 64 KiB stages; a tile's DMA is issued one full iteration (~2k cycles) before
+// the barrier that publishes it.  P1 = DMA pieces (of 16 per thread and tile) issued in the second half; the other 16 - P1 follow
+// in the first half of the next iteration (spreads the TA load; they then have half an iteration to land).
+// LDS images, swizzles, fragment addressing, operand orientations and epilogues are those of the kernels above.
+// ======================================================================================================================
+template <int DEEP> struct W4C {   // DEEP 0: 2 stages of 64-deep K-tiles; 1: 4 stages of 32-deep K-tiles (see the schedule notes in the kernel)
+    static constexpr int BM = 256, BN = 256, BK = DEEP ? 32 : 64, STAGES = DEEP ? 4 : 2, THREADS = 256, MT = 8;
+    static constexpr int A_BYTES = 256 * BK * 2, STAGE_BYTES = 2 * A_BYTES, LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int NDMA = A_BYTES / 16 / THREADS;   // DMA instructions per thread per operand tile (8 / 4)
+};
+using W4 = W4C<0>;
+
+template <typename T, bool TA, bool TB, int ACT, int P1, int DEEP>
+__global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(const GemmArgs g) {
+    using W4 = W4C<DEEP>;
+    constexpr int BM = W4::BM, BN = W4::BN, BK = W4::BK, THREADS = W4::THREADS, ND = W4::NDMA;
+    constexpr int STAGE = W4::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[W4::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wrow = wm * 128, wcol = wn * 128;
+
+    int bid = blockIdx.x;
+    const int ks = bid / g.ntiles;
+    bid -= ks * g.ntiles;
+    {
+        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    int tile_m, tile_n;
+    {
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        tile_m = first + in % gm;
+        tile_n = in / gm;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int kt0 = ks * g.ktiles_per_split;
+    const int kt1 = min(g.ktiles, kt0 + g.ktiles_per_split);
+    const int T_ = kt1 - kt0;
+
+    const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+    const char* a_base = TA ? g.A + m0 * 2 : g.A + m0 * lda_b;
+    const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
+    int64_t a_bytes = TA ? g.ka_rows * lda_b - m0 * 2 : (g.M - m0) * lda_b;
+    int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+    if (a_bytes > 0x7FFFFF00ll) a_bytes = 0x7FFFFF00ll;   // (mico_gemm routes here only when every offset in use stays below 2^31)
+    if (b_bytes > 0x7FFFFF00ll) b_bytes = 0x7FFFFF00ll;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+    const int64_t a_crem = g.M - m0, b_crem = g.N - n0;
+
+    f32x4 acc[2][8][4];   // [64-column half][16-row tile][16-column tile]: &acc[c][4 h] is one 64x64 epilogue block
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // k-segment s (split-precision GEMMs) maps logical k to physical column k - s * kseg + seg_off[s]
+    // (readfirstlane: pins the six offsets into SGPRs here - left to itself hipcc re-selects and re-loads them inside the loop)
+    const bool segs = g.e.nseg > 0;
+    const int kseg_ = __builtin_amdgcn_readfirstlane(segs ? g.e.kseg : 0x3FFFFFFF);
+    const int aso0 = __builtin_amdgcn_readfirstlane(segs ? g.e.a_seg_off[0] : 0);
+    const int aso1 = __builtin_amdgcn_readfirstlane(segs ? g.e.a_seg_off[1] - kseg_ - g.e.a_seg_off[0] : 0);          // increments
+    const int aso2 = __builtin_amdgcn_readfirstlane(segs ? g.e.a_seg_off[2] - kseg_ - g.e.a_seg_off[1] : 0);
+    const int bso0 = __builtin_amdgcn_readfirstlane(segs ? g.e.b_seg_off[0] : 0);
+    const int bso1 = __builtin_amdgcn_readfirstlane(segs ? g.e.b_seg_off[1] - kseg_ - g.e.b_seg_off[0] : 0);
+    const int bso2 = __builtin_amdgcn_readfirstlane(segs ? g.e.b_seg_off[2] - kseg_ - g.e.b_seg_off[1] : 0);
+    const FragBase ab = frag_base<TA, BM, BK>(wrow, lane), bb = frag_base<TB, BN, BK>(wcol, lane);
+    unsigned voa[ND], vob[ND];
+    dma_offsets<TA, BM, THREADS, BK, ND>(voa, wave, lane, lda_b, a_crem);
+    dma_offsets<TB, BN, THREADS, BK, ND>(vob, wave, lane, ldb_b, b_crem);
+#pragma unroll
+    for (int p = 0; p < ND; ++p) {   // w4_edge
+        if (voa[p] == 0xFFFFFFF0u) voa[p] = 0x80000000u;
+        if (vob[p] == 0xFFFFFFF0u) vob[p] = 0x80000000u;
+    }
+
+    // source of one K-tile: scalar byte offsets of both operands.  The loop body is ONE basic block (256 accumulator registers live
+    // across control flow made the register allocator rotate them through copies): a tile past the end of this workgroup's K range
+    // is "loaded" with every lane out of bounds (no memory traffic, the LDS image is zero-filled and never read).  A ragged last
+    // K-tile needs no masking here: reduction-major operands end at the descriptor's bound (rows >= K zero-fill) and problems with
+    // a k-contiguous operand and K % 64 != 0 are not routed to this kernel (mico_gemm).
+    struct Src { unsigned koa, kob; bool valid; };
+    auto src_of = [&](int kt) {
+        Src s;
+        s.valid = kt < kt1;
+        const int k0 = (MICO_GEMM_ABLATE == 5 ? kt0 + ((kt - kt0) & 1) : kt) * BK;   // ablation 5: re-read the first two K-tiles (cache-resident)
+        // k-segments without control flow: segment index by comparison, offsets from scalars read once
+        // (arithmetic, not ?: - a select between by-reference captures becomes a select of ADDRESSES that keeps them in memory)
+        const int sg1 = k0 >= kseg_, sg2 = k0 >= 2 * kseg_;
+        const int ka = k0 + aso0 + sg1 * aso1 + sg2 * aso2, kb = k0 + bso0 + sg1 * bso1 + sg2 * bso2;
+        s.koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
+        s.kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
+        return s;
+    };
+    // one DMA piece of the 16 per thread and tile: 0-7 operand A, 8-15 operand B.  A piece past the matrix edge carries offset 2^31
+    // (w4_edge above): adding a tile's k offset (< 2^31, checked in mico_gemm) keeps it beyond the descriptor's bound (< 2^31) without
+    // a per-piece condition (16 SGPR pairs the kernel does not have).
+    auto piece = [&](const Src& s, int bo, int p) {
+        if (MICO_GEMM_ABLATE == 1) return;
+        if (p < ND) {
+            unsigned v = s.valid ? voa[p] + s.koa : 0xFFFFFFF0u;
+            if (MICO_GEMM_ABLATE == 4) v = 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (LDS_AS void*)(lds + bo + (p * THREADS + wave * 64) * 16), 16, v, 0, 0, 0);
+        } else {
+            unsigned v = s.valid ? vob[p - ND] + s.kob : 0xFFFFFFF0u;
+            if (MICO_GEMM_ABLATE == 4) v = 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (LDS_AS void*)(lds + bo + W4::A_BYTES + ((p - ND) * THREADS + wave * 64) * 16), 16, v, 0, 0, 0);
+        }
+    };
+    // two fragment sets, named so that every index is a compile-time constant (k-step 0 / k-step 1)
+    s16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+    auto frag = [&](s16x8 (&fax)[8], s16x8 (&fbx)[8], LDS_AS const char* pa, LDS_AS const char* pb, int abase, int bbase, int idx) {
+        if (MICO_GEMM_ABLATE == 2) {
+            if (idx < 8) asm volatile("" : "+v"(fax[idx])); else asm volatile("" : "+v"(fbx[idx - 8]));
+            return;
+        }
+        if (idx < 8) fax[idx] = read_frag_dma<TA, BM, BK>(pa, abase, idx);
+        else fbx[idx - 8] = read_frag_dma<TB, BN, BK>(pb, bbase, idx - 8);
+    };
+    // One half = 64 MFMAs (8 row tiles x 8 column tiles) on set (fax, fbx).  The wave is alone on its SIMD and issues in order, so
+    // whatever sits between two MFMAs must fit the 16 cycles the first one occupies the matrix pipe: the half's side work - the 16
+    // fragment requests of the NEXT set and NP DMA pieces - is dealt out one item per MFMA slot (fragments in the even slots of
+    // the first half of the slots, pieces evenly over the odd ones) and every slot is pinned with a sched_barrier.
+    auto half = [&](const s16x8 (&fax)[8], const s16x8 (&fbx)[8], s16x8 (&nax)[8], s16x8 (&nbx)[8], LDS_AS const char* pa,
+                    LDS_AS const char* pb, int abase, int bbase, const Src& s, int bo, auto p0_c, auto np_c) {
+        constexpr int P0 = decltype(p0_c)::value, NP = decltype(np_c)::value;
+        constexpr int STEP = 64 / (NP > 0 ? NP : 1);
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const int i = m >> 3, cj = m & 7;
+            mfma_acc<T>(fbx[cj], fax[i], acc[cj >> 2][i][cj & 3]);
+#if MICO_W4_DBG == 6
+            if (m >= 30 && m < 62 && (m & 1) == 0) frag(nax, nbx, pa, pb, abase, bbase, (m - 30) >> 1);
+#else
+            if (m < 32 && (m & 1) == 0) frag(nax, nbx, pa, pb, abase, bbase, m >> 1);
+#endif
+            if (NP > 0 && (m % STEP) == (STEP > 1 ? 1 : 0) && m / STEP < NP) piece(s, bo, P0 + m / STEP);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#define IC(N) std::integral_constant<int, (N)>{}
+
+    if constexpr (DEEP) {
+        // ---- 4 stages of 32-deep K-tiles (one MFMA k-step each).  Iteration t: 64 MFMAs on the fragments of tile t (in registers since
+        // iteration t-1) || fragment requests of tile t+1 || DMA of tile t+4 into the stage tile t occupied (already in registers).
+        // Top of the iteration: vmcnt(16) = this wave's share of tile t+1 has landed (t+2, t+3 stay in flight), lgkmcnt(0), ONE
+        // barrier: tile t+1 is visible and nobody reads tile t's stage any more.  A tile's DMA is issued three iterations (~3k cycles)
+        // before the barrier that publishes it and 96 KiB are in flight per CU.  Tiles past the end of the K range are "loaded"
+        // out of bounds, i.e. zero-filled: the loop runs in pairs (static fragment-set names) and an odd tail multiplies zeros.
+        constexpr int PT = 2 * ND;   // 8 pieces per thread and tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const Src sq = src_of(kt0 + q);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) piece(sq, q * STAGE, p);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MICO_GEMM_ABLATE == 1 ? 0 : 3 * PT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) frag(fa0, fb0, lds, lds + W4::A_BYTES, ab.b0, bb.b0, idx);
+        int bo = 0;
+#if MICO_GEMM_ABLATE == 8
+        unsigned long long prof_wait = 0, prof_bar = 0;
+        const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        auto top = [&]() {
+#if MICO_GEMM_ABLATE == 8
+            const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PT) : "memory");
+            const unsigned long long a1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long a2 = __builtin_amdgcn_s_memtime();
+            prof_wait += a1 - a0; prof_bar += a2 - a1;
+#else
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((MICO_GEMM_ABLATE == 1 || MICO_W4_DBG == 1) ? 0 : MICO_W4_DBG == 4 ? PT : 2 * PT) : "memory");
+            __builtin_amdgcn_s_barrier();
+#if MICO_W4_DBG == 5
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#endif
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int t = 0; t < T_; t += 2) {
+            asm volatile("" : "+s"(bo));
+            {
+                top();
+                const Src s4 = src_of(kt0 + t + 4);
+                const int nbo = (bo + STAGE) & (4 * STAGE - 1);
+                half(fa0, fb0, fa1, fb1, lds + nbo, lds + nbo + W4::A_BYTES, ab.b0, bb.b0, s4, bo, IC(0), IC(PT));
+                bo = nbo;
+            }
+            {
+                top();
+                const Src s4 = src_of(kt0 + t + 5);
+                const int nbo = (bo + STAGE) & (4 * STAGE - 1);
+                half(fa1, fb1, fa0, fb0, lds + nbo, lds + nbo + W4::A_BYTES, ab.b0, bb.b0, s4, bo, IC(0), IC(PT));
+                bo = nbo;
+            }
+        }
+#if MICO_GEMM_ABLATE == 8
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_mico_w4_prof[0], prof_wait);
+            atomicAdd(&g_mico_w4_prof[1], prof_bar);
+            atomicAdd(&g_mico_w4_prof[2], __builtin_amdgcn_s_memtime() - prof_t0);
+            atomicAdd(&g_mico_w4_prof[3], (unsigned long long)((T_ + 1) / 2 * 2));
+        }
+#endif
+    } else {
+    // ---- prologue: tile 0 and the first P1 pieces of tile 1 in flight, tile 0 published, its k-step 0 fragments requested ----
+    {
+        const Src s0 = src_of(kt0), s1 = src_of(kt0 + 1);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) piece(s0, 0, p);
+#pragma unroll
+        for (int p = 0; p < P1; ++p) piece(s1, STAGE, p);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MICO_GEMM_ABLATE == 1 ? 0 : P1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) frag(fa0, fb0, lds, lds + W4::A_BYTES, ab.b0, bb.b0, idx);
+    }
+    int bo = 0;
+    for (int t = 0; t < T_; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bo) : : "memory");   // the fragment requests of the previous half (asm reads are not counted by the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_AS const char* ta = lds + bo;
+        LDS_AS const char* tb = ta + W4::A_BYTES;
+        const Src sn = src_of(kt0 + t + 1);   // late pieces of the next tile (other stage)
+        // ---- first half: MFMAs of k-step 0; requests k-step 1; the late pieces of tile t+1 ----
+        half(fa0, fb0, fa1, fb1, ta, tb, ab.b1, bb.b1, sn, bo ^ STAGE, IC(P1), IC(16 - P1));
+        // ---- mid: tile t+1 landed (own pieces), barrier: stage `bo` is no longer read by anyone, tile t+1 is visible ----
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const Src s2 = src_of(kt0 + t + 2);
+        LDS_AS const char* na = lds + (bo ^ STAGE);
+        LDS_AS const char* nb = na + W4::A_BYTES;
+        // ---- second half: MFMAs of k-step 1; requests tile t+1's k-step 0 (past the last tile: stale bytes, never used); the first P1
+        // pieces of tile t+2 into this stage ----
+        half(fa1, fb1, fa0, fb0, na, nb, ab.b0, bb.b0, s2, bo, IC(0), IC(P1));
+        bo ^= STAGE;
+    }
+    }
+#undef IC
+    mfma_acc_fence();
+    // ---- epilogue: four 64x64 blocks per wave through its 16 KiB of LDS ----
+    if (g.split_k > 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) gemm_epilogue_atomic(g, &acc[c][h * 4], m0 + wrow + h * 64, n0 + wcol + c * 64, lane);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                gemm_epilogue_block<T, 4, ACT>(g, &acc[c][h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol + c * 64, lane);
+    }
+}
+
+#endif   // MICO_GEMM_W4 (kernel)
+
 constexpr int pc_bk(int, int) { return 32; }
 
 template <typename T>
@@ -817,6 +1161,28 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     else if (ta && tb) MICO_LAUNCH((gemm_kernel<T, true, true, CFG>), grid, block, 0, st, g);
     else MICO_LAUNCH((gemm_kernel<T, true, false, CFG>), grid, block, 0, st, g);
 }
+
+#ifdef MICO_GEMM_W4
+#ifndef MICO_W4_P1
+#define MICO_W4_P1 16
+#endif
+template <typename T, int DEEP>
+void launch_w4(int ta, int tb, const GemmArgs& g, hipStream_t st) {
+    constexpr int P1 = MICO_W4_P1;
+    const dim3 grid(g.ntiles * g.split_k), block(W4::THREADS);
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_w4_kernel<T, false, false, MICO_ACT_GELU_SAVE_DERIV, P1, DEEP>), grid, block, 0, st, g); return; }
+    if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_w4_kernel<T, false, true, MICO_ACT_MUL_AUX, P1, DEEP>), grid, block, 0, st, g); return; }
+    const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    if (lean && !ta && !tb) { MICO_LAUNCH((gemm_w4_kernel<T, false, false, ACT_LEAN, P1, DEEP>), grid, block, 0, st, g); return; }
+    if (lean && !ta && tb) { MICO_LAUNCH((gemm_w4_kernel<T, false, true, ACT_LEAN, P1, DEEP>), grid, block, 0, st, g); return; }
+    if (lean && ta && tb) { MICO_LAUNCH((gemm_w4_kernel<T, true, true, ACT_LEAN, P1, DEEP>), grid, block, 0, st, g); return; }
+    if (!ta && !tb) MICO_LAUNCH((gemm_w4_kernel<T, false, false, 0, P1, DEEP>), grid, block, 0, st, g);
+    else if (!ta && tb) MICO_LAUNCH((gemm_w4_kernel<T, false, true, 0, P1, DEEP>), grid, block, 0, st, g);
+    else if (ta && tb) MICO_LAUNCH((gemm_w4_kernel<T, true, true, 0, P1, DEEP>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_w4_kernel<T, true, false, 0, P1, DEEP>), grid, block, 0, st, g);
+}
+
+#endif   // MICO_GEMM_W4 (launcher)
 
 // split factor for fp32-accumulating (weight-gradient) GEMMs: fill `slots` resident workgroups in whole waves.
 // cost(s) = waves(s) * (k-tiles per split + fixed prologue / atomic-epilogue cost in k-tile units)
@@ -863,6 +1229,8 @@ int mico_set_err(int code, const char* fmt, ...) {
 }
 
 thread_local int g_mico_last_gemm_kernel = 0;
+static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-wave-per-SIMD kernel; 2 = it takes every large problem
+extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant; g_mico_gemm_variant = v; return old; }
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
 extern "C" int mico_version(void) { return 103; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
@@ -903,23 +1271,34 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     const bool big = (big_tiles >= 128 || long_k_acc) && N >= 192;
     // the producer/consumer kernel (192x256) takes every large problem; MICO_GEMM_NO_PC (ablation builds) keeps the 8-wave kernel
 #ifdef MICO_GEMM_NO_PC
-    const bool pc = false;
+    bool pc = false;
 #else
     // measured (tools/gemm_bench.py, ViT-g/14 shapes): the producer/consumer kernel wins for the weight-gradient orientation
     // (both operands reduction-major, long K per workgroup: 911 vs 730 TFLOP/s) and loses for the short-K forward / dX GEMMs
     // (742-866 vs 946-960), whose per-tile prologue + epilogue cost weighs more on the smaller 192x256 tile
 #ifdef MICO_GEMM_PC_ALL
-    const bool pc = big;
+    bool pc = big;
 #else
     // (its epilogue is the lean instantiation: launches with an aux copy / activation / dropout / pos / remap stay on the 8-wave kernel)
-    const bool pc = big && ta && tb && g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    bool pc = big && ta && tb && g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
 #endif
 #endif
+    // the one-wave-per-SIMD kernel has no masked K-tail path: a k-contiguous operand needs K % 64 == 0 (reduction-major ones end at
+    // their descriptor bound); its DMA offsets are 31-bit (operand extent reachable from a tile's base < 2 GiB)
+    const int64_t a_ext = ta ? (K + 64) * lda * 2 : 256 * lda * 2 + K * 2, b_ext = tb ? (K + 64) * ldb * 2 : 256 * ldb * 2 + K * 2;
+#ifdef MICO_GEMM_W4
+    const bool w4_built = true;
+#else
+    const bool w4_built = false;
+#endif
+    const bool w4 = w4_built && big && g_mico_gemm_variant >= 2 && (ta || K % 64 == 0) && (tb || K % 64 == 0) && a_ext < 0x7FFFFF00ll && b_ext < 0x7FFFFF00ll;
+    if (w4) pc = false;
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = big ? 256 : 128;
     const int slots = big ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
     g.ntiles = g.ntm * g.ntn;
-    const int BKc = pc ? pc_bk(ta, tb) : (big ? Big::BK : Small::BK);
+    const bool deep = g_mico_gemm_variant == 3;
+    const int BKc = w4 ? (deep ? 32 : 64) : pc ? pc_bk(ta, tb) : (big ? Big::BK : Small::BK);
     g.ktiles = (int)((K + BKc - 1) / BKc);
     if (split_k <= 0) {
         if (!(c_dtype == MICO_F32 && g.e.accumulate)) split_k = 1;
@@ -958,7 +1337,12 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
     MICO_CHECK(g.e.drop_p >= 0.f && g.e.drop_p < 1.f, "mico_gemm: drop_p must be in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
-    g_mico_last_gemm_kernel = pc ? 2 : (big ? 1 : 0);
+    g_mico_last_gemm_kernel = w4 ? 3 : pc ? 2 : (big ? 1 : 0);
+#ifdef MICO_GEMM_W4
+    if (w4 && deep) DISPATCH_T16(dtype, (launch_w4<T, 1>(ta, tb, g, st)));
+    else if (w4) DISPATCH_T16(dtype, (launch_w4<T, 0>(ta, tb, g, st)));
+    else
+#endif
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
     else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));

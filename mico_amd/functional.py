@@ -125,7 +125,7 @@ class TowerSpec:
 def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None):
     """LayerNorm -> 16-bit GEMM operand.  Returns (buf, view, mean, rstd); in the split-precision (fp16 parity) mode buf is
     [rows, 2*cols] = [hi | lo] and view its hi half.  frame_map: compacting gather of whole frames (rows = kept rows)."""
-    split = runtime.split_precision() and cols % 64 == 0
+    split = runtime.split_activations() and cols % 64 == 0
     buf = _empty((rows, 2 * cols if split else cols), dt, dev)
     mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
     ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt, frame_map=frame_map,
@@ -863,7 +863,7 @@ class BertFn(torch.autograd.Function):
         emb = _empty((rows, D), torch.float32, dev)
         ops.bert_embed_fwd(ids, P("embeddings.word_embeddings.weight").detach(), P("embeddings.position_embeddings.weight").detach(),
                            P("embeddings.token_type_embeddings.weight").detach()[0].contiguous(), emb, S)
-        split0 = runtime.split_precision()
+        split0 = runtime.split_activations()
         x32, x16 = _empty((rows, D), torch.float32, dev), _empty((rows, 2 * D if split0 else D), dt, dev)
         mean_e, rstd_e = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
         ops.layernorm_fwd(emb, P("embeddings.LayerNorm.weight"), P("embeddings.LayerNorm.bias"), spec.eps, out16=x16, out32=x32,
@@ -886,7 +886,7 @@ class BertFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(hd)
         acts = []
 
-        split = runtime.split_precision()
+        split = runtime.split_activations()
 
         def ln_out(u, pre):
             o32 = _empty((rows, D), torch.float32, dev)

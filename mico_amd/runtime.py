@@ -21,6 +21,9 @@ class _Cfg:
     # fp16 parity configuration: forward GEMMs use hi/lo split weights (x W_hi + x W_lo in one launch through the kernel's
     # k-segments), which removes the weight-rounding half of the fp16 GEMM error.  Off for bf16 (throughput configuration).
     split_fp16 = True
+    # what is split when split_fp16 is on: "full" = weights AND LayerNorm outputs (3 k-segments, x_hi W_hi + x_lo W_hi + x_hi W_lo),
+    # "weights" = weights only (2 k-segments, x W_hi + x W_lo: removes the weight-rounding half of the error at 2x the MFMA work)
+    split_mode = "full"
     # training: project the cross-attention K/V of a step's condition tokens once (functional.CrossKVFn) instead of in every BERT pass
     share_cross_kv = True
 
@@ -158,6 +161,11 @@ def cast_weight(w, dt, k_pad=None, n_pad=None):
 
 def split_precision():
     return CFG.compute_dtype == torch.float16 and CFG.split_fp16
+
+
+def split_activations():
+    """LayerNorm emits [hi | lo] operands (the third k-segment of a split-precision forward GEMM)."""
+    return split_precision() and CFG.split_mode == "full"
 
 
 def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False):

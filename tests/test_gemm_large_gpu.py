@@ -20,7 +20,8 @@ def _ops(A, B, ta, tb):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
-@pytest.mark.parametrize("M,N,K", [(4096 + 77, 2048 + 8, 512 + 24), (6000, 1408, 352), (193 * 40 + 5, 4224, 96)])
+@pytest.mark.parametrize("M,N,K", [(4096 + 77, 2048 + 8, 512 + 24), (6000, 1408, 352), (193 * 40 + 5, 4224, 96),
+                                   (5000 + 13, 1408 + 8, 704), (257 * 32, 1536, 64), (8192 + 40, 2048, 1408)])
 def test_large_plain(cuda, dtype, ta, tb, M, N, K):
     from mico_amd import ops
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -51,6 +51,13 @@ def main():
                 fn()
             e1.record()
             torch.cuda.synchronize()
+            lib = ops._lib.lib()
+            if hasattr(lib, "mico_debug_w4_prof"):   # timing build (-DMICO_GEMM_ABLATE=8)
+                import ctypes
+                buf = (ctypes.c_ulonglong * 4)()
+                lib.mico_debug_w4_prof(buf)
+                if buf[3]:
+                    print(f"      per K-step of 32 (wave 0, s_memtime ticks): vmcnt wait {buf[0] / buf[3]:.0f}  barrier {buf[1] / buf[3]:.0f}  whole {buf[2] / buf[3]:.0f}")
             ms = e0.elapsed_time(e1) / a.iters
             tf = 2.0 * M * N * K / ms / 1e9
             res.append((name, cname, ms, tf))
