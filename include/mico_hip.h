@@ -29,6 +29,10 @@ extern "C" {
 /* library identity / errors */
 int mico_version(void);
 const char* mico_last_error_string(void);
+/* Layout of the parameter structs as THIS library was compiled, for bindings to verify theirs (tests/test_host_cpu.py compares the
+ * ctypes mirror field by field): writes up to n ints - sizeof(mico_gemm_epilogue), then the byte offset of each of its fields in
+ * declaration order, then -1, then sizeof(mico_attn_params), its field offsets, -1.  Returns the number of ints the full table has. */
+int mico_struct_layout(int* out, int n);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GEMM on MFMA (v_mfma_f32_16x16x32_{f16,bf16}), fp32 accumulate, fused epilogues.

@@ -44,6 +44,7 @@ class AttnParams(C.Structure):
 PROTOTYPES = {
     "mico_version": [],
     "mico_last_error_string": [],
+    "mico_struct_layout": [C.POINTER(c_int), c_int],
     "mico_gemm_last_kernel": [],
     "mico_gemm_set_variant": [c_int],
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,

@@ -25,6 +25,7 @@
 // split along K in whole waves of resident workgroups and combined with fp32 atomics.
 #include "common.h"
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <type_traits>
 
@@ -1234,6 +1235,31 @@ extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_varian
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
 extern "C" int mico_version(void) { return 103; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
+
+extern "C" int mico_struct_layout(int* out, int n) {
+#define OFF(S, F) (int)offsetof(S, F)
+    const int t[] = {
+        (int)sizeof(mico_gemm_epilogue),
+        OFF(mico_gemm_epilogue, bias), OFF(mico_gemm_epilogue, aux_out), OFF(mico_gemm_epilogue, aux_in), OFF(mico_gemm_epilogue, ldaux),
+        OFF(mico_gemm_epilogue, act), OFF(mico_gemm_epilogue, row_scale), OFF(mico_gemm_epilogue, rows_per_scale), OFF(mico_gemm_epilogue, resid),
+        OFF(mico_gemm_epilogue, pos), OFF(mico_gemm_epilogue, pos_rows), OFF(mico_gemm_epilogue, remap_group), OFF(mico_gemm_epilogue, remap_skip),
+        OFF(mico_gemm_epilogue, remap_offset), OFF(mico_gemm_epilogue, alpha), OFF(mico_gemm_epilogue, accumulate), OFF(mico_gemm_epilogue, nseg),
+        OFF(mico_gemm_epilogue, kseg), OFF(mico_gemm_epilogue, a_seg_off), OFF(mico_gemm_epilogue, b_seg_off), OFF(mico_gemm_epilogue, row_map),
+        OFF(mico_gemm_epilogue, rows_per_map), OFF(mico_gemm_epilogue, drop_p), OFF(mico_gemm_epilogue, drop_seed), OFF(mico_gemm_epilogue, drop_site),
+        -1,
+        (int)sizeof(mico_attn_params),
+        OFF(mico_attn_params, B), OFF(mico_attn_params, H), OFF(mico_attn_params, Sq), OFF(mico_attn_params, Sk), OFF(mico_attn_params, hd),
+        OFF(mico_attn_params, q_bs), OFF(mico_attn_params, q_rs), OFF(mico_attn_params, k_bs), OFF(mico_attn_params, k_rs), OFF(mico_attn_params, v_bs),
+        OFF(mico_attn_params, v_rs), OFF(mico_attn_params, o_bs), OFF(mico_attn_params, o_rs), OFF(mico_attn_params, scale), OFF(mico_attn_params, mask),
+        OFF(mico_attn_params, mask_mode), OFF(mico_attn_params, drop_p), OFF(mico_attn_params, drop_seed), OFF(mico_attn_params, drop_site),
+        OFF(mico_attn_params, kv_batch_mod),
+        -1,
+    };
+#undef OFF
+    const int total = (int)(sizeof(t) / sizeof(t[0]));
+    for (int i = 0; i < n && i < total; ++i) out[i] = t[i];
+    return total;
+}
 
 extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                          int64_t ldb, void* C, int64_t ldc, int c_dtype, const mico_gemm_epilogue* epi, int split_k,

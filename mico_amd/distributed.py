@@ -183,6 +183,7 @@ class GradBucketReducer:
                 self._where[p] = bi
         self._early = set()          # ids of parameters whose gradient was already reduced inside a backward (arena slices)
         self._early_handles = []
+        self._early_slices = []      # (flat arena slice, its parameters) of those reductions: finish() checks the aliasing
         if is_dist():
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -195,6 +196,13 @@ class GradBucketReducer:
         all-reduce it in place right away - no bucket copy, and it overlaps with the backward of the earlier blocks."""
         if not is_dist():     # the process group is gone (a reducer outliving its group): nothing to reduce
             return
+        # In-place reduction of the arena slice is only right when autograd will ADOPT the arena views as the parameters' .grad, i.e.
+        # when none of them has a gradient yet (zero_grad(set_to_none=True), one backward per step).  With an existing .grad
+        # (accumulation, set_to_none=False) autograd ADDS the view into it on the compute stream - while RCCL would be reducing that
+        # memory - and the result would stay rank-local: leave such slices to the bucket path, which reduces the accumulated .grad.
+        if any(p.grad is not None for p in params):
+            return
+        self._early_slices.append((flat, list(params)))
         if _nccl():
             h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
             self._early_handles.append((h, None, flat))
@@ -205,14 +213,21 @@ class GradBucketReducer:
 
     def reset(self):
         self._pending = {bi: len(b) for bi, b in enumerate(self.buckets)}
+        self._seen = {}
         self._launched = set()
         self._handles = []
         self._early = set()
         self._early_handles = []
+        self._early_slices = []
 
     def _hook(self, p):
         bi = self._where[p]
         self._pending[bi] -= 1
+        if self._seen.get(id(p), 0) > 0:
+            raise RuntimeError("GradBucketReducer: a parameter's gradient was accumulated twice before finish() (two backward passes in one "
+                               "step?) - its bucket was already reduced; call finish() after every backward, or accumulate locally and "
+                               "build the reducer for the last micro-step only")
+        self._seen[id(p)] = self._seen.get(id(p), 0) + 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
@@ -238,6 +253,18 @@ class GradBucketReducer:
             h.wait()
             if flat is not None:     # gloo has no AVG: sum, then scale
                 flat.div_(W)
+        # the reduced slices ARE the parameters' gradients only if autograd adopted the arena views; where it made its own tensor
+        # instead, hand the averaged values over (views of a slice start at 16-byte aligned offsets, see functional.GradArena)
+        for flat, params in self._early_slices:
+            o = 0
+            for p in params:
+                n = p.numel()
+                view = flat[o:o + n].view(p.shape)
+                if p.grad is None:
+                    p.grad = view
+                elif p.grad.data_ptr() != view.data_ptr():
+                    p.grad.copy_(view)
+                o += (n + 3) // 4 * 4
         for h, flat, grads in self._handles:
             h.wait()
             flat.div_(W)

@@ -493,6 +493,7 @@ def tower_chunk_frames(spec, n_frames, device):
 class EvaTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, groups, dp_scale, *params):
+        runtime.remember_precision(ctx)
         Bf = sum(g.shape[0] for g in groups)
         needs_grad = any(ctx.needs_input_grad)    # False under torch.no_grad(): nothing is kept for a backward then
         chunk = tower_chunk_frames(spec, Bf, params[0].device) if needs_grad else Bf
@@ -516,6 +517,7 @@ class EvaTowerFn(torch.autograd.Function):
         return torch.cat(outs, dim=0)
 
     @staticmethod
+    @runtime.saved_precision
     def backward(ctx, dout):
         spec, params = ctx.spec, ctx.params
         grads = GradArena(params)
@@ -649,6 +651,7 @@ class _LayerNormF32(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g, b, eps):
+        runtime.remember_precision(ctx)
         x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
         rows = x2.shape[0]
         y = torch.empty_like(x2)
@@ -659,6 +662,7 @@ class _LayerNormF32(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @runtime.saved_precision
     def backward(ctx, dy):
         x2, g, mean, rstd = ctx.saved_tensors
         dy2 = dy.reshape(x2.shape).contiguous().float()
@@ -703,6 +707,7 @@ class _CondPack(torch.autograd.Function):
     def forward(ctx, feats, w, b, g, beta, table, rows_per_group):
         """feats [rows, Dv] fp32; table [groups, 768] fp32 (frame + type embedding per frame slot);
         output row r gets table[(r // rows_per_group) % groups]."""
+        runtime.remember_precision(ctx)
         dt = runtime.compute_dtype()
         dev = feats.device
         rows, Dv = feats.shape
@@ -721,6 +726,7 @@ class _CondPack(torch.autograd.Function):
         return y
 
     @staticmethod
+    @runtime.saved_precision
     def backward(ctx, dy):
         x16, u, mean, rstd, w, g = ctx.saved_tensors
         rpg, groups, dt = ctx.meta
@@ -790,6 +796,7 @@ class CrossKVFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, cond_own, cond_neg, *kvparams):
+        runtime.remember_precision(ctx)
         # kvparams: per layer key.weight, key.bias, value.weight, value.bias
         dt = runtime.compute_dtype()
         dev = cond_own.device
@@ -810,6 +817,7 @@ class CrossKVFn(torch.autograd.Function):
         return kv, None
 
     @staticmethod
+    @runtime.saved_precision
     def backward(ctx, dkv_own, dkv_neg):
         spec, kvparams, cond16 = ctx.spec, ctx.kvparams, ctx.cond16
         n, E, D = ctx.shape
@@ -846,6 +854,7 @@ class BertFn(torch.autograd.Function):
         drop: None (eval), (p_hidden, p_attention, seed) - train-mode dropout of bert.py:148,267,295,373 - or a dict
         {"kv_cache": {...}} (inference only): the per-layer cross-attention K/V projections of `cond` are stored in / taken from
         that dict, so a decode loop projects its (constant) condition tokens once instead of at every step."""
+        runtime.remember_precision(ctx)
         kv_cache = None
         if isinstance(drop, dict):
             kv_cache, drop = drop["kv_cache"], None
@@ -956,6 +965,7 @@ class BertFn(torch.autograd.Function):
         return x32.view(b, S, D)
 
     @staticmethod
+    @runtime.saved_precision
     def backward(ctx, dseq):
         spec, params, dt = ctx.spec, ctx.params, ctx.dt
         P = lambda n: params[spec.idx[n]]
@@ -1090,6 +1100,7 @@ VOCAB_PAD = 64
 class LMHeadLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seq, labels, wt, bt, g, beta, wdec, bdec):
+        runtime.remember_precision(ctx)
         dt = runtime.compute_dtype()
         dev = seq.device
         D = seq.shape[-1]
@@ -1120,6 +1131,7 @@ class LMHeadLossFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @runtime.saved_precision
     def backward(ctx, gout):
         x16, pre, act, hl, mean, rstd, logits, lab, n_valid, wt, g, wdec = ctx.saved_tensors
         dt, V, Vp, seq_shape = ctx.meta
@@ -1128,6 +1140,10 @@ class LMHeadLossFn(torch.autograd.Function):
         S = runtime.grad_scale()
         inv_s = 1.0 / S
         dsc = (gout.float() * S / n_valid).reshape(1).contiguous()
+        if getattr(ctx, "_logits_consumed", False):
+            raise RuntimeError("LMHeadLossFn: a second backward through the same graph - the 16-bit logits were overwritten by their "
+                               "gradient in the first one (no fp32 [rows, 30522] copy is kept); re-run the forward instead of retain_graph")
+        ctx._logits_consumed = True
         dlog = logits   # overwrite the logits with their gradient (same dtype / shape)
         if Vp != V:
             dlog[:, V:].zero_()

@@ -21,8 +21,14 @@ VISION_TYPES = {   # mico.py:323-349
 
 
 class AttrDict(dict):
-    """easydict-like config object (the reference passes an EasyDict as `opts`)."""
-    __getattr__ = dict.get
+    """easydict-like config object (the reference passes an EasyDict as `opts`): attribute access to the keys, AttributeError for a
+    missing / misspelled key exactly like EasyDict (so hasattr() means what it says); .get(key) for optional ones."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
 
     def __setattr__(self, k, v):
         self[k] = v
@@ -119,6 +125,10 @@ class MMGeneralModule(nn.Module):
 
     def load_clip_model(self):
         t = self.config.vision_encoder_type
+        if t == "evaclip02_bige":
+            # mico.py:341-344 accepts EVA02-CLIP-bigE-14-plus (64 post-norm blocks, width 1792, xattn); the MI355X tower implements the
+            # pre-norm block of the B/16, L/14 and g/14 towers only (postnorm False on the hot path)
+            raise NotImplementedError("evaclip02_bige (EVA02-CLIP-bigE-14-plus, post-norm) is not supported by the MI355X tower")
         if t not in VISION_TYPES:
             raise NotImplementedError(t)
         name, self.vision_dim = VISION_TYPES[t]
@@ -177,7 +187,7 @@ class MMGeneralModule(nn.Module):
             x = 2
         trans = getattr(self, f"hidden_trans_{modality}_multimodal")
         fe = getattr(self, f"{modality}_frame_embedding")
-        if modality == "vision" and self.config.frame_embedding_type == "none":
+        if modality == "vision" and self.config.frame_embedding_type != "adaptive":   # mico.py:195-204: added for 'adaptive' only
             table = torch.zeros((n, self.multimodal_dim), dtype=torch.float32, device=feats.device)
         else:
             if n != fe.shape[1]:   # nearest interpolation of the frame slots (mico.py:196-200)

@@ -61,6 +61,9 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
     leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
     dtype = dtype or A.dtype
+    if A.dtype != B.dtype:   # the kernel takes ONE element type for both operands: mixed bit patterns would multiply silently
+        raise MicoHipError(f"mico_gemm operands differ in dtype ({A.dtype} x {B.dtype}): a backward pass running under another "
+                           "runtime.precision than its forward?")
     if M is None:
         M = A.shape[1] if ta else A.shape[0]
     if K is None:

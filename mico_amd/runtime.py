@@ -54,6 +54,39 @@ def precision(dtype):
         CFG.compute_dtype = old
 
 
+def snapshot():
+    """The precision state a forward pass ran under; see using()."""
+    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode)
+
+
+@contextlib.contextmanager
+def using(state):
+    """Re-establish a snapshot() for the duration of a backward pass: saved activations are in the forward's dtype / gradient scale,
+    so the backward must take its weights, its gradient scale and its split mode from the same state even when it runs outside the
+    `with precision(...)` block the forward ran in (fp16 activations were otherwise multiplied by bf16-bit weights)."""
+    old = snapshot()
+    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode = state
+    try:
+        yield
+    finally:
+        CFG.compute_dtype, CFG.split_fp16, CFG.split_mode = old
+
+
+def saved_precision(backward):
+    """Decorator for autograd.Function.backward: runs it under the precision state its forward stored with remember_precision(ctx)."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        with using(ctx._mico_precision):
+            return backward(ctx, *grads)
+    return wrapped
+
+
+def remember_precision(ctx):
+    ctx._mico_precision = snapshot()
+
+
 _UID = [0]
 
 
@@ -142,7 +175,9 @@ def after_optimizer_step(refreshed_ids):
     A foreign optimizer that writes through `.data` (as the reference's does) must call clear_weight_cache() after its step."""
     for key in list(_W16):
         src = _ENTRY_SRC.get(key)
-        if src is None or not all(i in refreshed_ids for i in src):
+        # only the mirrors in the ACTIVE compute dtype were refreshed (_live_copies): an entry of the other dtype built from the same
+        # parameters is stale even though its parameter ids are in refreshed_ids (e.g. bf16 training interleaved with fp16 evaluation)
+        if src is None or key[1] != CFG.compute_dtype or not all(i in refreshed_ids for i in src):
             del _W16[key]
             _ENTRY_SRC.pop(key, None)
             _ENTRY_REFS.pop(key, None)

@@ -93,6 +93,87 @@ def _reducer(rank, world):
             assert torch.allclose(p.grad, sum(gs) / world, atol=1e-6)
 
 
+class _ArenaFn(torch.autograd.Function):
+    """Stand-in for the ViT tower's backward: parameter gradients live in one flat arena, the finished slice is announced to
+    runtime.grad_slice_hook() from INSIDE the backward (functional._tower_backward does this per block)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        from mico_amd import runtime
+        from mico_amd.functional import GradArena
+        x, w = ctx.saved_tensors
+        arena = GradArena([w, dy.new_empty(w.shape[0])])
+        arena.get(0).copy_(dy.t() @ x)
+        arena.get(1).copy_(dy.sum(0))
+        hook = runtime.grad_slice_hook()
+        if hook is not None:
+            hook(arena.span(0, 2), [ctx.w_param, ctx.b_param])
+        return dy @ w, arena.get(0), arena.get(1)
+
+
+def _arena_reducer(rank, world):
+    """The early in-place all-reduce of an arena slice: right when autograd adopts the arena views (no prior .grad), and
+    left to the bucket path when a .grad already exists (set_to_none=False / accumulation); a second backward before finish() raises."""
+    from mico_amd.distributed import GradBucketReducer
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 5)
+    red = GradBucketReducer(lin.parameters(), bucket_bytes=1 << 20)
+
+    def run(x):
+        fn_ctx = {}
+        class F(_ArenaFn):
+            @staticmethod
+            def backward(ctx, dy):
+                ctx.w_param, ctx.b_param = lin.weight, lin.bias
+                return _ArenaFn.backward(ctx, dy)
+        F.apply(x, lin.weight, lin.bias).square().sum().backward()
+
+    def expect(x_of_rank, prior=None):
+        tot = [torch.zeros_like(p) for p in lin.parameters()]
+        for r in range(world):
+            xr = x_of_rank(r)
+            y = (xr @ lin.weight.detach().t() + lin.bias.detach())
+            dy = 2 * y
+            tot[0] += dy.t() @ xr
+            tot[1] += dy.sum(0)
+        out = [t / world for t in tot]
+        if prior is not None:
+            out = [o + p for o, p in zip(out, prior)]
+        return out
+
+    xs = lambda step: (lambda r: torch.randn(4, 6, generator=torch.Generator().manual_seed(50 * step + r)))
+    # (1) no prior gradient: early path, views adopted
+    lin.zero_grad(set_to_none=True)
+    run(xs(0)(rank))
+    assert len(red._early_slices) == 1
+    red.finish()
+    for p, e in zip(lin.parameters(), expect(xs(0))):
+        assert torch.allclose(p.grad, e, atol=1e-5), (p.grad - e).abs().max()
+    # (2) an existing .grad (zeros from set_to_none=False): the early path must stand back, the bucket path reduces the sum
+    lin.zero_grad(set_to_none=False)
+    run(xs(1)(rank))
+    assert len(red._early_slices) == 0
+    red.finish()
+    for p, e in zip(lin.parameters(), expect(xs(1))):
+        assert torch.allclose(p.grad, e, atol=1e-5), (p.grad - e).abs().max()
+    # (3) two backward passes before finish(): refused loudly instead of leaving the second contribution rank-local
+    lin.zero_grad(set_to_none=True)
+    run(xs(2)(rank))
+    try:
+        run(xs(3)(rank))
+        raise AssertionError("expected the double-accumulation guard to fire")
+    except RuntimeError as e:
+        assert "accumulated twice" in str(e)
+    red.reset()
+    from mico_amd import runtime
+    runtime.set_grad_slice_hook(None)
+
+
 def _targets(rank, world):
     """ITC targets and the own-rank diagonal (vast.py:409-427) as MiCo.forward computes them, against a single-process
     evaluation on the concatenated global batch."""
@@ -116,7 +197,7 @@ def _targets(rank, world):
     assert (w[torch.arange(b), targets] == 0).all() and (w > 0).sum() == b * (world * b - 1)
 
 
-@pytest.mark.parametrize("fn", [_packed, _fetch, _reducer, _targets])
+@pytest.mark.parametrize("fn", [_packed, _fetch, _reducer, _arena_reducer, _targets])
 def test_world2_gloo(fn):
     run2(fn)
 

@@ -33,6 +33,43 @@ def test_library_exports_every_declared_symbol():
     assert l.mico_version() >= 100
 
 
+def test_ctypes_structs_match_the_compiled_layout():
+    """The parameter structs the ctypes binding builds are the structs the library was compiled with: size and every field offset,
+    in declaration order (a stray trailing field in the ctypes GemmEpilogue went unnoticed because only symbol names
+    were compared).  No kernel runs: mico_struct_layout() is host code."""
+    import ctypes
+    from mico_amd import _lib
+    l = _lib.lib()
+    n = l.mico_struct_layout(None, 0)
+    buf = (ctypes.c_int * n)()
+    assert l.mico_struct_layout(buf, n) == n
+    table, cur = [], []
+    for v in buf:
+        if v == -1:
+            table.append(cur)
+            cur = []
+        else:
+            cur.append(v)
+    assert len(table) == 2
+    for cls, (size, *offs) in zip((_lib.GemmEpilogue, _lib.AttnParams), table):
+        assert ctypes.sizeof(cls) == size, (cls.__name__, ctypes.sizeof(cls), size)
+        mine = [getattr(cls, name).offset for name, _ in cls._fields_]
+        assert mine == offs, (cls.__name__, mine, offs)
+    # and the header's field lists are what the table was built from (a field added to the header but not to the table would hide here)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mico_hip.h")).read(), flags=re.S)
+    for struct, cls in (("mico_gemm_epilogue", _lib.GemmEpilogue), ("mico_attn_params", _lib.AttnParams)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = decl.split(",")
+            names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?$", first.strip())[0])
+            names += [re.findall(r"([A-Za-z_][A-Za-z0-9_]*)", r.strip())[0] for r in rest]
+        assert names == [n_ for n_, _ in cls._fields_], (struct, names)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from mico_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
