@@ -252,6 +252,12 @@ int mico_embed_scatter_add(const int64_t* ids, const float* dsum, float* dword, 
  *     dlogits (16-bit or fp32, may be NULL) = dscale * (softmax - smoothed_onehot)   (0 for ignored rows)
  *  Replaces F.cross_entropy in vast.py:411-414,455 and bert.py:1088-1090 (logits_scale = 1/temp for ITC).
  * ------------------------------------------------------------------------------------------------------------- */
+/* ITM hard-negative sampling (data/model/vast.py:423-440: weights = softmax(sim, 1) + 1e-4, own-rank diagonal zeroed, one multinomial
+ * draw per row - there a Python loop with a .item() host sync per row).  sim: fp32 [rows, cols] (ld) similarity logits AFTER the
+ * temperature; row r never draws column diag_offset + r (= rank * b + r); u: fp32 [rows] uniform numbers in [0, 1) supplied by the
+ * caller (injected for parity, torch.rand otherwise); out[r] = #{j : cdf_r[j] < u[r] * total_r} (inverse-CDF draw), int64. */
+int mico_itm_sample(const float* sim, int64_t ld, int rows, int cols, int diag_offset, const float* u, int64_t* out, void* stream);
+
 int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t rows, int cols,
                     const int64_t* target, int ignore_index, float label_smoothing, float logits_scale,
                     float* row_loss, float* row_lse,

@@ -66,7 +66,54 @@ __global__ __launch_bounds__(256) void ce_kernel(const LT* __restrict__ logits, 
     }
 }
 
+// ITM hard-negative draw (vast.py:423-440): one wave per row, every lane a contiguous chunk of the row (the row is read three times
+// from L1: max, sum of exponentials, weights).  idx = #{j : cdf_j < u * total} is a pure counting problem once every lane knows the
+// exclusive prefix of its chunk, so no lane has to be singled out.
+__global__ __launch_bounds__(64) void itm_sample_kernel(const float* __restrict__ sim, int64_t ld, int cols, int diag_offset,
+                                                        const float* __restrict__ u, int64_t* __restrict__ out) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float* x = sim + (int64_t)row * ld;
+    const int chunk = (cols + 63) / 64;
+    const int j0 = min(cols, lane * chunk), j1 = min(cols, j0 + chunk);
+    float m = -3.0e38f;
+    for (int j = j0; j < j1; ++j) m = fmaxf(m, x[j]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int j = j0; j < j1; ++j) se += __expf(x[j] - m);
+    se = wave_sum(se);
+    const float inv = 1.f / se;
+    const int dcol = diag_offset + row;
+    float part = 0.f;
+    for (int j = j0; j < j1; ++j) part += (j == dcol) ? 0.f : fmaf(__expf(x[j] - m), inv, 1e-4f);
+    float incl = part;   // inclusive scan over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    const float total = __shfl(incl, 63, 64);
+    const float tgt = u[row] * total;
+    float run = incl - part;
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) {
+        run += (j == dcol) ? 0.f : fmaf(__expf(x[j] - m), inv, 1e-4f);
+        cnt += run < tgt;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane == 0) out[row] = min(cnt, cols - 1);
+}
+
 }  // namespace
+
+extern "C" int mico_itm_sample(const float* sim, int64_t ld, int rows, int cols, int diag_offset, const float* u, int64_t* out,
+                               void* stream) {
+    MICO_CHECK(sim && u && out && cols > 0 && ld >= cols, "mico_itm_sample: bad args");
+    if (rows <= 0) return MICO_OK;
+    MICO_LAUNCH(itm_sample_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, sim, ld, cols, diag_offset, u, out);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
 
 extern "C" int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t rows, int cols,
                                const int64_t* target, int ignore_index, float label_smoothing, float logits_scale,

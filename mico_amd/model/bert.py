@@ -263,7 +263,7 @@ class BertForMaskedLM(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, max_new_tokens=20, num_beams=1,
-                 eos_token_id=None, pad_token_id=None, length_penalty=1.0, **unused):
+                 eos_token_id=None, pad_token_id=None, length_penalty=1.0, do_sample=False, top_k=50, sample_noise=None, **unused):
         """Beam search with the semantics of transformers==4.31 GenerationMixin.generate / BeamSearchScorer as the reference
         calls it (inference_demo.py:164-171: num_beams 3, length_penalty 0.6, early_stopping False, no logits processors):
         2*num_beams candidates per step, finished hypotheses scored sum_logprob / len**length_penalty, the "cannot improve"
@@ -271,6 +271,11 @@ class BertForMaskedLM(nn.Module):
         the host over 2*num_beams candidates per sample; the model step and log-softmax / top-k run on the device."""
         if unused:
             raise TypeError(f"generate(): unsupported arguments {sorted(unused)}")
+        if do_sample:
+            if int(num_beams) != 1:
+                raise TypeError("generate(): do_sample with num_beams > 1 (beam sampling) is not used by the reference and not provided")
+            return self._sample(input_ids, attention_mask, encoder_hidden_states, max_new_tokens, int(top_k), eos_token_id,
+                                pad_token_id, sample_noise)
         dev = input_ids.device
         B, cur = input_ids.shape
         nb = int(num_beams)
@@ -335,6 +340,42 @@ class BertForMaskedLM(nn.Module):
             if lens[b] < width:
                 out[b, lens[b]] = eos_token_id
         return out.to(dev)
+
+
+    def _sample(self, input_ids, attention_mask, enc, max_new_tokens, top_k, eos_token_id, pad_token_id, noise):
+        """Top-k sampling as the reference's captioner_mode asks transformers 4.31 for it (vast.py:526-536: do_sample=True, top_k=10,
+        temperature 1): per step the top_k logits are kept (TopKLogitsWarper), softmax over them, ONE draw per row; rows that have
+        produced eos emit pad from then on; stop when every row has finished or max_length is reached.  The draw is inverse-CDF over
+        the kept candidates in descending-score order with one uniform number per (row, step): `noise` [rows, max_new_tokens] injects
+        them (parity tests), otherwise they come from torch's generator - the same distribution as torch.multinomial, not the same
+        stream.  Device: model step + top-k; host: k candidates per row."""
+        dev = input_ids.device
+        B, cur = input_ids.shape
+        max_length = cur + int(max_new_tokens)
+        ids, mask = input_ids, attention_mask
+        unfinished = torch.ones(B, dtype=torch.bool)
+        kv_cache = {} if enc is not None else None
+        if enc is not None:
+            enc = enc.contiguous()
+        step = 0
+        while True:
+            logits = self.next_token_logits(ids, mask, enc, kv_cache).float()
+            top_s, top_i = torch.topk(logits, min(top_k, logits.shape[-1]), dim=-1, largest=True, sorted=True)
+            probs = torch.softmax(top_s, dim=-1).cpu().double()
+            top_i = top_i.cpu()
+            u = noise[:, step].double().cpu() if noise is not None else torch.rand(B, dtype=torch.float64)
+            cdf = probs.cumsum(-1)
+            pick = (cdf < (u * cdf[:, -1])[:, None]).sum(-1).clamp_max(probs.shape[-1] - 1)
+            tok = top_i[torch.arange(B), pick]
+            if eos_token_id is not None:
+                tok = torch.where(unfinished, tok, torch.full_like(tok, pad_token_id if pad_token_id is not None else 0))
+                unfinished = unfinished & (tok != eos_token_id)
+            ids = torch.cat([ids, tok.view(-1, 1).to(dev)], dim=1)
+            mask = self.update_attention_mask(mask)
+            step += 1
+            if not bool(unfinished.any()) or ids.shape[1] >= max_length:
+                break
+        return ids
 
 
 class _BeamHypotheses:

@@ -13,7 +13,7 @@ batch keys: vision_pixels [b,n,3,h,w] | audio_spectrograms [b,n,h,w] | depth_pix
 import torch
 
 from .. import distributed as D
-from .. import functional as Fn
+from .. import functional as Fn, ops
 from .. import runtime
 
 COND_MODALITY = {"v": "vision", "a": "audio", "d": "depth"}
@@ -117,13 +117,13 @@ def _forward_ret(self, batch, enc, subtasks):
         if st in inj:
             neg_c, neg_t = inj[st]["neg_cond_idx"].to(ids.device), inj[st]["neg_text_idx"].to(ids.device)
         else:
-            with torch.no_grad():
-                w_t2c = torch.softmax(sim_t2c.detach(), dim=1) + 1e-4
-                w_t2c[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
-                w_c2t = torch.softmax(sim_c2t.detach(), dim=1) + 1e-4
-                w_c2t[:, rank * bs: rank * bs + bs].fill_diagonal_(0)
-                neg_c = torch.multinomial(w_t2c, 1).view(-1)     # one device-side draw per row, no .item() host syncs
-                neg_t = torch.multinomial(w_c2t, 1).view(-1)
+            # one kernel per direction: softmax + 1e-4, own-rank diagonal zeroed, inverse-CDF draw per row (mico_itm_sample) - the
+            # reference loops over rows with a .item() host sync each (vast.py:428-440); `_itm_uniform` injects the random numbers
+            un = inj.get("_itm_uniform", {}).get(st)
+            u_c, u_t = (un[0].to(ids.device), un[1].to(ids.device)) if un is not None else (
+                torch.rand(bs, device=ids.device), torch.rand(bs, device=ids.device))
+            neg_c = ops.itm_sample(sim_t2c.detach(), rank * bs, u_c.float())
+            neg_t = ops.itm_sample(sim_c2t.detach(), rank * bs, u_t.float())
         if world:
             cond_neg = world[f"cond_{st[1:]}_fetch"](cond, neg_c)
         else:
@@ -194,11 +194,21 @@ def forward(self, batch, task, compute_loss=True):
             if compute_loss:
                 out.update(_forward_cap(self, batch, enc, subtasks))
             else:   # evaluation dict of vast.py:513-547: beam-search captions per sub-task (captioner_mode sampling is not provided)
-                if getattr(self.config, "captioner_mode", False):
-                    raise NotImplementedError("captioner_mode (top-k sampling) is not provided; beam search is")
                 tk = self.multimodal_encoder.tokenizer
                 for st in subtasks:
                     cond = _condition_feats(self, enc, st[1:])
+                    if self.config.get("captioner_mode", False):
+                        # vast.py:519-536: generate_nums sampled captions per sample (top-k 10 sampling), rows sample-major
+                        gn = int(self.config.generate_nums)
+                        cond = cond.unsqueeze(1).expand(-1, gn, -1, -1).reshape(-1, *cond.shape[1:]).contiguous()
+                        init = torch.full((cond.shape[0], 1), tk.bos_token_id, dtype=torch.long, device=cond.device)
+                        ids = self.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(cond.shape[0], 1, 1),
+                                                               do_sample=True, top_k=10, encoder_hidden_states=cond,
+                                                               max_new_tokens=self.max_caption_len, eos_token_id=tk.sep_token_id,
+                                                               pad_token_id=tk.pad_token_id,
+                                                               sample_noise=(batch.get("_injected") or {}).get("sample_noise"))
+                        out[f"generated_captions_{st}"] = tk.batch_decode(ids[:, 1:], skip_special_tokens=True)
+                        continue
                     init = torch.full((cond.shape[0], 1), tk.bos_token_id, dtype=torch.long, device=cond.device)
                     ids = self.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(cond.shape[0], 1, 1),
                                                            encoder_hidden_states=cond, max_new_tokens=self.max_caption_len,

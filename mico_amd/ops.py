@@ -280,6 +280,15 @@ def ce_fwd_bwd(logits, target, *, cols=None, ignore_index=-100, label_smoothing=
           "mico_ce_fwd_bwd")
 
 
+def itm_sample(sim, diag_offset, u):
+    """One hard-negative index per row of the fp32 similarity logits `sim` [rows, cols]; see mico_itm_sample."""
+    sim = sim.contiguous()
+    out = torch.empty(sim.shape[0], dtype=torch.int64, device=sim.device)
+    check(_lib.lib().mico_itm_sample(_p(sim), sim.stride(0), sim.shape[0], sim.shape[1], int(diag_offset), _p(u.contiguous()), _p(out), _st()),
+          "mico_itm_sample")
+    return out
+
+
 def l2norm_fwd(x, y, inv_norm):
     check(_lib.lib().mico_l2norm_fwd(_p(x), _p(y), _p(inv_norm), x.shape[0], x.shape[1], _st()), "mico_l2norm_fwd")
 

@@ -598,3 +598,42 @@ def generate_beam(sd, cond, max_new_tokens, num_beams, length_penalty, bos=101, 
         if len(h) < width:
             out[b, len(h)] = eos
     return out
+
+
+def generate_sample(sd, cond, max_new_tokens, top_k, noise, bos=101, eos=102, pad=0, mask_token_id=103):
+    """Top-k sampling decode of the reference's captioner_mode (data/model/vast.py:526-536: do_sample=True, top_k=10) under the
+    transformers==4.31 `sample` loop semantics (TopKLogitsWarper -> softmax -> one draw per row; finished rows emit pad; stop when all
+    rows are finished or at max_length).  Third-party arithmetic absent from the reference tree ("parity unpinned"): the draw is
+    restated as inverse-CDF over the kept candidates in descending order with the injected uniform numbers noise[row, step]."""
+    B = cond.shape[0]
+    ids = torch.full((B, 1), bos, dtype=torch.long)
+    mask = torch.ones(B, 1, 1, dtype=torch.long)
+    alive = torch.ones(B, dtype=torch.bool)
+    for step in range(max_new_tokens):
+        logits = decode_step_logits(sd, ids, mask, cond, mask_token_id).float()
+        top_s, top_i = torch.topk(logits, top_k, dim=-1)
+        cdf = torch.softmax(top_s, -1).double().cumsum(-1)
+        pick = (cdf < (noise[:, step].double() * cdf[:, -1])[:, None]).sum(-1).clamp_max(top_k - 1)
+        tok = top_i[torch.arange(B), pick]
+        tok = torch.where(alive, tok, torch.full_like(tok, pad))
+        alive = alive & (tok != eos)
+        ids = torch.cat([ids, tok[:, None]], 1)
+        mask = grow_mask(mask)
+        if not bool(alive.any()):
+            break
+    return ids
+
+
+def itm_sample(sim, rank, bs, u):
+    """Hard-negative draw of data/model/vast.py:423-440: weights = softmax(sim, 1) + 1e-4 with the own-rank diagonal zeroed, one
+    multinomial draw per row.  The reference draws with torch.multinomial (global generator); restated here as inverse-CDF with the
+    injected uniform numbers u[row] (same distribution).  Returns (indices, margin): margin[row] = distance of u * total to the nearest
+    CDF edge relative to total - rows with a tiny margin may legitimately differ by one under another summation order."""
+    w = torch.softmax(sim.float(), dim=1) + 1e-4
+    r = torch.arange(bs)
+    w[r, rank * bs + r] = 0
+    cdf = w.double().cumsum(1)
+    tgt = u.double() * cdf[:, -1]
+    idx = (cdf < tgt[:, None]).sum(1).clamp_max(sim.shape[1] - 1)
+    margin = (cdf - tgt[:, None]).abs().min(1).values / cdf[:, -1]
+    return idx, margin

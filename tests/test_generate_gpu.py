@@ -47,7 +47,59 @@ def test_generate_matches_oracle(cuda, num_beams, sep_bias, max_new):
                 mask = O.grow_mask(mask)
         assert ids.tolist() == ref.tolist()
     with pytest.raises(TypeError):
-        m.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(3, 1, 1), do_sample=True)
+        m.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(3, 1, 1), temperature=0.7)
+
+
+@pytest.mark.parametrize("sep_bias,max_new", [(0.0, 6), (9.0, 8)])
+def test_generate_top_k_sampling_matches_oracle(cuda, sep_bias, max_new):
+    """captioner_mode decode (vast.py:526-536: do_sample=True, top_k=10) with injected uniform numbers: token ids bit-exact against
+    oracle.generate_sample, incl. rows that finish early (eos, then pad) when the [SEP] bias is raised."""
+    torch.set_num_threads(16)
+    m, sd = build_model("evaclip02_base", 1, device=cuda)
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    bias = sdo["multimodal_encoder.cls.predictions.bias"].clone()
+    bias[102] += sep_bias
+    sdo["multimodal_encoder.cls.predictions.bias"] = bias
+    with torch.no_grad():
+        m.multimodal_encoder.cls.predictions.bias.copy_(bias.to(cuda))
+    g = torch.Generator().manual_seed(4)
+    cond = torch.randn(4, 7, 768, generator=g)
+    noise = torch.rand(4, max_new, generator=g)
+    with torch.no_grad():
+        ref = O.generate_sample(sdo, cond, max_new, 10, noise)
+    tk = m.multimodal_encoder.tokenizer
+    with runtime.precision(torch.float16):
+        init = torch.full((4, 1), tk.bos_token_id, dtype=torch.long, device=cuda)
+        out = m.multimodal_encoder.generate(input_ids=init, attention_mask=init.new_ones(4, 1, 1), encoder_hidden_states=cond.to(cuda),
+                                            max_new_tokens=max_new, do_sample=True, top_k=10, eos_token_id=tk.sep_token_id,
+                                            pad_token_id=tk.pad_token_id, sample_noise=noise)
+    print(sep_bias, out.tolist(), ref.tolist())
+    assert out.cpu().tolist() == ref.tolist()
+    if sep_bias > 0:
+        assert (ref == 102).any() and (ref[:, 1:] == 0).any(), "the case was meant to finish rows early"
+
+
+def test_forward_cap_captioner_mode(cuda):
+    """MiCo.forward(batch, "cap%tv", compute_loss=False) with config.captioner_mode: generate_nums sampled captions per sample,
+    sample-major (vast.py:519-536), same ids as the oracle under the same injected noise."""
+    from mico_amd.weights import synth_inputs
+    torch.set_num_threads(16)
+    m, sd = build_model("evaclip02_base", 1, device=cuda, max_caption_len=5, captioner_mode=True, generate_nums=2)
+    sdo = dict(sd)
+    sdo["multimodal_encoder.cls.predictions.decoder.weight"] = sdo["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    inp = synth_inputs(dict(b=2, vision=2, S=8), seed=8)
+    noise = torch.rand(4, 5, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        enc = O.encode_batch(sdo, O.ARCHS["evaclip02_base"], inp)
+        cond = O.condition_feats(enc, "v")
+        ref = O.generate_sample(sdo, cond.repeat_interleave(2, dim=0), 5, 10, noise)
+    batch = {k: v.to(cuda) for k, v in inp.items()}
+    batch["_injected"] = {"sample_noise": noise}
+    with runtime.precision(torch.float16), torch.no_grad():
+        out = m(batch, "cap%tv", compute_loss=False)
+    want = m.multimodal_encoder.tokenizer.batch_decode(ref[:, 1:], skip_special_tokens=True)
+    assert out == {"generated_captions_tv": want} and len(want) == 4
 
 
 def test_forward_cap_evaluation_dict(cuda):

@@ -400,3 +400,26 @@ def test_embed_loss_l2(cuda):
     dx = torch.empty_like(x)
     ops.l2norm_bwd(dy, y, inv, dx)
     assert rel_err(dx, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("bs,W,rank", [(64, 1, 0), (64, 8, 3), (5, 2, 1), (3, 1, 0)])
+def test_itm_sample(cuda, bs, W, rank):
+    """mico_itm_sample (vast.py:423-440: softmax + 1e-4, own-rank diagonal zeroed, one draw per row) against the oracle's inverse-CDF
+    restatement under injected uniform numbers - bit-exact indices wherever u * total is not within rounding of a CDF edge - plus the
+    two hard rules of the reference: never the own diagonal, always a valid index."""
+    from mico_amd import ops
+    from oracle import mico_oracle as O
+    g = torch.Generator().manual_seed(11 + bs + W)
+    sim = torch.randn(bs, bs * W, generator=g) / 0.07 * 0.05          # cosine similarities / temperature
+    sim[torch.arange(bs), rank * bs + torch.arange(bs)] += 8.0      # the positive pair dominates its row, as in training
+    for trial in range(4):
+        u = torch.rand(bs, generator=g)
+        if trial == 0:
+            u[0], u[-1] = 0.0, 0.999999
+        ref, margin = O.itm_sample(sim, rank, bs, u)
+        got = ops.itm_sample(sim.to(cuda), rank * bs, u.to(cuda)).cpu()
+        sure = margin > 1e-5
+        assert torch.equal(got[sure], ref[sure]), (got, ref)
+        assert ((got - ref).abs() <= 1).all()
+        assert (got != rank * bs + torch.arange(bs)).all() and (got >= 0).all() and (got < bs * W).all()
+        assert sure.float().mean() > 0.9
