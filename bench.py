@@ -2,25 +2,34 @@
 """bench.py - MiCo omni-modal alignment step (ViT-g/14 fwd+bwd) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 20 --warmup 3          (launches its own 8 ranks, one per GPU, when not already under torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (BASELINE.json configs[2], the single-GPU ViT-g/14 configuration the metric is quoted on): per GPU b = 64 samples
 of image (1 frame, 224^2) + audio (4 spectrogram windows of 224x224 = 10 s of mel-spec) + text (77 tokens), synthetic
 inputs resident in HBM, random-init weights of the real architecture (EVA01-CLIP-g/14 tower shared by image and audio,
 BERT-base with cross-attention), one step = forward + backward of the full alignment loss "ret%tva_cap%tva" (ITC + ITM with
-in-batch hard negatives + causal masked-caption LM; step-B of SURVEY.md section 8d), bf16 MFMA with fp32 accumulation /
-residual stream / statistics.  For N > 1 every rank runs that workload on its own shard (weak scaling), the contrastive
-features are exchanged with one packed RCCL all-gather, hard-negative condition rows with an index-then-fetch all-to-all,
-and gradients are averaged with bucketed all-reduces overlapped with backward.
+in-batch hard negatives + causal masked-caption LM; step-B of SURVEY.md section 8d).  For N > 1 every rank runs that workload on
+its own shard (weak scaling), the contrastive features are exchanged with one packed RCCL all-gather, hard-negative condition
+rows with an index-then-fetch all-to-all, and gradients are averaged with bucketed all-reduces overlapped with backward.
 
-One JSON line on rank 0 (see the repo prompt for the field contract) with two extra objects:
+Precision of the timed run (--dtype): fp16 MFMA operands, fp32 accumulation / residual stream / statistics - the 16-bit type the
+reference's own trainer runs in (fp16 autocast, data/utils/pipeline.py:43) at the bf16 MFMA rate.  `parity` in the JSON line holds
+max|out - ref| / max|ref| of exactly this configuration against the reference-generated goldens (tests/golden/vit_g14_*.pt), measured
+in the same process after the timed region; `parity_config` is the same step timed in the configuration with margin under the 1e-3
+gate (fp16 with hi/lo-split weights: 2 k-segments per forward GEMM) next to it.
+
+One JSON line on rank 0 (see the repo prompt for the field contract) with extra objects:
   roofline     - the dominant kernel (MFMA GEMM) timed per launch with HIP events inside the timed region;
   cpu_baseline - the CPU oracle (oracle/mico_oracle.py, a restatement of the reference parity-locked to it) timed on the
-                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                 host cores on a bounded sample of the same workload plus the BASELINE.md section 4 anchors (rank 0, N = 1 only);
+  parity / parity_config / secondary / comm - see above and main().
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,8 +41,15 @@ sys.path.insert(0, ROOT)
 
 # algorithmic forward GF / sample for step-B at config-3 shapes: 2 * MAC of every
 # GEMM incl. attention, LM head only where a loss consumes it; fwd+bwd = 3 x fwd
-ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74}
+ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74, "vitg_omni14_txt77": 24.04}
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
+
+PRECISIONS = {   # --dtype -> (torch dtype, split_fp16, split_mode, description)
+    "fp16": ("float16", False, "full", "fp16 MFMA operands (plain), fp32 accumulate / residual stream / LN / softmax"),
+    "bf16": ("bfloat16", False, "full", "bf16 MFMA operands, fp32 accumulate / residual stream / LN / softmax"),
+    "fp16-split-w": ("float16", True, "weights", "fp16 MFMA, forward GEMMs x W_hi + x W_lo (weights hi/lo split, 2 k-segments)"),
+    "fp16-split": ("float16", True, "full", "fp16 MFMA, forward GEMMs x_hi W_hi + x_lo W_hi + x_hi W_lo (3 k-segments)"),
+}
 
 
 def parse():
@@ -44,15 +60,17 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--vision", default="evaclip01_giant")
     ap.add_argument("--layers", type=int, default=None, help="truncate the ViT (debug only; invalidates the metric)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="fp16", choices=sorted(PRECISIONS))
     ap.add_argument("--task", default=None)
     ap.add_argument("--workload", default="img_aud_txt", choices=["img_aud_txt", "omni"],
                     help="img_aud_txt = BASELINE configs[2] (the metric's single-GPU configuration, default); omni = one rank's share "
                          "of configs[3]: image+video (9 vision frames) + depth + audio + text, 14 frames/sample (not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip parity / parity_config / secondary (only the headline measurement)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
     ap.add_argument("--gemm-detail", action="store_true", help="print a per-shape table of the timed GEMM launches to stderr")
+    ap.add_argument("--no-gemm-timer", action="store_true", help="A/B switch: no per-launch HIP events around the GEMMs (roofline is then null)")
     ap.add_argument("--optimizer", action="store_true",
                     help="also run the AdamW step (mico_amd.optim, SURVEY section 8 row f4) inside the timed step: a full training step, "
                          "beyond the metric's fwd+bwd definition")
@@ -62,36 +80,153 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd_cpu, args):
-    """Oracle step-B forward+backward on the host cores, bounded sample: --cpu-batch samples, ONE untimed-warmup-free step."""
+    """The CPU oracle on the host cores.  `value`: the bench's own step (same task, same shapes) at --cpu-batch samples, one step
+    (20-30 s of CPU work).  `anchors`: the BASELINE.md section 4 shapes - config 2 (ViT-B/16 image + text contrastive step) at bs 8,
+    config 3's image + text sub-step (ViT-g/14) at bs 2, config 1 (single-image ViT-g/14 encode) - one warm-up + 3 timed steps,
+    median.  32 threads: PyTorch's CPU GEMMs on this path stop scaling (and regress badly) far below the 256 hardware threads of the
+    GPU box's host - a first run with all 256 threads took 1292 s for the same sample."""
     from oracle import mico_oracle as O
-    from mico_amd.weights import synth_inputs
+    from mico_amd.weights import synth_inputs, synth_state_dict
+    from mico_amd.model import MiCo, default_cfg
     import random
-    # 32 threads: PyTorch's CPU GEMMs on this path stop scaling (and regress badly) far below the 256 hardware threads of the
-    # GPU box's host - a first run with all 256 threads took 1292 s for the same sample.
     ncores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
     arch = O.ARCHS[args.vision]
     b = args.cpu_batch
+
+    def tied(sd):
+        sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        sd["multimodal_encoder.cls.predictions.decoder.weight"] = sd["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+        return sd
+
     inp = synth_inputs(dict(b=b, **WORKLOADS[args.workload]["shape"]), seed=99)
-    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_cpu.items()}
-    sd["multimodal_encoder.cls.predictions.decoder.weight"] = sd["multimodal_encoder.bert.embeddings.word_embeddings.weight"]
+    sd = tied(sd_cpu)
     mi, lab = O.token_masker(inp["input_ids"], 0.6, random.Random(0))
     idx = torch.arange(b).roll(1)
-    injected = {"tva": dict(neg_cond_idx=idx, neg_text_idx=idx), "cap": dict(masked_ids=mi, labels=lab)}
+    injected = {st: dict(neg_cond_idx=idx, neg_text_idx=idx) for st in ("tva", "tvd", "tv")}
+    injected["cap"] = dict(masked_ids=mi, labels=lab)
     t0 = time.time()
     out, _ = O.mico_forward(sd, arch, inp, args.task, dict(itm_ratio=0.1), injected=injected)
     sum(out.values()).backward()
     dt = time.time() - t0
-    return dict(value=b / dt, unit="samples/s", cores=ncores, kind="port",
-                sample=f"oracle/mico_oracle.py fp32, same step ({args.task}) at b={b} (image 1 + audio 4 frames + 77 tokens), "
-                       f"1 step, {dt:.1f} s on {ncores} threads")
+    res = dict(value=b / dt, unit="samples/s", cores=ncores, kind="port", cpu=cpu_model_string(), host_threads=os.cpu_count(),
+               sample=f"oracle/mico_oracle.py fp32, same step ({args.task}) at b={b} ({WORKLOADS[args.workload]['frames']} frames + 77 tokens "
+                      f"per sample), 1 step, {dt:.1f} s on {ncores} threads")
+
+    def timed(fn, n=3):
+        fn()
+        ts = []
+        for _ in range(n):
+            t = time.time()
+            fn()
+            ts.append(time.time() - t)
+        return statistics.median(ts)
+
+    def itc_step(vt, sdx, bs):
+        inpx = synth_inputs(dict(b=bs, vision=1, S=77), seed=98)
+
+        def f():
+            for v in sdx.values():
+                v.grad = None
+            o, _ = O.mico_forward(sdx, O.ARCHS[vt], inpx, "ret%tv", dict(itm_ratio=0.1),
+                                  injected={"tv": dict(neg_cond_idx=torch.arange(bs).roll(1), neg_text_idx=torch.arange(bs).roll(1))})
+            o["loss_itc"].backward()
+        return f
+
+    anchors = {}
+    mb = MiCo(default_cfg("evaclip02_base"))
+    sdb = tied(synth_state_dict({k: tuple(v.shape) for k, v in mb.state_dict().items()}, seed=0))
+    del mb
+    t = timed(itc_step("evaclip02_base", sdb, 8))
+    anchors["config2_vitb16_img_txt_itc_bs8"] = dict(samples_per_s=8 / t, median_step_s=t)
+    del sdb
+    t = timed(itc_step(args.vision, sd, 2))
+    anchors["config3_vitg14_img_txt_itc_bs2"] = dict(samples_per_s=2 / t, median_step_s=t)
+    px = synth_inputs(dict(b=1, vision=1, S=0), seed=97)["vision_pixels"]
+
+    def enc():
+        with torch.no_grad():
+            O.encode_batch(sd, arch, dict(vision_pixels=px))
+    t = timed(enc)
+    anchors["config1_vitg14_single_image_encode"] = dict(samples_per_s=1 / t, median_step_s=t)
+    res["anchors"] = anchors
+    res["anchors_protocol"] = "BASELINE.md section 4: fp32, 1 warm-up + 3 timed steps, median"
+    return res
 
 
 WORKLOADS = {
     "img_aud_txt": dict(shape=dict(vision=1, audio=4, S=77), task="ret%tva_cap%tva", key="vitg_img1_aud4_txt77_stepB", frames=5),
     "omni": dict(shape=dict(vision=9, depth=1, audio=4, S=77), task="ret%tva%tvd_cap%tva", key="vitg_omni14_txt77", frames=14),
 }
+
+
+def set_precision(name):
+    from mico_amd import runtime
+    dt, split, mode, _ = PRECISIONS[name]
+    runtime.set_compute_dtype(getattr(torch, dt))
+    runtime.CFG.split_fp16, runtime.CFG.split_mode = split, mode
+    runtime.clear_weight_cache()
+
+
+def measure_parity(model, dev):
+    """max|out - ref| / max|ref| of the ACTIVE precision configuration against the reference-generated goldens: the depth-2 g/14 tower
+    (final-LN tokens of 2 images; its own 2-block model with the same weight generator) and the full 40-block g/14 (token rows + the
+    L2-normalised 512-d feat_v; needs the bench's full-depth model)."""
+    from mico_amd.model import MiCo, default_cfg
+    from mico_amd.weights import synth_state_dict
+    from mico_amd.functional import l2_normalize
+    gd = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    was_training = model.training
+    try:
+        fx = torch.load(os.path.join(gd, "vit_g14_d2.pt"), map_location="cpu", weights_only=False)
+        m2 = MiCo(default_cfg("evaclip01_giant", vision_layers=2))
+        m2.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m2.state_dict().items()}, 0), strict=False)
+        m2.to(dev).eval()
+        g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+        x = torch.randn((2, 3, 224, 224), generator=g)
+        with torch.no_grad():
+            o = m2.vision_encoder.visual(x.to(dev), return_all_features=True).float().cpu()
+        out["vit_g14_depth2_tokens"] = ((o - fx["out"]).abs().max() / fx["out"].abs().max()).item()
+        del m2
+        if model.config.get("vision_layers") is None and model.config.vision_encoder_type == "evaclip01_giant":
+            fx = torch.load(os.path.join(gd, "vit_g14_full.pt"), map_location="cpu", weights_only=False)
+            g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+            x = torch.randn((1, 1, 3, 224, 224), generator=g).to(dev)
+            model.eval()
+            with torch.no_grad():
+                o = model.forward_vision_encoder(x)
+                feat = l2_normalize(model.contra_head_v(model.pool_vision_for_contra(o))).float().cpu()
+            out["vit_g14_full_token_rows"] = ((o[0, 0, [0, 1, 128, 256]].float().cpu() - fx["rows"]).abs().max() / fx["amax"]).item()
+            out["vit_g14_full_feat_v"] = ((feat - fx["feat_v"]).abs().max() / fx["feat_v"].abs().max()).item()
+    finally:
+        model.train(was_training)
+    out["metric"] = "max|out - ref| / max|ref| vs reference fp32 CPU outputs (tests/golden, generated by oracle/make_golden.py)"
+    out["gate"] = 1e-3
+    return out
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become the launcher - one process per GPU over RCCL, same arguments."""
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -101,7 +236,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun)")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -111,10 +251,9 @@ def main():
     from mico_amd import runtime, ops
     from mico_amd.model import MiCo, default_cfg
     from mico_amd.weights import synth_state_dict, synth_inputs
-    from mico_amd.distributed import GradBucketReducer
+    from mico_amd.distributed import GradBucketReducer, packed_all_gather
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    runtime.set_compute_dtype(dtype)
+    set_precision(args.dtype)
     torch.manual_seed(rank)     # host RNG: stochastic-depth draws differ per rank (weights/inputs come from counter hashes)
     from mico_amd.functional import DropPlan
     DropPlan.skip_dropped = not args.dense_droppath
@@ -136,38 +275,53 @@ def main():
         nodecay = [p for n, p in model.named_parameters() if any(k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
         optimizer = AdamW([dict(params=decay, weight_decay=0.01, lr=1e-6), dict(params=nodecay, weight_decay=0.0, lr=1e-6)],
                           lr=1e-6, betas=(0.9, 0.98))
+    finish_ms = []
 
-    def step():
+    def step(the_batch=None, task=None):
         model.zero_grad(set_to_none=True)
-        losses = model(dict(batch), args.task, compute_loss=True)
+        losses = model(dict(the_batch if the_batch is not None else batch), task or args.task, compute_loss=True)
         total = sum(losses.values())
         total.backward()
         if reducer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             reducer.finish()
+            e1.record()
+            finish_ms.append((e0, e1))
         if optimizer is not None:
             optimizer.step()
         return losses
 
+    def timed_steps(n, the_batch=None, task=None):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            losses = step(the_batch, task)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el, losses
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    timer = ops.KernelTimer()
+    timer = None if args.no_gemm_timer else ops.KernelTimer()
     ops.GEMM_TIMER = timer
     DropPlan.stats[:] = [0, 0]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    finish_ms.clear()
+    elapsed, losses = timed_steps(args.steps)
     ops.GEMM_TIMER = None
-    if args.gemm_detail and rank == 0:
-        import sys
+    kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    if args.gemm_detail and rank == 0 and timer is not None:
         tab = {}
         for (var, flops, e0, e1), det in zip(timer.records, timer.detail):
             d = tab.setdefault((var, det[1], det[2], det[3], det[4]), [0, 0.0, 0.0, 0])
@@ -176,70 +330,90 @@ def main():
         for key, d in sorted(tab.items(), key=lambda kv: -kv[1][2]):
             print(f"{str(key[0]):>14s} {key[1]:6d} {key[2]:6d} {key[3]:>10s} {key[4]:5d} {d[0]:8d} {d[3] / d[0]:8.0f} {d[2] / d[0] * 1e3:8.1f} "
                   f"{d[1] / d[2] / 1e9:8.1f} {d[2] / args.steps:8.2f}", file=sys.stderr)
+
+    # ---- communication figures (N > 1): exposed gradient-reduction wait per step, packed all-gather latency ----
+    comm = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        exposed = sum(e0.elapsed_time(e1) for e0, e1 in finish_ms) / max(1, len(finish_ms))
+        feat = torch.randn(b, 512, device=dev)
+        ids = batch["input_ids"]
+        for _ in range(3):
+            packed_all_gather([feat, ids, batch["attention_mask"], feat])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            packed_all_gather([feat, ids, batch["attention_mask"], feat])
+        torch.cuda.synchronize()
+        ag_us = (time.perf_counter() - t0) / 20 * 1e6
+        grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
+        comm = dict(backend="nccl (RCCL)", world_size=dist.get_world_size(), packed_allgather_us=ag_us,
+                    packed_allgather_bytes_per_rank=int(feat.numel() * 4 * 2 + ids.numel() * 8 * 2),
+                    grad_bytes=grad_bytes, grad_reduce_exposed_ms_per_step=exposed,
+                    grad_reduce_note="time the step spends in GradBucketReducer.finish() waiting for reductions that did not hide behind "
+                                     "the backward; the ViT blocks' arena slices are reduced in place from inside the backward")
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     samples = b * world * args.steps
     value = samples / elapsed
-    summ = timer.summary()
     kern = {0: "gemm_kernel<T,{ta},{tb},TileCfg<128,128,2,2,64,2>>", 1: "gemm_kernel<T,{ta},{tb},TileCfg<256,256,2,4,32,4>>",
-            2: "gemm_pc_kernel<T,{ta},{tb},32>"}
+            2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>"}
     role = {(0, 0): "y = x W^T (forward)", (0, 1): "dx = dy W", (1, 1): "dW = dy^T x", (1, 0): "x^T W"}
 
     def kname(key):
         ta, tb, kk = key
         return kern[kk].format(ta=str(bool(ta)).lower(), tb=str(bool(tb)).lower()) + " : " + role[(ta, tb)]
 
-    per_variant = {kname(k): dict(launches=v["launches"], avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / v["ms"] / 1e9)
-                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
-    tot_flops = sum(v["flops"] for v in summ.values())
-    tot_ms = sum(v["ms"] for v in summ.values())
-    dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
-    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from the separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01_gemm_hbm_traffic.json, FETCH_SIZE
-    # doubled as MI355X_MICROARCH.md prescribes for gfx950).  null when that profile is not present.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-    if os.path.exists(tpath) and world == 1:
-        tj = json.load(open(tpath))
-        key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc"}[dom[0][2]]
-        if key in tj:
-            traffic = tj[key]["hbm_bytes_per_launch"]
-    roofline = dict(bound="mfma", kernel=kname(dom[0]), achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
-                    launches=dom[1]["launches"],
-                    avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
-                    all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
+    roofline = None
+    if timer is not None:
+        summ = timer.summary()
+        per_variant = {kname(k): dict(launches=v["launches"], avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / v["ms"] / 1e9)
+                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        tot_flops = sum(v["flops"] for v in summ.values())
+        tot_ms = sum(v["ms"] for v in summ.values())
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from the separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/*_gemm_hbm_traffic.json, FETCH_SIZE
+        # doubled as MI355X_MICROARCH.md prescribes for gfx950).  null when that profile is not present.
+        traffic = None
+        for tname in ("r02_gemm_hbm_traffic.json", "r01_gemm_hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and world == 1:
+                tj = json.load(open(tpath))
+                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4"}[dom[0][2]]
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+                    break
+        roofline = dict(bound="mfma", kernel=kname(dom[0]), achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
+                        launches=dom[1]["launches"], avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
+                        all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
     workload = wl["key"]
-    full = args.layers is None and args.vision == "evaclip01_giant" and args.task == "ret%tva_cap%tva" and args.workload == "img_aud_txt"
+    full = args.layers is None and args.vision == "evaclip01_giant" and args.task == wl["task"]
     # stochastic depth: a dropped (block, branch, frame) contributes exactly zero to values and gradients, so the engine does
     # not evaluate it.  The nominal (dense) FLOP count is what the reference executes; the executed count scales the ViT-block
-    # share (5 frames x 40 blocks x 13.341 GF x 3 = 8.00 of the 8.74 TF/sample) by the kept fraction of this run's draws.
-    kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
+    # share (frames x 40 blocks x 13.341 GF x 3 per sample) by the kept fraction of this run's draws.
     nominal = ALG_TFLOP_PER_SAMPLE.get(workload)
-    executed = nominal - 8.00 * (1.0 - kept) if nominal else None
+    vit_block_tf = wl["frames"] * 40 * 13.341 * 3 / 1e3
+    executed = nominal - vit_block_tf * (1.0 - kept) if nominal else None
     # shared cross-attention K/V (runtime.CFG.share_cross_kv): the reference projects 4 condition sets per sample and layer (ITM triplet +
     # captioning pass, 1285 tokens each), the engine 2: 12 layers x 2 sets x 1285 x 2*768*1536 flop x 3 (fwd + dX + dW) = 0.218 TF/sample
-    from mico_amd import runtime as _rt
-    if executed is not None and _rt.CFG.share_cross_kv and args.task == "ret%tva_cap%tva" and not args.eval_mode:
+    if executed is not None and runtime.CFG.share_cross_kv and args.task == "ret%tva_cap%tva" and not args.eval_mode:
         executed -= 12 * 2 * 1285 * 2 * 768 * 1536 * 3 / 1e12
-    step_tflops = executed * value / world if full else None
+    step_tflops = executed * value / world if (full and executed) else None
     res = {
         "metric": "omni-modal samples/sec (ViT-g/14 fwd+bwd)", "value": value, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype.split("-")[0], "data": "synthetic",
         "config": {"workload": (f"BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, "
                                 f"b={b}/GPU, task {args.task} (ITC+ITM+CAP)" if args.workload == "img_aud_txt" else
                                 f"BASELINE.json configs[3] per-rank share: ViT-g/14 image+video(9)+depth(1)+audio(4)+text(77) fwd+bwd, "
-                                f"b={b}/GPU, task {args.task}; tower chunked with recompute"),
-                   "per_gpu_batch": b, "global_batch": b * world,
+                                f"b={b}/GPU, task {args.task}"),
+                   "per_gpu_batch": b, "global_batch": b * world, "precision": PRECISIONS[args.dtype][3],
                    "vision": args.vision, "vit_layers": args.layers or "full", "parallelism": f"dp{world}",
                    "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),
                    "droppath_schedule": ("dense: every branch evaluated then scaled by 0 | 1/keep" if args.dense_droppath
@@ -250,16 +424,49 @@ def main():
         "samples_per_sec_per_gpu": value / world,
         "step_executed_tflops_per_gpu": step_tflops,
         "tflop_per_sample": {"dense_nominal": nominal, "executed": executed},
-        "cross_kv": "condition K/V projected once per step and shared by the ITM triplet and the captioning pass" if _rt.CFG.share_cross_kv else "per pass",
+        "cross_kv": "condition K/V projected once per step and shared by the ITM triplet and the captioning pass" if runtime.CFG.share_cross_kv else "per pass",
         "step_mfma_frac": (step_tflops / MFMA_PEAK_TFLOPS) if step_tflops else None,
         "losses": {k: float(v.detach()) for k, v in losses.items()},
-        "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "peak_mem_gb": peak_mem,
         "roofline": roofline,
     }
+    if comm is not None:
+        res["comm"] = comm
+    extras = not args.no_extras and args.workload == "img_aud_txt" and not args.optimizer
+    if extras:
+        # ---- the timed precision against the reference goldens, measured here and now ----
+        res["parity"] = dict(precision=PRECISIONS[args.dtype][3], **measure_parity(model, dev))
+    if extras and world == 1:
+        # ---- the same step in the configuration with margin under the 1e-3 gate, timed next to it ----
+        pc = "fp16-split-w" if args.dtype != "fp16-split-w" else "fp16"
+        set_precision(pc)
+        k2 = max(2, args.steps // 4)
+        step()
+        el2, _ = timed_steps(k2)
+        res["parity_config"] = dict(precision=PRECISIONS[pc][3], value=b * k2 / el2, unit="samples/s", steps=k2, warmup=1,
+                                    ms_per_step=el2 / k2 * 1e3, **{"parity": measure_parity(model, dev)})
+        set_precision(args.dtype)
+        # ---- secondary: one rank's share of BASELINE configs[3] (14 frames per sample: image + 8 video frames + depth + 4 audio windows) ----
+        try:
+            wo = WORKLOADS["omni"]
+            torch.cuda.empty_cache()
+            ob = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, **wo["shape"]), seed=4321).items()}
+            step(ob, wo["task"])
+            k3 = 2
+            torch.cuda.reset_peak_memory_stats()
+            el3, _ = timed_steps(k3, ob, wo["task"])
+            res["secondary"] = {"omni_configs3_rank_share": dict(
+                value=b * k3 / el3, unit="samples/s", ms_per_step=el3 / k3 * 1e3, steps=k3, warmup=1, frames_per_sample=wo["frames"],
+                task=wo["task"], peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, precision=PRECISIONS[args.dtype][3],
+                tower_chunk_frames=runtime.tower_chunk_override() or "auto (from free HBM)")}
+            del ob
+        except Exception as e:   # the headline line must survive a failure of the secondary measurement
+            res["secondary"] = {"omni_configs3_rank_share": {"error": repr(e)}}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(sd_cpu, args)
     print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

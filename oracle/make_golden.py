@@ -88,11 +88,19 @@ def bert_fixture(m):
     cond = torch.randn((b, E, 768), generator=g)
     fx = dict(meta=dict(b=b, S=S, E=E, seed=5, lens=lens))
     o = me(input_ids=ids, attention_mask=mask)
+    def top2(tag, logits):
+        """argmax ids plus how decided each one is: gap between the two largest logits of the position relative to the largest
+        |logit| of the tensor - the parity test demands bit-exact ids wherever the gap exceeds the 16-bit logit resolution."""
+        t, i = logits.detach().float().topk(2, dim=-1)
+        fx[tag + "_argmax"] = logits.argmax(-1).clone()
+        fx[tag + "_top2_ids"] = i.clone()
+        fx[tag + "_top2_gap"] = ((t[..., 0] - t[..., 1]) / logits.detach().abs().max()).clone()
+
     fx["self_seq"] = o.sequence_output.detach().clone()
-    fx["self_argmax"] = o.logits.argmax(-1).clone()
+    top2("self", o.logits)
     o = me(input_ids=ids, attention_mask=mask, encoder_hidden_states=cond)
     fx["cross_seq"] = o.sequence_output.detach().clone()
-    fx["cross_argmax"] = o.logits.argmax(-1).clone()
+    top2("cross", o.logits)
     m3 = torch.tril(mask.unsqueeze(1).expand(-1, S, -1).clone())
     labels = torch.full((b, S), -100)
     labels[0, 3], labels[0, 7], labels[1, 2], labels[2, 1] = 2000, 1037, 30521, 999
@@ -100,7 +108,7 @@ def bert_fixture(m):
     o = me(input_ids=ids, attention_mask=m3, encoder_hidden_states=cond_r, labels=labels)
     fx["causal_seq"] = o.sequence_output.detach().clone()
     fx["causal_loss"] = o.loss.detach().clone()
-    fx["causal_argmax"] = o.logits.argmax(-1).clone()
+    top2("causal", o.logits)
     fx["labels"] = labels
     o.loss.backward()
     named = dict(me.named_parameters())

@@ -168,3 +168,18 @@ def test_frame_embedding_nearest_index_matches_interpolate():
         fe = torch.randn(1, src, 16)
         idx = torch.floor(torch.arange(n, dtype=torch.float32) * (src / n)).long()
         assert torch.equal(fe[:, idx], F.interpolate(fe.permute(0, 2, 1), n, mode="nearest").permute(0, 2, 1))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` outside torchrun launches its own N ranks - and says so loudly when the box does not have N GPUs,
+    instead of silently measuring one rank (`assert world == args.gpus or world == 1`)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but only" in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])
+    # under a launcher whose world size disagrees with --gpus: refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])

@@ -71,11 +71,23 @@ def test_bert(setup, cuda):
     ids, mask, cond = ids.to(cuda), mask.to(cuda), cond.to(cuda)
     me = m.multimodal_encoder
     with runtime.precision(torch.float16):
+        def ids_exact(tag, logits):
+            """argmax token ids bit-exact wherever the reference itself decides: its gap between the two largest
+            logits of the position exceeds 2e-3 of max|logit|, twice the 1e-3 gate on the logits.  The other positions (6 + 1 + 1 of
+            3 x 48 with these random-init weights; the fixture records them) are ties at that resolution: there the product must
+            still name one of the reference's two candidates."""
+            got = logits.argmax(-1).cpu()
+            decided = fx[tag + "_top2_gap"] > 2e-3
+            assert decided.float().mean() > 0.85
+            assert torch.equal(got[decided], fx[tag + "_argmax"][decided]), (tag, (got != fx[tag + "_argmax"]).nonzero())
+            assert (got[..., None] == fx[tag + "_top2_ids"]).any(-1).all(), tag
+
         o = me(input_ids=ids, attention_mask=mask)
         assert rel_err(o.sequence_output, fx["self_seq"]) < 1e-3
-        assert (o.logits.argmax(-1).cpu() == fx["self_argmax"]).float().mean() > 0.97   # near-ties may flip under fp16
+        ids_exact("self", o.logits)
         o = me(input_ids=ids, attention_mask=mask, encoder_hidden_states=cond)
         assert rel_err(o.sequence_output, fx["cross_seq"]) < 1e-3
+        ids_exact("cross", o.logits)
         m3 = torch.tril(mask.unsqueeze(1).expand(-1, S, -1)).contiguous()
         m.zero_grad(set_to_none=True)
         cr = cond.clone().requires_grad_(True)
