@@ -114,6 +114,24 @@ int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const mico_gemm_epilogue* epi, int split_k, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * MX-fp8 GEMM (BASELINE.json configs[4], "fp8 MFMA"): block-scaled OCP microscaling operands on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 MFMA rate; gfx950's unscaled fp8 MFMAs run at the bf16 rate).
+ *   mico_quant_mx8: x [rows, cols] 16-bit (ld) * pre_scale -> q [rows, cols] e4m3 (ldq bytes) + scales uint32 [cols / 128][rows]: the
+ *     four E8M0 bytes of one row's 128-column tile per word (byte b = columns 32 b .. 32 b + 31 of the tile), scale 2^e with the
+ *     smallest e such that the block's amax / 2^e <= 448.  cols % 128 == 0.
+ *   mico_gemm_mx8:  C[M,N] = epilogue( sum_k A[m,k] sa[m,k/32] * B[n,k] sb[n,k/32] ), A [M,K] / B [N,K] e4m3 with leading dimensions in
+ *     bytes, scales as written by mico_quant_mx8, fp32 accumulation; the epilogue struct, c_dtype and out_dtype (the 16-bit type of C and
+ *     of the aux tensors) mean what they mean for mico_gemm.  K % 128 == 0; only this orientation (y = x W^T; an input gradient
+ *     dx = dy W is the same call on a transposed fp8 copy of W, quantised along ITS reduction dimension).  No split-K.
+ * The reference has no fp8 path (its only reduced precision is fp16 autocast, data/utils/pipeline.py:30,43): configs[4] is this
+ * build's to honour; tolerance and use are documented in DESIGN.md section 4.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_quant_mx8(const void* x, int64_t ld, int64_t rows, int cols, void* q, int64_t ldq, void* scales, float pre_scale,
+                   int dtype, void* stream);
+int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* a_scales, const void* B, int64_t ldb,
+                  const void* b_scales, void* C, int64_t ldc, int c_dtype, const mico_gemm_epilogue* epi, int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * LayerNorm (row statistics in fp32).  Replaces model/evaclip/transformer.py:121-127 (eps 1e-6) and
  * torch.nn.LayerNorm in model/bert.py:92,147,288,296 / model/mico.py:49,400-403 (eps 1e-12).
  *   x: [rows, cols] fp32 (x_dtype == MICO_F32) or 16-bit;  y16 / y32 optional outputs;  mean/rstd [rows] saved.
@@ -255,7 +273,8 @@ int mico_embed_scatter_add(const int64_t* ids, const float* dsum, float* dword, 
 /* ITM hard-negative sampling (data/model/vast.py:423-440: weights = softmax(sim, 1) + 1e-4, own-rank diagonal zeroed, one multinomial
  * draw per row - there a Python loop with a .item() host sync per row).  sim: fp32 [rows, cols] (ld) similarity logits AFTER the
  * temperature; row r never draws column diag_offset + r (= rank * b + r); u: fp32 [rows] uniform numbers in [0, 1) supplied by the
- * caller (injected for parity, torch.rand otherwise); out[r] = #{j : cdf_r[j] < u[r] * total_r} (inverse-CDF draw), int64. */
+ * caller (injected for parity, torch.rand otherwise); out[r] = #{j : cdf_r[j] <= u[r] * total_r} (inverse-CDF draw: the first column whose CDF
+ * exceeds the target, so a zero-weight column is never drawn), int64. */
 int mico_itm_sample(const float* sim, int64_t ld, int rows, int cols, int diag_offset, const float* u, int64_t* out, void* stream);
 
 int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t rows, int cols,

@@ -27,6 +27,7 @@
 #include <stdarg.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <algorithm>
 #include <type_traits>
 
 #ifndef MICO_W4_DBG
@@ -620,6 +621,180 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PHASE_STAMP(6);
 #endif
+}
+
+// ======================================================================================================================
+// MX-fp8 GEMM (BASELINE.json configs[4]: "fp8 MFMA"): C = epilogue(A B^T) with A [M, K] and B [N, K] in OCP e4m3 and one E8M0 scale per
+// 32 consecutive k (the OCP microscaling format), on v_mfma_scale_f32_16x16x128_f8f6f4 - the only fp8 MFMA on gfx950 that runs above
+// the bf16 rate (2x; the unscaled fp8 forms run AT the bf16 rate).
+// Operand layout of that instruction, measured (tools/probes/mx_layout.hip): lane (r = l % 16, g = l / 16) supplies row r; its eight
+// operand registers hold k = 16 g .. 16 g + 15 (registers 0-3) and k = 64 + 16 g .. + 15 (registers 4-7) - two 16-byte chunks, chunk g and
+// chunk 4 + g of the row's 128 bytes, i.e. exactly the two k-step reads of the 16-bit kernels' 128-byte-row LDS image - and the scale
+// operand of lane (r, b) is the scale of row r's block b (k = 32 b .. 32 b + 31).  So the tile images, the DMA staging, the swizzle, the
+// fragment addressing and the epilogues are those of the 16-bit kernels with "64 16-bit elements" read as "128 bytes"; only the MFMA
+// differs (one scaled instruction where the 16-bit kernels issue two) and a 1 KiB scale image per operand rides along with each tile.
+// Scales in memory: uint32 [K / 128][rows] - the four E8M0 bytes of one row's 128-k tile in one word, K-tile-major so that a tile's
+// scales are one contiguous KiB.  Schedule: 256x256x128 tile, 8 waves, 2 stages, one barrier pair per K-tile (first version).
+// ======================================================================================================================
+struct Mx8 {
+    static constexpr int BM = 256, BN = 256, BKB = 128, THREADS = 512, MT = 8;
+    static constexpr int A_BYTES = 256 * BKB, S_BYTES = 256 * 4, STAGE_BYTES = 2 * A_BYTES + 2 * S_BYTES, LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int NDMA = A_BYTES / 16 / THREADS;   // 4 DMA instructions per thread per operand tile
+};
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct Mx8Args {
+    GemmArgs g;               // M, N, K (K in elements = bytes), A / B / C, lda / ldb (bytes), tiles, epilogue
+    const unsigned* sa;       // [K / 128][M]
+    const unsigned* sb;       // [K / 128][N]
+};
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(Mx8::THREADS, 2) void gemm_mx8_kernel(const Mx8Args a) {
+    const GemmArgs& g = a.g;
+    constexpr int BM = Mx8::BM, BN = Mx8::BN, THREADS = Mx8::THREADS, ND = Mx8::NDMA;
+    __shared__ __attribute__((aligned(16))) char smem[Mx8::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wrow = wm * 128, wcol = wn * 64;
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    int tile_m, tile_n;
+    {
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        tile_m = first + in % gm;
+        tile_n = in / gm;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int T_ = g.ktiles;
+    // the tile images are those of a 16-bit [rows][64] operand: leading dimensions and k offsets in BYTES
+    const char* a_base = g.A + m0 * g.lda;
+    const char* b_base = g.B + n0 * g.ldb;
+    int64_t a_bytes = (g.M - m0) * g.lda, b_bytes = (g.N - n0) * g.ldb;
+    if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+    if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+    // scale words: one descriptor per operand over the whole [K / 128][rows] array, bounds = its end (rows past M / N of the last
+    // tile row read the next K-tile's words or zero-fill - they scale operand rows that are zero-filled themselves)
+    __amdgpu_buffer_rsrc_t rssa = __builtin_amdgcn_make_buffer_rsrc((void*)a.sa, 0, (int)min((int64_t)T_ * g.M * 4, (int64_t)0x7FFFFF00), 0x00020000);
+    __amdgpu_buffer_rsrc_t rssb = __builtin_amdgcn_make_buffer_rsrc((void*)a.sb, 0, (int)min((int64_t)T_ * g.N * 4, (int64_t)0x7FFFFF00), 0x00020000);
+    unsigned voa[ND], vob[ND];
+    dma_offsets<false, BM, THREADS, 64, ND>(voa, wave, lane, g.lda, g.M - m0);
+    dma_offsets<false, BN, THREADS, 64, ND>(vob, wave, lane, g.ldb, g.N - n0);
+    const FragBase ab = frag_base<false, BM, 64>(wrow, lane), bb = frag_base<false, BN, 64>(wcol, lane);
+    auto stage = [&](int kt, int bo) {
+        dma_issue<THREADS, ND>(rsa, lds + bo, wave, voa, (unsigned)kt * 128u);
+        dma_issue<THREADS, ND>(rsb, lds + bo + Mx8::A_BYTES, wave, vob, (unsigned)kt * 128u);
+        if (wave == 0)        // 256 scale words of the A tile rows: 64 lanes x 16 bytes
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rssa, (LDS_AS void*)(lds + bo + 2 * Mx8::A_BYTES), 16,
+                                                     (unsigned)(((int64_t)kt * g.M + m0) * 4 + lane * 16), 0, 0, 0);
+        else if (wave == 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rssb, (LDS_AS void*)(lds + bo + 2 * Mx8::A_BYTES + Mx8::S_BYTES), 16,
+                                                     (unsigned)(((int64_t)kt * g.N + n0) * 4 + lane * 16), 0, 0, 0);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int p = lane & 15, gq = lane >> 4;
+    int bo = 0;
+    stage(0, 0);
+    for (int t = 0; t < T_; ++t) {
+        __syncthreads();   // stage `bo` landed (vmcnt(0) precedes the barrier); the other stage is no longer being read
+        if (t + 1 < T_) stage(t + 1, bo ^ Mx8::STAGE_BYTES);
+        LDS_AS const char* ta = lds + bo;
+        LDS_AS const char* tb = ta + Mx8::A_BYTES;
+        LDS_AS const unsigned* sca = (LDS_AS const unsigned*)(ta + 2 * Mx8::A_BYTES);
+        LDS_AS const unsigned* scb = sca + 256;
+        i32x8 fb[4];
+        int sb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const s16x8 lo = *(LDS_AS const s16x8*)(tb + bb.b0 + j * 2048), hi = *(LDS_AS const s16x8*)(tb + bb.b1 + j * 2048);
+            const u32x4 l4 = __builtin_bit_cast(u32x4, lo), h4 = __builtin_bit_cast(u32x4, hi);
+            fb[j] = (i32x8){(int)l4[0], (int)l4[1], (int)l4[2], (int)l4[3], (int)h4[0], (int)h4[1], (int)h4[2], (int)h4[3]};
+            sb[j] = (int)((scb[wcol + j * 16 + p] >> (8 * gq)) & 0xFFu);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // the A row tiles in two halves: 32 fragment registers live instead of 64
+            i32x8 fa[4];
+            int sa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ii = h * 4 + i;
+                const s16x8 lo = *(LDS_AS const s16x8*)(ta + ab.b0 + ii * 2048), hi = *(LDS_AS const s16x8*)(ta + ab.b1 + ii * 2048);
+                const u32x4 l4 = __builtin_bit_cast(u32x4, lo), h4 = __builtin_bit_cast(u32x4, hi);
+                fa[i] = (i32x8){(int)l4[0], (int)l4[1], (int)l4[2], (int)l4[3], (int)h4[0], (int)h4[1], (int)h4[2], (int)h4[3]};
+                sa[i] = (int)((sca[wrow + ii * 16 + p] >> (8 * gq)) & 0xFFu);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)   // operands swapped (D^T = B A^T) like the 16-bit kernels: a lane owns 4 consecutive columns
+                    acc[h * 4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[h * 4 + i][j], 0, 0, 0, sb[j], 0, sa[i]);
+        }
+        bo ^= Mx8::STAGE_BYTES;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
+}
+
+// 16-bit [rows, cols] -> e4m3 [rows, cols] + E8M0 block scales (one per 32 consecutive columns, packed 4 per uint32, K-tile-major).
+// scale = 2^e with the smallest e such that amax / 2^e <= 448 (the largest e4m3 magnitude): nothing saturates, at most one binade of the
+// element format's range is given up.  A wave covers 512 columns of one row per pass (8 per lane: one 16-byte load), a 32-block is 4 lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const T* __restrict__ x, int64_t ld, int64_t rows, int cols, unsigned char* __restrict__ q,
+                                                        int64_t ldq, unsigned* __restrict__ sc, float pre_scale) {
+    const int lane = threadIdx.x & 63;
+    const int chunks = (cols + 511) / 512;
+    const int64_t units = rows * chunks;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += (int64_t)gridDim.x * 4) {
+        const int64_t row = u / chunks;
+        const int c0 = (int)(u - row * chunks) * 512 + lane * 8;
+        const bool live = c0 < cols;     // cols % 128 == 0: a lane's 8 columns and its 16-lane scale word are all in or all out
+        float v[8];
+        if (live) unpack8<T>(*(const s16x8*)(x + row * ld + c0), v);
+        else
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] *= pre_scale; amax = fmaxf(amax, fabsf(v[k])); }
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        // e = ceil(log2(amax / 448)) from the float's bits (amax / 448 = m * 2^ex, 1 <= m < 2: e = ex + (m > 1))
+        const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
+        int e = (int)((bits >> 23) & 0xFF) - 127 + ((bits & 0x7FFFFF) ? 1 : 0);
+        e = amax > 0.f ? max(-127, min(127, e)) : -127;
+        const float inv = __uint_as_float((unsigned)(127 - e) << 23);      // 2^-e (e = -127: 2^254 is not a float; such blocks are all-zero)
+        unsigned w0 = 0, w1 = 0;
+        if (amax > 0.f && e > -127) {
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, w1, true);
+        }
+        if (live) *(u32x2*)(q + row * ldq + c0) = (u32x2){w0, w1};
+        // the four block scales of a 128-column tile sit in lanes 0, 4, 8, 12 of each 16-lane group
+        const unsigned sbyte = (unsigned)(e + 127);
+        const int base = lane & ~15;
+        const unsigned word = (__shfl(sbyte, base, 64) & 0xFF) | ((__shfl(sbyte, base + 4, 64) & 0xFF) << 8) |
+                              ((__shfl(sbyte, base + 8, 64) & 0xFF) << 16) | ((__shfl(sbyte, base + 12, 64) & 0xFF) << 24);
+        if (live && (lane & 15) == 0) sc[(int64_t)(c0 >> 7) * rows + row] = word;
+    }
 }
 
 // ======================================================================================================================
@@ -1259,6 +1434,63 @@ extern "C" int mico_struct_layout(int* out, int n) {
     const int total = (int)(sizeof(t) / sizeof(t[0]));
     for (int i = 0; i < n && i < total; ++i) out[i] = t[i];
     return total;
+}
+
+extern "C" int mico_quant_mx8(const void* x, int64_t ld, int64_t rows, int cols, void* q, int64_t ldq, void* scales, float pre_scale,
+                              int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype), "mico_quant_mx8: dtype must be MICO_F16 or MICO_BF16");
+    MICO_CHECK(x && q && scales && rows > 0 && cols > 0, "mico_quant_mx8: bad args");
+    MICO_CHECK(cols % 128 == 0 && ld % 8 == 0 && ldq % 8 == 0 && ld >= cols && ldq >= cols, "mico_quant_mx8: cols must be a multiple of 128, ld / ldq multiples of 8 and >= cols");
+    const int chunks = (cols + 511) / 512;
+    const int64_t units = rows * chunks;
+    const unsigned grid = (unsigned)std::min<int64_t>((units + 3) / 4, 256 * 16);
+    DISPATCH_T16(dtype, MICO_LAUNCH((quant_mx8_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols,
+                                    (unsigned char*)q, ldq, (unsigned*)scales, pre_scale));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* a_scales, const void* B, int64_t ldb,
+                             const void* b_scales, void* C, int64_t ldc, int c_dtype, const mico_gemm_epilogue* epi, int out_dtype, void* stream) {
+    MICO_CHECK(dtype_ok(out_dtype), "mico_gemm_mx8: out_dtype (the 16-bit type of C / aux tensors) must be MICO_F16 or MICO_BF16");
+    MICO_CHECK(A && B && C && a_scales && b_scales, "mico_gemm_mx8: null operand");
+    MICO_CHECK(M > 0 && N > 0 && K > 0 && K % 128 == 0, "mico_gemm_mx8: K must be a positive multiple of 128 (got %lld)", (long long)K);
+    MICO_CHECK(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K, "mico_gemm_mx8: lda / ldb must be multiples of 16 bytes and >= K");
+    MICO_CHECK(N % 4 == 0 && ldc % 4 == 0, "mico_gemm_mx8: N and ldc must be multiples of 4");
+    MICO_CHECK(c_dtype == MICO_F32 || c_dtype == out_dtype, "mico_gemm_mx8: c_dtype must be MICO_F32 or out_dtype");
+    if (c_dtype != MICO_F32) MICO_CHECK(ldc % 8 == 0 && ((uintptr_t)C & 15) == 0, "mico_gemm_mx8: a 16-bit C needs ldc %% 8 == 0 and a 16-byte aligned base");
+    MICO_CHECK(256 * lda < 0x7FFFFFFFll && 256 * ldb < 0x7FFFFFFFll, "mico_gemm_mx8: leading dimension too large");
+    Mx8Args a;
+    GemmArgs& g = a.g;
+    g.A = (const char*)A; g.B = (const char*)B; g.C = (char*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.c_dtype = c_dtype;
+    if (epi) g.e = *epi;
+    else { g.e = mico_gemm_epilogue{}; g.e.alpha = 1.f; }
+    MICO_CHECK(g.e.nseg == 0, "mico_gemm_mx8: k-segments are a 16-bit feature");
+    MICO_CHECK(g.e.act >= MICO_ACT_NONE && g.e.act <= MICO_ACT_MUL_AUX, "mico_gemm_mx8: unknown act %d", g.e.act);
+    if (g.e.act == MICO_ACT_GELU_GRAD || g.e.act == MICO_ACT_MUL_AUX) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm_mx8: GELU_GRAD / MUL_AUX need aux_in");
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MICO_CHECK(g.e.aux_out && c_dtype != MICO_F32, "mico_gemm_mx8: GELU_SAVE_DERIV needs aux_out and a 16-bit C");
+    if (epi && (epi->aux_out || epi->aux_in)) MICO_CHECK(epi->ldaux % 8 == 0, "mico_gemm_mx8: ldaux must be a multiple of 8");
+    if (g.e.row_scale) MICO_CHECK(g.e.rows_per_scale > 0, "mico_gemm_mx8: rows_per_scale must be > 0");
+    if (g.e.row_map) MICO_CHECK(g.e.rows_per_map > 0 && !g.e.remap_group, "mico_gemm_mx8: row_map needs rows_per_map > 0 and no remap_group");
+    g.ntm = (int)((M + 255) / 256); g.ntn = (int)((N + 255) / 256);
+    g.ntiles = g.ntm * g.ntn;
+    g.ktiles = (int)(K / 128);
+    g.split_k = 1; g.ktiles_per_split = g.ktiles;
+    g.ka_rows = g.kb_rows = K;
+    a.sa = (const unsigned*)a_scales; a.sb = (const unsigned*)b_scales;
+    const dim3 grid(g.ntiles), block(Mx8::THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+#define MX8(ACTV) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_mx8_kernel<T, ACTV>), grid, block, 0, st, a))
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MX8(MICO_ACT_GELU_SAVE_DERIV);
+    else if (g.e.act == MICO_ACT_MUL_AUX) MX8(MICO_ACT_MUL_AUX);
+    else if (lean) MX8(ACT_LEAN);
+    else MX8(0);
+#undef MX8
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
 }
 
 extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,

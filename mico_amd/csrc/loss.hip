@@ -97,11 +97,14 @@ __global__ __launch_bounds__(64) void itm_sample_kernel(const float* __restrict_
     int cnt = 0;
     for (int j = j0; j < j1; ++j) {
         run += (j == dcol) ? 0.f : fmaf(__expf(x[j] - m), inv, 1e-4f);
-        cnt += run < tgt;
+        cnt += run <= tgt;     // first column whose CDF exceeds the target: a zero-weight column (the diagonal) is never chosen
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-    if (lane == 0) out[row] = min(cnt, cols - 1);
+    if (lane == 0) {
+        if (cnt >= cols) cnt = (dcol == cols - 1) ? cols - 2 : cols - 1;   // u * total rounded up to the total: the last column with weight
+        out[row] = max(cnt, 0);
+    }
 }
 
 }  // namespace

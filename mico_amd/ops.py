@@ -112,6 +112,71 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     return out
 
 
+def _epilogue(bias=None, aux_out=None, aux_in=None, act=ACT_NONE, row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0,
+              remap=(0, 0, 0), alpha=1.0, accumulate=False, row_map=None, rows_per_map=0, drop=None):
+    e = GemmEpilogue()
+    e.bias, e.aux_out, e.aux_in = _p(bias), _p(aux_out), _p(aux_in)
+    aux = aux_out if aux_out is not None else aux_in
+    e.ldaux = aux.stride(0) if aux is not None else 0
+    e.act = act
+    e.row_scale, e.rows_per_scale = _p(row_scale), rows_per_scale
+    e.resid, e.pos, e.pos_rows = _p(resid), _p(pos), pos_rows
+    e.remap_group, e.remap_skip, e.remap_offset = remap
+    e.alpha = alpha
+    e.accumulate = 1 if accumulate else 0
+    e.row_map, e.rows_per_map = _p(row_map), rows_per_map
+    if drop is not None:
+        e.drop_p, e.drop_seed, e.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
+    return e
+
+
+class Mx8:
+    """An MX-fp8 operand: q uint8 [rows, K] (OCP e4m3 bytes) + scales int32 [K / 128, rows] (four E8M0 bytes per word), see mico_quant_mx8."""
+    __slots__ = ("q", "scales")
+
+    def __init__(self, q, scales):
+        self.q, self.scales = q, scales
+
+    def dequant(self):
+        """fp32 [rows, K] - tests and error measurements only."""
+        rows, K = self.q.shape
+        v = self.q.view(torch.float8_e4m3fn).float()
+        w = self.scales.t().contiguous().view(torch.uint8).view(rows, K // 128, 4).reshape(rows, K // 32).float()
+        return v * torch.exp2(w - 127.0).repeat_interleave(32, dim=1)
+
+
+def quant_mx8(x, pre_scale=1.0, rows=None):
+    """16-bit [rows, K] (row stride = ld) -> Mx8; K % 128 == 0."""
+    rows = rows if rows is not None else x.shape[0]
+    K = x.shape[1]
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((K // 128, rows), dtype=torch.int32, device=x.device)
+    check(_lib.lib().mico_quant_mx8(_p(x), x.stride(0), rows, K, _p(q), q.stride(0), _p(sc), float(pre_scale), dt_code(x.dtype), _st()),
+          "mico_quant_mx8")
+    return Mx8(q, sc)
+
+
+def gemm_mx8(A, B, out, *, dtype, M=None, **epi):
+    """out = epilogue(A B^T) on the block-scaled fp8 MFMA; A [M, K] / B [N, K] Mx8 operands; dtype = the 16-bit type of a 16-bit out /
+    aux tensors; epilogue keywords as ops.gemm (no split-K, no k-segments)."""
+    M = M if M is not None else A.q.shape[0]
+    N, K = B.q.shape
+    e = _epilogue(**epi)
+    timer = GEMM_TIMER
+    timed = timer is not None and (0, 0) in timer.variants
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().mico_gemm_mx8(M, N, K, _p(A.q), A.q.stride(0), _p(A.scales), _p(B.q), B.q.stride(0), _p(B.scales), _p(out), out.stride(0),
+                                  dt_code(out.dtype), C.byref(e), dt_code(dtype), _st())
+    if timed:
+        e1.record()
+        timer.records.append(((0, 0, 4), 2.0 * M * N * K, e0, e1))
+        timer.detail.append((M, N, K, "mx8" + ("/f32" if out.dtype == torch.float32 else ""), 1))
+    check(rc, "mico_gemm_mx8")
+    return out
+
+
 def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
                   post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16, frame_map=None,
                   rows_per_frame=0, x_copy=None, drop=None):

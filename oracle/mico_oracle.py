@@ -634,6 +634,9 @@ def itm_sample(sim, rank, bs, u):
     w[r, rank * bs + r] = 0
     cdf = w.double().cumsum(1)
     tgt = u.double() * cdf[:, -1]
-    idx = (cdf < tgt[:, None]).sum(1).clamp_max(sim.shape[1] - 1)
+    idx = (cdf <= tgt[:, None]).sum(1)          # first column whose CDF exceeds the target: never a zero-weight (diagonal) column
+    n = sim.shape[1]
+    last = torch.where(rank * bs + r == n - 1, n - 2, n - 1)
+    idx = torch.where(idx >= n, last, idx)
     margin = (cdf - tgt[:, None]).abs().min(1).values / cdf[:, -1]
     return idx, margin
