@@ -41,10 +41,12 @@ sys.path.insert(0, ROOT)
 
 # algorithmic forward GF / sample for step-B at config-3 shapes: 2 * MAC of every
 # GEMM incl. attention, LM head only where a loss consumes it; fwd+bwd = 3 x fwd
-ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74, "vitg_omni14_txt77": 24.04}
+ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74, "vitg_omni14_txt77": 24.04, "vitg_vid8_cap": 13.08}
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
 
 PRECISIONS = {   # --dtype -> (torch dtype, split_fp16, split_mode, description)
+    "fp8": ("bfloat16", False, "full", "block-scaled MX fp8 (e4m3, E8M0 per 32) MFMA for the forward and input-gradient GEMMs of the towers and "
+                                       "BERT's large projections; weight gradients, attention and everything else as bf16"),
     "fp16": ("float16", False, "full", "fp16 MFMA operands (plain), fp32 accumulate / residual stream / LN / softmax"),
     "bf16": ("bfloat16", False, "full", "bf16 MFMA operands, fp32 accumulate / residual stream / LN / softmax"),
     "fp16-split-w": ("float16", True, "weights", "fp16 MFMA, forward GEMMs x W_hi + x W_lo (weights hi/lo split, 2 k-segments)"),
@@ -62,9 +64,10 @@ def parse():
     ap.add_argument("--layers", type=int, default=None, help="truncate the ViT (debug only; invalidates the metric)")
     ap.add_argument("--dtype", default="fp16", choices=sorted(PRECISIONS))
     ap.add_argument("--task", default=None)
-    ap.add_argument("--workload", default="img_aud_txt", choices=["img_aud_txt", "omni"],
+    ap.add_argument("--workload", default="img_aud_txt", choices=["img_aud_txt", "omni", "vid_cap_fp8"],
                     help="img_aud_txt = BASELINE configs[2] (the metric's single-GPU configuration, default); omni = one rank's share "
-                         "of configs[3]: image+video (9 vision frames) + depth + audio + text, 14 frames/sample (not the headline metric)")
+                         "of configs[3]: image+video (9 vision frames) + depth + audio + text, 14 frames/sample (not the headline metric); "
+                         "vid_cap_fp8 = one rank of configs[4]: 8 video frames + BERT generative head (CAP), b = 32, --dtype fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip parity / parity_config / secondary (only the headline measurement)")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -168,6 +171,7 @@ def cpu_baseline(sd_cpu, args):
 WORKLOADS = {
     "img_aud_txt": dict(shape=dict(vision=1, audio=4, S=77), task="ret%tva_cap%tva", key="vitg_img1_aud4_txt77_stepB", frames=5),
     "omni": dict(shape=dict(vision=9, depth=1, audio=4, S=77), task="ret%tva%tvd_cap%tva", key="vitg_omni14_txt77", frames=14),
+    "vid_cap_fp8": dict(shape=dict(vision=8, S=77), task="cap%tv", key="vitg_vid8_cap", frames=8, batch=32, dtype="fp8"),
 }
 
 
@@ -176,6 +180,7 @@ def set_precision(name):
     dt, split, mode, _ = PRECISIONS[name]
     runtime.set_compute_dtype(getattr(torch, dt))
     runtime.CFG.split_fp16, runtime.CFG.split_mode = split, mode
+    runtime.CFG.fp8 = name == "fp8"
     runtime.clear_weight_cache()
 
 
@@ -233,6 +238,10 @@ def main():
     args = parse()
     wl = WORKLOADS[args.workload]
     args.task = args.task or wl["task"]
+    if "dtype" in wl and "--dtype" not in " ".join(sys.argv):
+        args.dtype = wl["dtype"]
+    if "batch" in wl and "--batch" not in " ".join(sys.argv):
+        args.batch = wl["batch"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -360,11 +369,13 @@ def main():
     samples = b * world * args.steps
     value = samples / elapsed
     kern = {0: "gemm_kernel<T,{ta},{tb},TileCfg<128,128,2,2,64,2>>", 1: "gemm_kernel<T,{ta},{tb},TileCfg<256,256,2,4,32,4>>",
-            2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>"}
+            2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>", 4: "gemm_mx8_kernel<T> (fp8 e4m3 x E8M0/32, v_mfma_scale_f32_16x16x128)"}
     role = {(0, 0): "y = x W^T (forward)", (0, 1): "dx = dy W", (1, 1): "dW = dy^T x", (1, 0): "x^T W"}
 
     def kname(key):
         ta, tb, kk = key
+        if kk == 4:
+            return kern[kk] + " : y = x W^T and dx = dy (W^T)^T"
         return kern[kk].format(ta=str(bool(ta)).lower(), tb=str(bool(tb)).lower()) + " : " + role[(ta, tb)]
 
     roofline = None
@@ -384,12 +395,13 @@ def main():
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
-                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4"}[dom[0][2]]
+                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8"}[dom[0][2]]
                 if key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
                     break
-        roofline = dict(bound="mfma", kernel=kname(dom[0]), achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
+        peak = 5000.0 if dom[0][2] == 4 else MFMA_PEAK_TFLOPS     # dense MX-fp8 peak (MI355X_MICROARCH.md) for the fp8 kernel
+        roofline = dict(bound="mfma", kernel=kname(dom[0]), achieved=achieved, peak=peak, unit="TFLOP/s",
+                        frac=achieved / peak, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
                         all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
     workload = wl["key"]
@@ -412,7 +424,9 @@ def main():
         "config": {"workload": (f"BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, "
                                 f"b={b}/GPU, task {args.task} (ITC+ITM+CAP)" if args.workload == "img_aud_txt" else
                                 f"BASELINE.json configs[3] per-rank share: ViT-g/14 image+video(9)+depth(1)+audio(4)+text(77) fwd+bwd, "
-                                f"b={b}/GPU, task {args.task}"),
+                                f"b={b}/GPU, task {args.task}" if args.workload == "omni" else
+                                f"BASELINE.json configs[4] per-rank share: ViT-g/14 video (8 x 224^2 frames) + BERT cross-attention generative "
+                                f"head (CAP), b={b}/GPU, task {args.task}, fp8 MFMA"),
                    "per_gpu_batch": b, "global_batch": b * world, "precision": PRECISIONS[args.dtype][3],
                    "vision": args.vision, "vit_layers": args.layers or "full", "parallelism": f"dp{world}",
                    "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),

@@ -133,13 +133,33 @@ def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x
     return buf, (buf[:, :cols] if split else buf), mean, rstd
 
 
+def _mx8_worthwhile(m, n):
+    """The fp8 kernel has one tile shape (256x256, one workgroup per CU): it pays where the problem fills the chip - the towers' GEMMs
+    and BERT's cross-attention K/V projections - not on BERT's few thousand text rows, which stay on the 128x128 16-bit kernel."""
+    return ((m + 255) // 256) * ((n + 255) // 256) >= 128
+
+
 def _gemm_fwd(a_buf, a_cols, plist, tag, out, **epi):
     """Forward GEMM out = a W^T: plain in the bf16 configuration; in the fp16 parity configuration the weight is hi|lo split
     (and the activation too when its producer emitted [hi | lo]) and the products are summed by one k-segmented launch."""
+    if runtime.fp8_enabled() and a_cols % 128 == 0 and "pos" not in epi and _mx8_worthwhile(a_buf.shape[0], out.shape[1]):
+        # configs[4]: block-scaled fp8 MFMA.  The activation is quantised here in a pass of its own (5 TB/s; fusing it into the producing
+        # LayerNorm / GELU epilogue is the next step), the weight's fp8 copy is cached per optimizer step.
+        return ops.gemm_mx8(ops.quant_mx8(a_buf[:, :a_cols]), runtime.gemm_weight_mx8(plist, tag), out, dtype=a_buf.dtype, **epi)
     w, ks = runtime.gemm_weight(plist, tag)
     if ks is not None and a_buf.shape[1] == 2 * a_cols and a_cols == ks[0]:
         ks = (ks[0], [0, a_cols, 0], [0, 0, ks[0]])
     return ops.gemm(a_buf[:, :a_cols], w, out, ksegs=ks, **epi)
+
+
+def _gemm_dx(dy16, plist, tag, out, **epi):
+    """Input gradient out = epilogue(dy W), W = the rows of `plist` concatenated ([N_out, K_in]): 16-bit MFMA reading W reduction-major
+    (no transposed copy), or - configs[4] - the block-scaled fp8 MFMA on dy and a transposed fp8 copy of W, both quantised along N_out."""
+    n_out = sum(p.shape[0] for p in plist)
+    k_in = plist[0].numel() // plist[0].shape[0]
+    if runtime.fp8_enabled() and n_out % 128 == 0 and _mx8_worthwhile(dy16.shape[0], k_in):
+        return ops.gemm_mx8(ops.quant_mx8(dy16), runtime.gemm_weight_mx8(plist, tag, transposed=True), out, dtype=dy16.dtype, **epi)
+    return ops.gemm(dy16, runtime.gemm_weight(plist, tag)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
 
 
 def _qkv_params(P, b, arch):
@@ -353,7 +373,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
                 ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
                 dhln = _empty((M2, Hd), dt, dev)
-                ops.gemm(g16, w16_of(w3), dhln, tb=True, M=M2, N=Hd, K=D)
+                _gemm_dx(g16, [w3], "w", dhln)
                 dhsw = _empty((M2, Hd), dt, dev)
                 ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
                                   dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
@@ -363,18 +383,18 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
                 ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
                 ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
-                ops.gemm(dx1, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
-                ops.gemm(dx2, w16_of(w2), dln2, tb=True, M=M2, N=D, K=Hd, accumulate=True)
+                _gemm_dx(dx1, [w1], "w", dln2)
+                _gemm_dx(dx2, [w2], "w", dln2, accumulate=True)
                 del dhln, dhsw, dx1, dx2
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
                 ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                ops.gemm(g16, w16_of(w2), dh, tb=True, M=M2, N=Hd, K=D, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
+                _gemm_dx(g16, [w2], "w", dh, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
                 linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
                 ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
-                ops.gemm(dh, w16_of(w1), dln2, tb=True, M=M2, N=D, K=Hd)
+                _gemm_dx(dh, [w1], "w", dln2)
                 del dh
             ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt, frame_map=fmap2,
@@ -391,7 +411,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
             ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
             dao = _empty((M1, D), dt, dev)
-            ops.gemm(g16, w16_of(wp), dao, tb=True, M=M1, N=D, K=D)
+            _gemm_dx(g16, [wp], "w", dao)
             if arch["subln"]:
                 dao2 = _empty((M1, D), dt, dev)
                 ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,
@@ -410,7 +430,6 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             ops.colsum(dqkv, dbias, scale=inv_s)
             G(b + "attn.q_bias").add_(dbias[:D])
             G(b + "attn.v_bias").add_(dbias[2 * D:])
-            wqkv = runtime.gemm_weight(_qkv_params(P, b, arch), "qkv")[0]
             if arch["subln"]:
                 dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
                 linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
@@ -420,7 +439,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             else:
                 linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
             dln1 = _empty((M1, D), torch.float32, dev)
-            ops.gemm(dqkv, wqkv, dln1, tb=True, M=M1, N=D, K=3 * D)
+            _gemm_dx(dqkv, _qkv_params(P, b, arch), "qkv", dln1)
             ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,
                               rows_per_frame=N)

@@ -24,6 +24,10 @@ class _Cfg:
     # what is split when split_fp16 is on: "full" = weights AND LayerNorm outputs (3 k-segments, x_hi W_hi + x_lo W_hi + x_hi W_lo),
     # "weights" = weights only (2 k-segments, x W_hi + x W_lo: removes the weight-rounding half of the error at 2x the MFMA work)
     split_mode = "full"
+    # BASELINE.json configs[4] ("fp8 MFMA"): the ViT towers' and BERT's forward and input-gradient GEMMs run on the block-scaled fp8 MFMA
+    # (OCP MX e4m3, one E8M0 scale per 32 reduction elements; mico_gemm_mx8) - weight gradients, attention, LayerNorm, the residual stream
+    # and every loss stay as in the 16-bit configuration of compute_dtype.  Off by default (the 16-bit path is the parity path).
+    fp8 = False
     # training: project the cross-attention K/V of a step's condition tokens once (functional.CrossKVFn) instead of in every BERT pass
     share_cross_kv = True
 
@@ -56,7 +60,7 @@ def precision(dtype):
 
 def snapshot():
     """The precision state a forward pass ran under; see using()."""
-    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode)
+    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8)
 
 
 @contextlib.contextmanager
@@ -65,11 +69,11 @@ def using(state):
     so the backward must take its weights, its gradient scale and its split mode from the same state even when it runs outside the
     `with precision(...)` block the forward ran in (fp16 activations were otherwise multiplied by bf16-bit weights)."""
     old = snapshot()
-    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode = state
+    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8 = state
     try:
         yield
     finally:
-        CFG.compute_dtype, CFG.split_fp16, CFG.split_mode = old
+        CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8 = old
 
 
 def saved_precision(backward):
@@ -196,6 +200,35 @@ def cast_weight(w, dt, k_pad=None, n_pad=None):
 
 def split_precision():
     return CFG.compute_dtype == torch.float16 and CFG.split_fp16
+
+
+@contextlib.contextmanager
+def fp8_mode(on=True):
+    old = CFG.fp8
+    CFG.fp8 = bool(on)
+    try:
+        yield
+    finally:
+        CFG.fp8 = old
+
+
+def fp8_enabled():
+    """fp8 GEMMs are an alternative to the split-precision parity configuration, never combined with it."""
+    return CFG.fp8 and not split_precision()
+
+
+def gemm_weight_mx8(plist, tag="w", transposed=False):
+    """MX-fp8 copy (ops.Mx8) of nn.Linear-style parameters (rows of all `plist` entries concatenated): W [N, K] quantised along K for
+    y = x W^T, or (transposed) W^T [K, N] quantised along N for dx = dy W - each along ITS reduction dimension, which is what the block
+    scales require.  Cached per parameter version like the 16-bit copies and re-quantised after an optimizer step."""
+    def build(dt):
+        w = plist[0].detach() if len(plist) == 1 else torch.cat([p.detach() for p in plist], 0)
+        w2 = w.reshape(w.shape[0], -1)
+        if transposed:
+            w2 = w2.t()
+        w16 = w2.contiguous().to(dt)      # layout copy + cast of a weight, once per optimizer step (not on the per-token path)
+        return ops.quant_mx8(w16)
+    return w16(("mx8t" if transposed else "mx8", tag, param_uid(plist[0])), plist, build)
 
 
 def split_activations():

@@ -298,3 +298,36 @@ def test_subtitle_subtasks(cuda):
     with runtime.precision(torch.float16), torch.no_grad():
         e2 = m.encode_batch(raw)
     assert e2["condition_feats_s"].shape == (2, m.max_subtitle_len, 768)
+
+
+def test_fp8_tower_tolerance(cuda):
+    """BASELINE configs[4] precision ("fp8 MFMA"): the towers' forward and input-gradient GEMMs on the block-scaled fp8 MFMA
+    (runtime.fp8_mode).  The reference has no fp8 path - the bound is this build's, measured against the same reference goldens as the
+    16-bit configurations: final-LN tokens of the depth-2 towers within 6e-2 of max|ref| (measured 1.5-3e-2; e4m3 carries 3 mantissa
+    bits: ~3 % per product, averaged over the reduction), gradient digests within 0.2.  Also: the fp8 kernels actually ran."""
+    from mico_amd import ops
+    for vtype, tag in (("evaclip02_base", "b16_d2"), ("evaclip01_giant", "g14_d2")):
+        m, sd = build_model(vtype, 2, device=cuda)
+        fx = golden(f"vit_{tag}.pt")
+        g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+        x = torch.randn((2, 3, 224, 224), generator=g)
+        w = torch.randn(fx["out"].shape, generator=g) / fx["out"].numel() ** 0.5
+        calls = []
+        orig = ops.gemm_mx8
+        ops.gemm_mx8 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            import mico_amd.functional as Fm
+            Fm._mx8_worthwhile, keep = (lambda mm, nn: True), Fm._mx8_worthwhile     # 2 images are a small problem: force the fp8 path
+            with runtime.precision(torch.bfloat16), runtime.fp8_mode():
+                m.zero_grad(set_to_none=True)
+                out = m.vision_encoder.visual(x.to(cuda), return_all_features=True)
+                e = rel_err(out, fx["out"])
+                (out * w.to(cuda)).sum().backward()
+        finally:
+            ops.gemm_mx8 = orig
+            Fm._mx8_worthwhile = keep
+        named = dict(m.vision_encoder.visual.named_parameters())
+        worst = max(grad_digest_check(d, named[n].grad, None) for n, d in fx["grads"].items())
+        print(f"{tag} fp8: fwd rel err {e:.2e}, worst grad digest err {worst:.2e}, {len(calls)} fp8 GEMM launches")
+        assert len(calls) >= 2 * 4 * 2 - 2      # 4 forward + 4 input-gradient GEMMs per block (B/16 has more), 2 blocks
+        assert e < 0.15 and worst < 0.35

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--m", type=int, default=82240)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--mx8", action="store_true", help="forward GEMMs on the block-scaled fp8 MFMA (+ the activation quantisation pass)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     dev = torch.device("cuda:0")
@@ -34,13 +35,16 @@ def main():
         dw = torch.zeros(N, K, device=dev)
         bias = torch.randn(N, device=dev)
         sk = 0
+        if a.mx8:
+            qx, qw = ops.quant_mx8(x), ops.quant_mx8(w)
         cases = {
-            "fwd": lambda: ops.gemm(x, w, y, bias=bias),
+            "fwd": (lambda: ops.gemm_mx8(qx, qw, y, dtype=dt, bias=bias)) if a.mx8 else (lambda: ops.gemm(x, w, y, bias=bias)),
+            **({"quant": lambda: ops.quant_mx8(x)} if a.mx8 else {}),
             "dx": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N),
             "dw": lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=sk),
         }
         for cname, fn in cases.items():
-            if a.only and cname != a.only:
+            if (a.only and cname != a.only) or (a.mx8 and cname in ("dx", "dw")):
                 continue
             for _ in range(3):
                 fn()
