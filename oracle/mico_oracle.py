@@ -600,7 +600,7 @@ def generate_beam(sd, cond, max_new_tokens, num_beams, length_penalty, bos=101, 
     return out
 
 
-def generate_sample(sd, cond, max_new_tokens, top_k, noise, bos=101, eos=102, pad=0, mask_token_id=103):
+def generate_sample(sd, cond, max_new_tokens, top_k, noise, bos=101, eos=102, pad=0, mask_token_id=103, step_logits=None):
     """Top-k sampling decode of the reference's captioner_mode (data/model/vast.py:526-536: do_sample=True, top_k=10) under the
     transformers==4.31 `sample` loop semantics (TopKLogitsWarper -> softmax -> one draw per row; finished rows emit pad; stop when all
     rows are finished or at max_length).  Third-party arithmetic absent from the reference tree ("parity unpinned"): the draw is
@@ -610,7 +610,9 @@ def generate_sample(sd, cond, max_new_tokens, top_k, noise, bos=101, eos=102, pa
     mask = torch.ones(B, 1, 1, dtype=torch.long)
     alive = torch.ones(B, dtype=torch.bool)
     for step in range(max_new_tokens):
-        logits = decode_step_logits(sd, ids, mask, cond, mask_token_id).float()
+        # step_logits(ids, mask) substitutes another model step (tests: the product's own logits, so that the SEARCH is compared
+        # bit-exactly while logit parity is gated separately - with random-init weights the top-k order flips within 16-bit rounding)
+        logits = (step_logits(ids, mask) if step_logits is not None else decode_step_logits(sd, ids, mask, cond, mask_token_id)).float()
         top_s, top_i = torch.topk(logits, top_k, dim=-1)
         cdf = torch.softmax(top_s, -1).double().cumsum(-1)
         pick = (cdf < (noise[:, step].double() * cdf[:, -1])[:, None]).sum(-1).clamp_max(top_k - 1)
