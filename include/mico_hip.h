@@ -329,9 +329,15 @@ typedef struct mico_adamw_tensor {
     int w16_dtype;    /* MICO_F16 / MICO_BF16 */
 } mico_adamw_tensor;
 
+/* grad_mult: every gradient is multiplied by it before use (1 / loss scale: the unscale_ of torch's GradScaler folded into the update,
+ * data/utils/pipeline.py:88,106; 1.0 otherwise). */
 int mico_adamw_step(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
                     int nchunks, int chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
-                    float step_size, void* stream);
+                    float step_size, float grad_mult, void* stream);
+/* Overflow check of a scaled backward (GradScaler.step, data/utils/pipeline.py:106): *flag = 1.0f if any gradient of the table (only
+ * .g / .numel of each entry are read) is inf or NaN; *flag is left untouched otherwise (the caller zeroes it). */
+int mico_grads_finite(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
+                      int nchunks, int chunk_elems, float* flag, void* stream);
 
 #ifdef __cplusplus
 }

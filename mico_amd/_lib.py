@@ -87,7 +87,8 @@ PROTOTYPES = {
     "mico_l2norm_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_image_preprocess": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp],
     "mico_fbank_windows": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_f, c_f, c_vp, c_vp],
-    "mico_adamw_step": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp],
+    "mico_adamw_step": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp],
+    "mico_grads_finite": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp],
 }
 _RESTYPES = {"mico_last_error_string": C.c_char_p}
 

@@ -116,12 +116,13 @@ __global__ void fbank_windows_kernel(const float* __restrict__ fbank, int T, int
 // ---- multi-tensor AdamW (data/utils/build_optimizer.py:105-197) ---------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(const mico_adamw_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
                                                     const int64_t* __restrict__ chunk_start, int chunk_elems, float lr, float beta1,
-                                                    float beta2, float eps, float wd, float step_size) {
+                                                    float beta2, float eps, float wd, float step_size, float grad_mult) {
     const mico_adamw_tensor t = tensors[chunk_tensor[blockIdx.x]];
     const int64_t s0 = chunk_start[blockIdx.x];
     const int64_t s1 = min(t.numel, s0 + (int64_t)chunk_elems);
     const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
     auto upd = [&](float p, float g, float& m, float& v) {
+        g *= grad_mult;     // 1 / loss scale (GradScaler.unscale_ folded into the update: no pass of its own over the gradients)
         m = m * beta1 + ob1 * g;
         v = v * beta2 + ob2 * g * g;
         p = p - step_size * (m / (sqrtf(v) + eps));
@@ -471,15 +472,47 @@ extern "C" int mico_fbank_windows(const float* fbank, int T, int mel, const int*
     return MICO_OK;
 }
 
+// any non-finite gradient among the tensors -> *flag = 1 (GradScaler's overflow check, pipeline.py:106 -> torch GradScaler.step)
+__global__ __launch_bounds__(256) void grads_finite_kernel(const mico_adamw_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
+                                                           const int64_t* __restrict__ chunk_start, int chunk_elems, float* __restrict__ flag) {
+    const mico_adamw_tensor t = tensors[chunk_tensor[blockIdx.x]];
+    const int64_t s0 = chunk_start[blockIdx.x], s1 = min(t.numel, s0 + (int64_t)chunk_elems);
+    bool bad = false;
+    const bool vec = (((uintptr_t)t.g) & 15) == 0 && (s0 & 3) == 0;
+    if (vec) {
+        int64_t i = s0 + threadIdx.x * 4;
+        for (; i + 3 < s1; i += 256 * 4) {
+            const f32x4 g = *(const f32x4*)(t.g + i);
+            bad |= !(fabsf(g[0]) <= 3.4e38f) | !(fabsf(g[1]) <= 3.4e38f) | !(fabsf(g[2]) <= 3.4e38f) | !(fabsf(g[3]) <= 3.4e38f);
+        }
+        const int64_t tail0 = s1 - ((s1 - s0) & 3);
+        i = tail0 + threadIdx.x;
+        if (i < s1) bad |= !(fabsf(t.g[i]) <= 3.4e38f);
+    } else {
+        for (int64_t i = s0 + threadIdx.x; i < s1; i += 256) bad |= !(fabsf(t.g[i]) <= 3.4e38f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;
+}
+
+extern "C" int mico_grads_finite(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
+                                 int nchunks, int chunk_elems, float* flag, void* stream) {
+    MICO_CHECK(tensors && chunk_tensor && chunk_start && flag && n_tensors > 0, "mico_grads_finite: null table");
+    MICO_CHECK(chunk_elems > 0 && chunk_elems % 4 == 0, "mico_grads_finite: chunk_elems must be a positive multiple of 4");
+    if (nchunks <= 0) return MICO_OK;
+    MICO_LAUNCH(grads_finite_kernel, dim3(nchunks), dim3(256), 0, ST, tensors, chunk_tensor, chunk_start, chunk_elems, flag);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
 extern "C" int mico_adamw_step(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
                                int nchunks, int chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
-                               float step_size, void* stream) {
+                               float step_size, float grad_mult, void* stream) {
     MICO_CHECK(tensors && chunk_tensor && chunk_start && n_tensors > 0, "mico_adamw_step: null table");
     MICO_CHECK(chunk_elems > 0 && chunk_elems % 4 == 0, "mico_adamw_step: chunk_elems must be a positive multiple of 4");
     MICO_CHECK(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "mico_adamw_step: bad hyper-parameters");
     if (nchunks <= 0) return MICO_OK;
     MICO_LAUNCH(adamw_kernel, dim3(nchunks), dim3(256), 0, ST, tensors, chunk_tensor, chunk_start, chunk_elems, lr, beta1, beta2, eps,
-                weight_decay, step_size);
+                weight_decay, step_size, grad_mult);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -33,6 +33,9 @@
 #ifndef MICO_W4_DBG
 #define MICO_W4_DBG 0
 #endif
+#ifndef MICO_W4_STAGGER
+#define MICO_W4_STAGGER 1
+#endif
 #ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
                            // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles,
                            // 6 = no epilogue
@@ -1163,10 +1166,15 @@ __global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     // whatever sits between two MFMAs must fit the 16 cycles the first one occupies the matrix pipe: the half's side work - the 16
     // fragment requests of the NEXT set and NP DMA pieces - is dealt out one item per MFMA slot (fragments in the even slots of
     // the first half of the slots, pieces evenly over the odd ones) and every slot is pinned with a sched_barrier.
+    // WOFF (0-3, the wave's index): the four waves issue their pieces in DIFFERENT slots.  A piece that fetches real data occupies the
+    // CU's one texture-address unit for ~16 cycles = one MFMA slot; issued in the same slot by all four waves (they run in lockstep
+    // between barriers) the last one waits for three others every time - measured as ~1000 lost cycles per 2048-cycle K-tile.
     auto half = [&](const s16x8 (&fax)[8], const s16x8 (&fbx)[8], s16x8 (&nax)[8], s16x8 (&nbx)[8], LDS_AS const char* pa,
-                    LDS_AS const char* pb, int abase, int bbase, const Src& s, int bo, auto p0_c, auto np_c) {
-        constexpr int P0 = decltype(p0_c)::value, NP = decltype(np_c)::value;
-        constexpr int STEP = 64 / (NP > 0 ? NP : 1);
+                    LDS_AS const char* pb, int abase, int bbase, const Src& s, int bo, auto p0_c, auto np_c, auto woff_c, auto late_c) {
+        constexpr int P0 = decltype(p0_c)::value, NP = decltype(np_c)::value, WOFF = decltype(woff_c)::value;
+        constexpr bool LATE = decltype(late_c)::value != 0;
+        constexpr int STEP = LATE ? 4 : 64 / (NP > 0 ? NP : 1);          // late pieces (first half, needed at the middle barrier): early slots
+        constexpr int SLOT0 = MICO_W4_STAGGER ? (STEP >= 4 ? WOFF * (STEP / 4) : 0) : (STEP > 1 ? 1 : 0);
 #pragma unroll
         for (int m = 0; m < 64; ++m) {
             const int i = m >> 3, cj = m & 7;
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
 #else
             if (m < 32 && (m & 1) == 0) frag(nax, nbx, pa, pb, abase, bbase, m >> 1);
 #endif
-            if (NP > 0 && (m % STEP) == (STEP > 1 ? 1 : 0) && m / STEP < NP) piece(s, bo, P0 + m / STEP);
+            if (NP > 0 && (m % STEP) == SLOT0 && m / STEP < NP) piece(s, bo, P0 + m / STEP);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1232,14 +1240,14 @@ __global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 top();
                 const Src s4 = src_of(kt0 + t + 4);
                 const int nbo = (bo + STAGE) & (4 * STAGE - 1);
-                half(fa0, fb0, fa1, fb1, lds + nbo, lds + nbo + W4::A_BYTES, ab.b0, bb.b0, s4, bo, IC(0), IC(PT));
+                half(fa0, fb0, fa1, fb1, lds + nbo, lds + nbo + W4::A_BYTES, ab.b0, bb.b0, s4, bo, IC(0), IC(PT), IC(0), IC(0));
                 bo = nbo;
             }
             {
                 top();
                 const Src s4 = src_of(kt0 + t + 5);
                 const int nbo = (bo + STAGE) & (4 * STAGE - 1);
-                half(fa1, fb1, fa0, fb0, lds + nbo, lds + nbo + W4::A_BYTES, ab.b0, bb.b0, s4, bo, IC(0), IC(PT));
+                half(fa1, fb1, fa0, fb0, lds + nbo, lds + nbo + W4::A_BYTES, ab.b0, bb.b0, s4, bo, IC(0), IC(PT), IC(0), IC(0));
                 bo = nbo;
             }
         }
@@ -1265,32 +1273,42 @@ __global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx) frag(fa0, fb0, lds, lds + W4::A_BYTES, ab.b0, bb.b0, idx);
     }
+    auto kloop = [&](auto woff_c) {
     int bo = 0;
-    for (int t = 0; t < T_; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bo) : : "memory");   // the fragment requests of the previous half (asm reads are not counted by the compiler)
-        __builtin_amdgcn_sched_barrier(0);
-        LDS_AS const char* ta = lds + bo;
-        LDS_AS const char* tb = ta + W4::A_BYTES;
-        const Src sn = src_of(kt0 + t + 1);   // late pieces of the next tile (other stage)
-        // ---- first half: MFMAs of k-step 0; requests k-step 1; the late pieces of tile t+1 ----
-        half(fa0, fb0, fa1, fb1, ta, tb, ab.b1, bb.b1, sn, bo ^ STAGE, IC(P1), IC(16 - P1));
-        // ---- mid: tile t+1 landed (own pieces), barrier: stage `bo` is no longer read by anyone, tile t+1 is visible ----
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const Src s2 = src_of(kt0 + t + 2);
-        LDS_AS const char* na = lds + (bo ^ STAGE);
-        LDS_AS const char* nb = na + W4::A_BYTES;
-        // ---- second half: MFMAs of k-step 1; requests tile t+1's k-step 0 (past the last tile: stale bytes, never used); the first P1
-        // pieces of tile t+2 into this stage ----
-        half(fa1, fb1, fa0, fb0, na, nb, ab.b0, bb.b0, s2, bo, IC(0), IC(P1));
-        bo ^= STAGE;
-    }
+        for (int t = 0; t < T_; ++t) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bo) : : "memory");   // the fragment requests of the previous half (asm reads are not counted by the compiler)
+            __builtin_amdgcn_sched_barrier(0);
+            LDS_AS const char* ta = lds + bo;
+            LDS_AS const char* tb = ta + W4::A_BYTES;
+            const Src sn = src_of(kt0 + t + 1);   // late pieces of the next tile (other stage)
+            // ---- first half: MFMAs of k-step 0; requests k-step 1; the late pieces of tile t+1 ----
+            half(fa0, fb0, fa1, fb1, ta, tb, ab.b1, bb.b1, sn, bo ^ STAGE, IC(P1), IC(16 - P1), woff_c, IC(1));
+            // ---- mid: tile t+1 landed (own pieces), barrier: stage `bo` is no longer read by anyone, tile t+1 is visible ----
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const Src s2 = src_of(kt0 + t + 2);
+            LDS_AS const char* na = lds + (bo ^ STAGE);
+            LDS_AS const char* nb = na + W4::A_BYTES;
+            // ---- second half: MFMAs of k-step 1; requests tile t+1's k-step 0 (past the last tile: stale bytes, never used); the first P1
+            // pieces of tile t+2 into this stage ----
+            half(fa1, fb1, fa0, fb0, na, nb, ab.b0, bb.b0, s2, bo, IC(0), IC(P1), woff_c, IC(0));
+            bo ^= STAGE;
+        }
+    };
+    // four copies of the loop, one per wave, differing only in the slots their DMA pieces are issued in
+    if (!MICO_W4_STAGGER || wave == 0) kloop(IC(0));
+    else if (wave == 1) kloop(IC(1));
+    else if (wave == 2) kloop(IC(2));
+    else kloop(IC(3));
     }
 #undef IC
     mfma_acc_fence();
     // ---- epilogue: four 64x64 blocks per wave through its 16 KiB of LDS ----
     if (g.split_k > 1) {
+        // the trailing pieces (tiles past the end, zero-fill) must have landed before this workgroup ends: LDS-DMA still in flight at
+        // s_endpgm lands in the LDS of the NEXT workgroup on this CU (seen as sporadic wrong split-K tiles)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll

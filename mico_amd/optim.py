@@ -47,8 +47,33 @@ class AdamW(torch.optim.Optimizer):
             self._chunk_cache[key] = hit
         return hit
 
+    def _grad_table(self, plist):
+        """descriptor table (gradients only) + chunk lists over `plist`, for mico_grads_finite"""
+        dev = plist[0].device
+        descs = (_Desc * len(plist))()
+        keep = []
+        for d, p in zip(descs, plist):
+            g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
+            keep.append(g)
+            d.g, d.numel = g.data_ptr(), p.numel()
+        table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        return table, keep, self._chunks([p.numel() for p in plist], dev)
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def grads_nonfinite(self, flag):
+        """flag (fp32 device scalar) <- 1 if any gradient this optimizer would consume is inf / NaN; no host sync here."""
+        plist = [p for group in self.param_groups for p in group["params"] if p.grad is not None]
+        if not plist:
+            return flag
+        table, keep, (ct, cs, n) = self._grad_table(plist)
+        _lib.check(_lib.lib().mico_grads_finite(table.data_ptr(), len(plist), ct.data_ptr(), cs.data_ptr(), n, CHUNK, flag.data_ptr(),
+                                                torch.cuda.current_stream(plist[0].device).cuda_stream), "mico_grads_finite")
+        del keep
+        return flag
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_mult=1.0):
+        """grad_mult: gradients are multiplied by it inside the update kernel (GradScaler: 1 / loss scale)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -95,11 +120,67 @@ class AdamW(torch.optim.Optimizer):
                 ct, cs, n = self._chunks([p.numel() for p in plist], dev)
                 rc = lib.mico_adamw_step(table.data_ptr(), len(plist), ct.data_ptr(), cs.data_ptr(), n, CHUNK, float(group["lr"]),
                                          float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), float(step_size),
-                                         torch.cuda.current_stream(dev).cuda_stream)
+                                         float(grad_mult), torch.cuda.current_stream(dev).cuda_stream)
                 _lib.check(rc, "mico_adamw_step")
                 del keep
         runtime.after_optimizer_step(refreshed)
         return loss
+
+
+class GradScaler:
+    """Dynamic loss scaling with the interface and semantics of torch.cuda.amp.GradScaler as the reference trainer uses it
+    (data/utils/pipeline.py:30,88,106-107: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()): the loss is
+    multiplied by the scale, step() checks the gradients for inf / NaN and SKIPS the optimizer step when it finds any (one device ->
+    host read of a flag, exactly where torch's scaler has its .item()), update() halves the scale after a skipped step and doubles it
+    after growth_interval clean ones.  On the MI355X path the un-scaling is not a pass of its own: mico_adamw_step multiplies the
+    gradients by 1 / scale while it reads them, and the overflow check is one read-only multi-tensor kernel (mico_grads_finite).
+    (The engine additionally carries its 16-bit activations' gradients x4096 inside each fp16 function; that internal scale never
+    reaches a parameter gradient and is independent of this one.)"""
+
+    def __init__(self, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self._scale, self._growth, self._backoff, self._interval = float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._good_steps, self._enabled, self._found_inf = 0, enabled, None
+
+    def scale(self, loss):
+        return loss * self._scale if self._enabled else loss
+
+    def get_scale(self):
+        return self._scale
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if not hasattr(optimizer, "grads_nonfinite"):
+            raise TypeError("mico_amd.optim.GradScaler drives mico_amd.optim.AdamW (fused un-scale + overflow check)")
+        dev = next(p for g in optimizer.param_groups for p in g["params"]).device
+        flag = torch.zeros(1, dtype=torch.float32, device=dev)
+        optimizer.grads_nonfinite(flag)
+        self._found_inf = bool(flag.item())      # the one host sync of the step (torch's GradScaler.step has the same one)
+        if self._found_inf:
+            return None
+        return optimizer.step(*args, grad_mult=1.0 / self._scale, **kwargs)
+
+    def update(self, new_scale=None):
+        if not self._enabled:
+            return
+        if new_scale is not None:
+            self._scale, self._good_steps = float(new_scale), 0
+        elif self._found_inf:
+            self._scale, self._good_steps = self._scale * self._backoff, 0
+        else:
+            self._good_steps += 1
+            if self._good_steps == self._interval:
+                self._scale, self._good_steps = self._scale * self._growth, 0
+        self._found_inf = None
+
+    def state_dict(self):
+        return {"scale": self._scale, "growth_factor": self._growth, "backoff_factor": self._backoff, "growth_interval": self._interval,
+                "_growth_tracker": self._good_steps} if self._enabled else {}
+
+    def load_state_dict(self, sd):
+        if sd:
+            self._scale, self._growth, self._backoff = float(sd["scale"]), float(sd["growth_factor"]), float(sd["backoff_factor"])
+            self._interval, self._good_steps = int(sd["growth_interval"]), int(sd["_growth_tracker"])
 
 
 def build_optimizer(model, args, checkpoint_optim=None):

