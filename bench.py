@@ -369,7 +369,8 @@ def main():
     samples = b * world * args.steps
     value = samples / elapsed
     kern = {0: "gemm_kernel<T,{ta},{tb},TileCfg<128,128,2,2,64,2>>", 1: "gemm_kernel<T,{ta},{tb},TileCfg<256,256,2,4,32,4>>",
-            2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>", 4: "gemm_mx8_kernel<T> (fp8 e4m3 x E8M0/32, v_mfma_scale_f32_16x16x128)"}
+            2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>", 4: "gemm_mx8_kernel<T> (fp8 e4m3 x E8M0/32, v_mfma_scale_f32_16x16x128)",
+            5: "gemm_persist_kernel<T,{ta},{tb}> (256x256 8-wave ping-pong, persistent)"}
     role = {(0, 0): "y = x W^T (forward)", (0, 1): "dx = dy W", (1, 1): "dW = dy^T x", (1, 0): "x^T W"}
 
     def kname(key):
@@ -395,7 +396,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
-                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8"}[dom[0][2]]
+                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8", 5: "big"}[dom[0][2]]
                 if key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
                     break

@@ -103,10 +103,11 @@ typedef struct mico_gemm_epilogue {
 } mico_gemm_epilogue;
 
 /* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256
- * producer/consumer, 3 = 256x256 one wave per SIMD (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
+ * producer/consumer, 3 = 256x256 one wave per SIMD (experiment builds), 4 = MX-fp8, 5 = 256x256 8-wave persistent (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
 int mico_gemm_last_kernel(void);
 /* kernel routing switch for A/B measurements (process-wide; returns the previous value): 0 = default routing, 1 = never the
- * one-wave-per-SIMD kernel, 2 = the one-wave-per-SIMD kernel takes every large problem it supports */
+ * one-wave-per-SIMD kernel, 2 / 3 = the one-wave-per-SIMD experiment kernel (builds with -DMICO_GEMM_W4 only) takes every large problem it
+ * supports, 4 = never the persistent form of the 8-wave kernel */
 int mico_gemm_set_variant(int variant);
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,

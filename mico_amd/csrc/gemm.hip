@@ -627,6 +627,158 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
 }
 
 // ======================================================================================================================
+// EXPERIMENT (round 2), compiled only with -DMICO_GEMM_PERSIST: persistent form of the 8-wave ping-pong kernel (forward / dX GEMMs without
+// split-K).  Result (tools/probes/README.md): microbench forward +1 %, dX +5 %; in situ 91.6 vs 92.5 samples/s - no gain, not routed.
+// Per 256x256 tile the kernel above pays ~11 us around its K loop - 2.9 us until the first K-tile has landed, a 12.7 us epilogue that
+// nothing overlaps, and ~4 us before the hardware has a new workgroup running on the CU - against 36 us of K loop at K = 1408
+// (tools/probes/gemm_phases.py).  Here 256 workgroups stay resident and walk the tiles their XCD would have been dealt (same tile
+// order, so the same panel sharing in L2); the first two K-tiles of the NEXT tile are requested before the epilogue of the current
+// one starts - the epilogue stages through the lower half of the LDS (8 KiB per wave, 32-row blocks), the prefetch lands in the
+// upper half (ring slots 2, 3; every tile's ring starts at slot 2) - so that the loads of tile i + 1 travel while the stores of tile i
+// drain, and there is no dispatch gap.  One `vmcnt(0)` + barrier between epilogue and K loop (stores and prefetch have both had the
+// whole epilogue to complete) keeps the K loop's counted waits free of stores.
+// ======================================================================================================================
+#ifdef MICO_GEMM_PERSIST
+template <typename T, bool TA, bool TB, int ACT>
+__global__ __launch_bounds__(Big::THREADS, 2) void gemm_persist_kernel(const GemmArgs g) {
+    using CFG = Big;
+    constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK, THREADS = CFG::THREADS, MT = CFG::MT;
+    constexpr int PT = CFG::A_DMA + CFG::B_DMA, RING = CFG::STAGES * CFG::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[CFG::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+    const int wrow = wm * (BM / CFG::WM), wcol = wn * 64;
+    const int grp = wave >> 2;
+    // this workgroup's tiles: positions j, j + per_xcd, ... of XCD x's contiguous chunk of the remapped tile order
+    const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx;
+    const int x = blockIdx.x % nx, j0 = blockIdx.x / nx, per_xcd = gridDim.x / nx;
+    const int chunk0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, chunk_n = q + (x < r ? 1 : 0);
+    const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+    const int T_ = g.ktiles;
+    // (K % 32 == 0 only - mico_gemm routes ragged K to the one-tile-per-workgroup kernel and its masked staging path)
+    const FragBase ab = frag_base<TA, BM, BK>(wrow, lane), bb = frag_base<TB, BN, BK>(wcol, lane);
+
+    struct Tile { int tm, tn; __amdgpu_buffer_rsrc_t rsa, rsb; unsigned voa[CFG::A_DMA], vob[CFG::B_DMA]; };
+    auto setup = [&](int pos, Tile& t) {
+        const int bid = chunk0 + pos;
+        const int gsz = GROUP_M * g.ntn;
+        const int grp_ = bid / gsz;
+        const int first = grp_ * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp_ * gsz;
+        t.tm = first + in % gm;
+        t.tn = in / gm;
+        const int64_t m0 = (int64_t)t.tm * BM, n0 = (int64_t)t.tn * BN;
+        const char* a_base = TA ? g.A + m0 * 2 : g.A + m0 * lda_b;
+        const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
+        int64_t a_bytes = TA ? g.ka_rows * lda_b - m0 * 2 : (g.M - m0) * lda_b;
+        int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+        if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+        if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+        t.rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+        t.rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+        dma_offsets<TA, BM, THREADS, BK, CFG::A_DMA>(t.voa, wave, lane, lda_b, g.M - m0);
+        dma_offsets<TB, BN, THREADS, BK, CFG::B_DMA>(t.vob, wave, lane, ldb_b, g.N - n0);
+    };
+    auto stage = [&](const Tile& t, int kt, int bo) {
+        const int k0 = kt * BK;
+        const unsigned koa = TA ? (unsigned)((int64_t)k0 * lda_b) : (unsigned)(k0 * 2);
+        const unsigned kob = TB ? (unsigned)((int64_t)k0 * ldb_b) : (unsigned)(k0 * 2);
+        dma_issue<THREADS, CFG::A_DMA>(t.rsa, lds + bo, wave, t.voa, koa);
+        dma_issue<THREADS, CFG::B_DMA>(t.rsb, lds + bo + CFG::A_BYTES, wave, t.vob, kob);
+    };
+    constexpr int SLOT2 = 2 * CFG::STAGE_BYTES;
+    Tile cur;
+    if (j0 >= chunk_n) return;
+    setup(j0, cur);
+    for (int i = 0; i < 2 && i < T_; ++i) stage(cur, i, (SLOT2 + i * CFG::STAGE_BYTES) & (RING - 1));
+
+    for (int pos = j0; pos < chunk_n; pos += per_xcd) {
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (T_ > 2) stage(cur, 2, (SLOT2 + 2 * CFG::STAGE_BYTES) & (RING - 1));
+        s16x8 fa[MT], fb[4];
+        auto read_k = [&](int bo) {
+            LDS_AS const char* ta = lds + bo;
+            LDS_AS const char* tb = ta + CFG::A_BYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = read_frag_b<TA, BM, BK>(ta, ab.b0, i);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fb[jj] = read_frag_b<TB, BN, BK>(tb, bb.b0, jj);
+        };
+        auto mma_k = [&]() {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = T16<T>::mfma(fb[jj], fa[i], acc[i][jj]);
+        };
+        auto head = [&](int t) {
+            const int ahead = T_ - 1 - t;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int bo = SLOT2;
+        if (grp == 0) {
+            for (int t = 0; t < T_; ++t) {
+                asm volatile("" : "+s"(bo));
+                head(t);
+                read_k(bo);
+                if (t + 3 < T_) stage(cur, t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));
+                bar();
+                mma_k();
+                __builtin_amdgcn_sched_barrier(0);
+                bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+            }
+        } else {
+            for (int t = 0; t < T_; ++t) {
+                asm volatile("" : "+s"(bo));
+                head(t);
+                if (t > 0) mma_k();
+                bar();
+                read_k(bo);
+                if (t + 3 < T_) stage(cur, t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+            }
+            if (T_ > 0) mma_k();
+        }
+        __syncthreads();   // every wave is done with the operand tiles; the DMA queue is empty (last head waited vmcnt(0))
+        // ---- the next tile's first two K-tiles travel while this tile's epilogue runs ----
+        const int64_t em0 = (int64_t)cur.tm * BM, en0 = (int64_t)cur.tn * BN;
+        const bool more = pos + per_xcd < chunk_n;
+        if (more) {
+            setup(pos + per_xcd, cur);
+            for (int i = 0; i < 2 && i < T_; ++i) stage(cur, i, (SLOT2 + i * CFG::STAGE_BYTES) & (RING - 1));
+        }
+        // (the lane index is laundered: everything the epilogue derives from it alone - column groups, swizzle keys, bias loads - is
+        // invariant across this loop and would otherwise be hoisted above it and held in registers through every K loop)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+#pragma unroll
+        for (int h = 0; h < MT / 2; ++h)
+            gemm_epilogue_block<T, 2, ACT>(g, &acc[h * 2], lds + wave * 8192, em0 + wrow + h * 32, en0 + wcol, lane_e);
+        // stores and prefetch have landed; nobody reads the epilogue staging area any more
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+#endif   // MICO_GEMM_PERSIST
+
+// ======================================================================================================================
 // MX-fp8 GEMM (BASELINE.json configs[4]: "fp8 MFMA"): C = epilogue(A B^T) with A [M, K] and B [N, K] in OCP e4m3 and one E8M0 scale per
 // 32 consecutive k (the OCP microscaling format), on v_mfma_scale_f32_16x16x128_f8f6f4 - the only fp8 MFMA on gfx950 that runs above
 // the bf16 rate (2x; the unscaled fp8 forms run AT the bf16 rate).
@@ -1341,6 +1493,24 @@ void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
 #endif
 }
 
+// persistent launch of the 8-wave kernel: the lean and the MLP-pair instantiations (the launches that carry the towers' forward / dX work)
+template <typename T>
+bool launch_persist(int ta, int tb, const GemmArgs& g, hipStream_t st) {
+#ifndef MICO_GEMM_PERSIST
+    return false;
+#else
+    const dim3 grid(256), block(Big::THREADS);
+    if (ta) return false;
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_persist_kernel<T, false, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return true; }
+    if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_persist_kernel<T, false, true, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return true; }
+    const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    if (!lean) return false;
+    if (!tb) MICO_LAUNCH((gemm_persist_kernel<T, false, false, ACT_LEAN>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_persist_kernel<T, false, true, ACT_LEAN>), grid, block, 0, st, g);
+    return true;
+#endif
+}
+
 template <typename T, typename CFG>
 void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles * g.split_k), block(CFG::THREADS);
@@ -1620,7 +1790,13 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else
 #endif
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
-    else if (big) DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
+    else if (big) {
+        // persistent form when every CU gets several tiles and nothing is split (variant 4 forces it off, for A/B runs)
+        bool done = false;
+        if (g.split_k == 1 && g.ntiles >= 512 && g.e.nseg == 0 && K % 32 == 0 && g_mico_gemm_variant != 4) DISPATCH_T16(dtype, (done = launch_persist<T>(ta, tb, g, st)));
+        if (done) g_mico_last_gemm_kernel = 5;
+        else DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
+    }
     else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));
     MICO_LAUNCH_CHECK();
     return MICO_OK;

@@ -19,6 +19,10 @@ import sys
 def variant(name):
     if "gemm_pc_kernel" in name:
         kind = "pc"
+    elif "gemm_persist_kernel" in name:
+        kind = "big"
+    elif "gemm_mx8_kernel" in name:
+        return "NN_mx8"
     elif "gemm_kernel" in name:
         kind = "big" if re.search(r"256,\s*256|Li256ELi256", name) else "small"
     else:
