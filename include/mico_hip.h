@@ -143,6 +143,9 @@ int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, c
  *   frame_map[r / rows_per_frame] * rows_per_frame + r % rows_per_frame of x (compacting gather of whole frames; all outputs
  *   are compact);  x_copy (optional, fp32 [rows, cols]) receives the gathered input rows (saved for the backward).
  *   drop_p > 0: dropout on the outputs (BertEmbeddings, bert.py:147-148), element index row * cols + col, see mico_dropout.
+ *   valid_cols (0 = cols): the rows are zero-padded [valid_cols | 0 ...] vectors - statistics (and, in the backward, the two row means)
+ *   are taken over the valid columns only; gamma / beta must be zero-padded so that the padded outputs are 0 (EVA02-CLIP-L's 2730-wide
+ *   SwiGLU hidden, eva_vit_model.py:203-224, lives in 2752-wide buffers: GEMM operands need 16-byte rows).
  * ------------------------------------------------------------------------------------------------------------- */
 int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                        void* y16, float* y32, float* mean, float* rstd,
@@ -150,7 +153,7 @@ int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
                        const float* post_add, int post_rows_per_group, int post_groups, int y16_split,
                        const int* frame_map, int rows_per_frame, float* x_copy,
                        float drop_p, unsigned drop_seed, int drop_site,
-                       int dtype, void* stream);
+                       int valid_cols, int dtype, void* stream);
 /* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
  * (dx16 = T(dx * scale16)).
  * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced
@@ -162,7 +165,7 @@ int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void*
                        const float* gamma, const float* mean, const float* rstd,
                        const float* dx_add, float* dx32, void* dx16, float scale16,
                        float* dgamma, float* dbeta, float grad_scale, float* ws,
-                       int64_t rows, int cols, const int* frame_map, int rows_per_frame, int dtype, void* stream);
+                       int64_t rows, int cols, const int* frame_map, int rows_per_frame, int valid_cols, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (flash style: scores never materialised), forward and backward.

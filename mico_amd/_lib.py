@@ -52,10 +52,10 @@ PROTOTYPES = {
     "mico_quant_mx8": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_f, c_int, c_vp],
     "mico_gemm_mx8": [c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, C.POINTER(GemmEpilogue), c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
-                           c_int, c_vp, c_int, c_vp, c_f, C.c_uint, c_int, c_int, c_vp],
+                           c_int, c_vp, c_int, c_vp, c_f, C.c_uint, c_int, c_int, c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
     "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
-                           c_i64, c_int, c_vp, c_int, c_int, c_vp],
+                           c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "mico_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_rope": [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],

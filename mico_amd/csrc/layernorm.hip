@@ -33,11 +33,15 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            int post_groups, int split16,
                                                            const int* __restrict__ frame_map, int rpf,
                                                            float* __restrict__ x_copy, float drop_p, unsigned drop_seed,
-                                                           int drop_site) {
+                                                           int drop_site, int valid_cols) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
-    const float inv = 1.0f / (float)cols;
+    // valid_cols < cols: the row is a zero-padded [valid_cols | 0 ...] vector (EVA02-L's 2730-wide SwiGLU hidden in a 2752-wide buffer):
+    // statistics over the valid columns only - the zeros add nothing to the sum and exactly (cols - valid) * mean^2 to the centred sum of
+    // squares, which is taken out in closed form; gamma / beta are zero-padded by the caller, so the padded outputs are 0
+    const float inv = 1.0f / (float)valid_cols;
+    const float npad = (float)(cols - valid_cols);
     // the next row of this wave is requested before the current one is reduced and stored (one row at a time the wave has no load in
     // flight during its two reductions and its stores)
     auto fetch = [&](int64_t row, f32x4 (&dst)[NV]) {
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
         }
-        const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+        const float rstd = rsqrtf(fmaxf(wave_sum(q) - npad * mean * mean, 0.f) * inv + eps);
         if (lane == 0) {
             if (mean_o) mean_o[row] = mean;
             if (rstd_o) rstd_o[row] = rstd;
@@ -122,12 +126,12 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            const float* __restrict__ rstd, const float* __restrict__ dx_add,
                                                            float* __restrict__ dx32, T* __restrict__ dx16, float scale16,
                                                            float* __restrict__ ws, int64_t rows, int cols, float dy_scale,
-                                                           const int* __restrict__ frame_map, int rpf) {
+                                                           const int* __restrict__ frame_map, int rpf, int valid_cols) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
-    const float inv = 1.0f / (float)cols;
+    const float inv = 1.0f / (float)valid_cols;   // (zero-padded rows: gamma is zero-padded, so the padded columns add nothing to either mean)
     f32x4 dg[NV], db[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -233,15 +237,16 @@ extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
 template <typename T, typename XT>
 void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
                    float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16,
-                   const int* fmap, int rpf, float* x_copy, float dp, unsigned dseed, int dsite) {
-#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite)
+                   const int* fmap, int rpf, float* x_copy, float dp, unsigned dseed, int dsite, int valid) {
+#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite, valid)
     if (!post_add && dp == 0.f && !y32 && !split16 && cols > 1024 && cols <= 1536) {
-        MICO_LAUNCH((ln_fwd_kernel<T, XT, 6, true>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite);
+        MICO_LAUNCH((ln_fwd_kernel<T, XT, 6, true>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite, valid);
         return;
     }
     if (cols <= 1024) LNF(4);
     else if (cols <= 1536) LNF(6);
     else if (cols <= 2048) LNF(8);
+    else if (cols <= 3072) LNF(12);
     else LNF(16);
 #undef LNF
 }
@@ -249,11 +254,12 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
 template <typename T, typename DT, typename XT>
 void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                    const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
-                   int cols, float dy_scale, const int* fmap, int rpf) {
-#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf)
+                   int cols, float dy_scale, const int* fmap, int rpf, int valid) {
+#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf, valid)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
-    else LNB(8);
+    else if (cols <= 2048) LNB(8);
+    else LNB(11);
 #undef LNB
 }
 
@@ -265,8 +271,10 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
                                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add,
                                   int post_rows_per_group, int post_groups, int y16_split, const int* frame_map,
                                   int rows_per_frame, float* x_copy, float drop_p, unsigned drop_seed, int drop_site,
-                                  int dtype, void* stream) {
+                                  int valid_cols, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
+    if (valid_cols <= 0) valid_cols = cols;
+    MICO_CHECK(valid_cols <= cols, "mico_layernorm_fwd: valid_cols > cols");
     if (rows <= 0) return MICO_OK;   // an empty batch is a no-op (its tensors have no storage to point to)
     MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
@@ -277,8 +285,8 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_grid(rows, 1024));
     DISPATCH_T16(dtype, {
-        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site);
-        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site);
+        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site, valid_cols);
+        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site, valid_cols);
     });
     MICO_LAUNCH_CHECK();
     return MICO_OK;
@@ -287,12 +295,14 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
 extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype, const float* gamma,
                                   const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
                                   float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
-                                  int cols, const int* frame_map, int rows_per_frame, int dtype, void* stream) {
+                                  int cols, const int* frame_map, int rows_per_frame, int valid_cols, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
+    if (valid_cols <= 0) valid_cols = cols;
+    MICO_CHECK(valid_cols <= cols, "mico_layernorm_bwd: valid_cols > cols");
     if (rows <= 0) return MICO_OK;
     if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_bwd: frame_map needs rows_per_frame > 0");
     MICO_CHECK(dy && x && gamma && mean && rstd, "mico_layernorm_bwd: null pointer");
-    MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 2048, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 2048 (got %d)", cols);
+    MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 2816, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 2816 (got %d)", cols);
     MICO_CHECK((dy_dtype == MICO_F32 || dy_dtype == dtype) && (x_dtype == MICO_F32 || x_dtype == dtype), "mico_layernorm_bwd: bad in dtype");
     MICO_CHECK(!(dgamma || dbeta) || ws, "mico_layernorm_bwd: dgamma/dbeta need a workspace");
     if (rows <= 0) return MICO_OK;
@@ -301,10 +311,10 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     const dim3 grid(nblk);
     float* wsp = (dgamma || dbeta) ? ws : nullptr;
     DISPATCH_T16(dtype, {
-        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
-        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
-        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
-        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame);
+        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
+        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
+        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
+        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {

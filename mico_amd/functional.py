@@ -91,6 +91,10 @@ class TowerSpec:
         self.np = grid * grid
         self.N = self.np + 1
         self.hidden = arch["mlp_hidden"]
+        # GEMM operands need 16-byte rows: a hidden width that is not a multiple of 8 (EVA02-CLIP-L: int(1024 * 2.6667) = 2730) lives
+        # in buffers padded to a multiple of 64 with zero weights / biases / LayerNorm parameters behind it - algebraically the
+        # same MLP (the padded units compute silu(0) * 0 = 0 and feed zero weights)
+        self.hidden_pad = self.hidden if self.hidden % 8 == 0 else (self.hidden + 63) // 64 * 64
         self.eps = 1e-6
         self.rope = rope   # (cos, sin) fp32 [np, hd] device tensors or None
         self.kpad3 = (3 * self.P * self.P + 63) // 64 * 64
@@ -122,14 +126,24 @@ class TowerSpec:
         return out
 
 
-def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None):
+def _padv(p, n):
+    """fp32 vector zero-padded to n entries (bias / LayerNorm parameter of a padded hidden width)"""
+    v = p.detach()
+    if v.shape[0] == n:
+        return v
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[:v.shape[0]] = v
+    return out
+
+
+def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None, valid_cols=0):
     """LayerNorm -> 16-bit GEMM operand.  Returns (buf, view, mean, rstd); in the split-precision (fp16 parity) mode buf is
     [rows, 2*cols] = [hi | lo] and view its hi half.  frame_map: compacting gather of whole frames (rows = kept rows)."""
     split = runtime.split_activations() and cols % 64 == 0
     buf = _empty((rows, 2 * cols if split else cols), dt, dev)
     mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
     ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt, frame_map=frame_map,
-                      rows_per_frame=rows_per_frame, x_copy=x_copy)
+                      rows_per_frame=rows_per_frame, x_copy=x_copy, valid_cols=valid_cols)
     return buf, (buf[:, :cols] if split else buf), mean, rstd
 
 
@@ -139,24 +153,26 @@ def _mx8_worthwhile(m, n):
     return ((m + 255) // 256) * ((n + 255) // 256) >= 128
 
 
-def _gemm_fwd(a_buf, a_cols, plist, tag, out, **epi):
+def _gemm_fwd(a_buf, a_cols, plist, tag, out, k_pad=None, n_pad=None, **epi):
     """Forward GEMM out = a W^T: plain in the bf16 configuration; in the fp16 parity configuration the weight is hi|lo split
     (and the activation too when its producer emitted [hi | lo]) and the products are summed by one k-segmented launch."""
-    if runtime.fp8_enabled() and a_cols % 128 == 0 and "pos" not in epi and _mx8_worthwhile(a_buf.shape[0], out.shape[1]):
+    if runtime.fp8_enabled() and a_cols % 128 == 0 and "pos" not in epi and not k_pad and not n_pad and _mx8_worthwhile(a_buf.shape[0], out.shape[1]):
         # configs[4]: block-scaled fp8 MFMA.  The activation is quantised here in a pass of its own (5 TB/s; fusing it into the producing
         # LayerNorm / GELU epilogue is the next step), the weight's fp8 copy is cached per optimizer step.
         return ops.gemm_mx8(ops.quant_mx8(a_buf[:, :a_cols]), runtime.gemm_weight_mx8(plist, tag), out, dtype=a_buf.dtype, **epi)
-    w, ks = runtime.gemm_weight(plist, tag)
+    w, ks = runtime.gemm_weight(plist, tag, k_pad=k_pad, n_pad=n_pad)
     if ks is not None and a_buf.shape[1] == 2 * a_cols and a_cols == ks[0]:
         ks = (ks[0], [0, a_cols, 0], [0, 0, ks[0]])
     return ops.gemm(a_buf[:, :a_cols], w, out, ksegs=ks, **epi)
 
 
-def _gemm_dx(dy16, plist, tag, out, **epi):
+def _gemm_dx(dy16, plist, tag, out, k_pad=None, n_pad=None, **epi):
     """Input gradient out = epilogue(dy W), W = the rows of `plist` concatenated ([N_out, K_in]): 16-bit MFMA reading W reduction-major
     (no transposed copy), or - configs[4] - the block-scaled fp8 MFMA on dy and a transposed fp8 copy of W, both quantised along N_out."""
-    n_out = sum(p.shape[0] for p in plist)
-    k_in = plist[0].numel() // plist[0].shape[0]
+    n_out = n_pad or sum(p.shape[0] for p in plist)          # (padded hidden widths: zero rows / columns behind the parameter's own)
+    k_in = k_pad or plist[0].numel() // plist[0].shape[0]
+    if k_pad or n_pad:
+        return ops.gemm(dy16, runtime.gemm_weight(plist, tag, k_pad=k_pad, n_pad=n_pad)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
     if runtime.fp8_enabled() and n_out % 128 == 0 and _mx8_worthwhile(dy16.shape[0], k_in):
         return ops.gemm_mx8(ops.quant_mx8(dy16), runtime.gemm_weight_mx8(plist, tag, transposed=True), out, dtype=dy16.dtype, **epi)
     return ops.gemm(dy16, runtime.gemm_weight(plist, tag)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
@@ -289,25 +305,29 @@ def _tower_forward(spec, groups, dp_scale, params, save):
             x_out = _empty((M, D), torch.float32, dev) if fmap2 is None else x
             epi = dict(resid=x, row_scale=sc2, rows_per_scale=N, row_map=fmap2, rows_per_map=N)
             if arch["swiglu"]:
-                g1, g2 = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
+                Hp = spec.hidden_pad                     # == Hd unless the hidden width needs padding (see TowerSpec)
+                npad = Hp if Hp != Hd else None
+                b1, b2 = _padv(P(b + "mlp.w1.bias"), Hp), _padv(P(b + "mlp.w2.bias"), Hp)
+                g1, g2 = _empty((M2, Hp), dt, dev), _empty((M2, Hp), dt, dev)
                 if runtime.split_precision():
                     # parity configuration: the gate runs in fp32 (x1, x2 and the gated product never round to fp16 on the
                     # forward path); 16-bit copies of x1 / x2 are kept for the backward kernels only
-                    x1f, x2f = _empty((M2, Hd), torch.float32, dev), _empty((M2, Hd), torch.float32, dev)
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=P(b + "mlp.w1.bias"))
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=P(b + "mlp.w2.bias"))
-                    hsw = _empty((M2, Hd), torch.float32, dev)
+                    x1f, x2f = _empty((M2, Hp), torch.float32, dev), _empty((M2, Hp), torch.float32, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", x1f, bias=b1, n_pad=npad)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", x2f, bias=b2, n_pad=npad)
+                    hsw = _empty((M2, Hp), torch.float32, dev)
                     ops.swiglu_fwd_f32(x1f, x2f, hsw)
                     ops.cast_f32_to_16(x1f, g1)
                     ops.cast_f32_to_16(x2f, g2)
                     del x1f, x2f
                 else:
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", g1, bias=P(b + "mlp.w1.bias"))
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", g2, bias=P(b + "mlp.w2.bias"))
-                    hsw = _empty((M2, Hd), dt, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w1.weight")], "w", g1, bias=b1, n_pad=npad)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.w2.weight")], "w", g2, bias=b2, n_pad=npad)
+                    hsw = _empty((M2, Hp), dt, dev)
                     ops.swiglu_fwd(g1, g2, hsw)
-                hlnb, hln, mean_f, rstd_f = _ln16(hsw, P(b + "mlp.ffn_ln.weight"), P(b + "mlp.ffn_ln.bias"), spec.eps, M2, Hd, dt, dev)
-                _gemm_fwd(hlnb, Hd, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), **epi)
+                hlnb, hln, mean_f, rstd_f = _ln16(hsw, _padv(P(b + "mlp.ffn_ln.weight"), Hp), _padv(P(b + "mlp.ffn_ln.bias"), Hp), spec.eps,
+                                                  M2, Hp, dt, dev, valid_cols=Hd if npad else 0)
+                _gemm_fwd(hlnb, Hp, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), k_pad=npad, **epi)
                 a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
             else:
                 h = _empty((M2, Hd), dt, dev)
@@ -370,22 +390,39 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             dln2 = _empty((M2, D), torch.float32, dev)
             if arch["swiglu"]:
                 w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
-                linear_wgrad(g16, a["hln"], G(b + "mlp.w3.weight"), inv_s)
+                Hp = spec.hidden_pad
+                npad = Hp if Hp != Hd else None
+                pend = []
+
+                def GP(name, shape):
+                    """gradient target of `name`, or - padded hidden width - a zero-filled buffer of the padded shape whose leading
+                    block is added to the parameter's gradient afterwards"""
+                    tgt = G(name)
+                    if npad is None:
+                        return tgt
+                    tmp = torch.zeros(shape, dtype=torch.float32, device=dev)
+                    pend.append((tgt, tmp))
+                    return tmp
+
+                linear_wgrad(g16, a["hln"], GP(b + "mlp.w3.weight", (D, Hp)), inv_s)
                 ops.colsum(g16, G(b + "mlp.w3.bias"), scale=inv_s, accumulate=True)
-                dhln = _empty((M2, Hd), dt, dev)
-                _gemm_dx(g16, [w3], "w", dhln)
-                dhsw = _empty((M2, Hd), dt, dev)
-                ops.layernorm_bwd(dhln, a["hsw"], P(b + "mlp.ffn_ln.weight"), a["mean_f"], a["rstd_f"], dx16=dhsw,
-                                  dgamma=G(b + "mlp.ffn_ln.weight"), dbeta=G(b + "mlp.ffn_ln.bias"), grad_scale=inv_s, dtype=dt)
-                dx1, dx2 = dhln, _empty((M2, Hd), dt, dev)   # reuse dhln storage for dx1
+                dhln = _empty((M2, Hp), dt, dev)
+                _gemm_dx(g16, [w3], "w", dhln, k_pad=npad)
+                dhsw = _empty((M2, Hp), dt, dev)
+                ops.layernorm_bwd(dhln, a["hsw"], _padv(P(b + "mlp.ffn_ln.weight"), Hp), a["mean_f"], a["rstd_f"], dx16=dhsw,
+                                  dgamma=GP(b + "mlp.ffn_ln.weight", (Hp,)), dbeta=GP(b + "mlp.ffn_ln.bias", (Hp,)), grad_scale=inv_s,
+                                  dtype=dt, valid_cols=Hd if npad else 0)
+                dx1, dx2 = dhln, _empty((M2, Hp), dt, dev)   # reuse dhln storage for dx1
                 ops.swiglu_bwd(a["g1"], a["g2"], dhsw, dx1, dx2)
-                linear_wgrad(dx1, a["ln2"], G(b + "mlp.w1.weight"), inv_s)
-                linear_wgrad(dx2, a["ln2"], G(b + "mlp.w2.weight"), inv_s)
-                ops.colsum(dx1, G(b + "mlp.w1.bias"), scale=inv_s, accumulate=True)
-                ops.colsum(dx2, G(b + "mlp.w2.bias"), scale=inv_s, accumulate=True)
-                _gemm_dx(dx1, [w1], "w", dln2)
-                _gemm_dx(dx2, [w2], "w", dln2, accumulate=True)
-                del dhln, dhsw, dx1, dx2
+                linear_wgrad(dx1, a["ln2"], GP(b + "mlp.w1.weight", (Hp, D)), inv_s)
+                linear_wgrad(dx2, a["ln2"], GP(b + "mlp.w2.weight", (Hp, D)), inv_s)
+                ops.colsum(dx1, GP(b + "mlp.w1.bias", (Hp,)), scale=inv_s, accumulate=True)
+                ops.colsum(dx2, GP(b + "mlp.w2.bias", (Hp,)), scale=inv_s, accumulate=True)
+                _gemm_dx(dx1, [w1], "w", dln2, n_pad=npad)
+                _gemm_dx(dx2, [w2], "w", dln2, n_pad=npad, accumulate=True)
+                for tgt, tmp in pend:
+                    tgt.add_(tmp[tuple(slice(0, n) for n in tgt.shape)])
+                del dhln, dhsw, dx1, dx2, pend
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)

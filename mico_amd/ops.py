@@ -179,7 +179,7 @@ def gemm_mx8(A, B, out, *, dtype, M=None, **epi):
 
 def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
                   post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16, frame_map=None,
-                  rows_per_frame=0, x_copy=None, drop=None):
+                  rows_per_frame=0, x_copy=None, drop=None, valid_cols=0):
     """split16: out16 is [rows, 2*cols] and receives [hi | lo] (split-precision GEMM operand).  frame_map (int32 [frames]):
     compacting gather of whole frames out of x; the number of rows is then len(frame_map) * rows_per_frame."""
     rows, cols = x.shape[0], x.shape[1]
@@ -189,12 +189,12 @@ def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rst
                                        _p(rstd), rows, cols, eps, _p(post_add), post_rows_per_group, post_groups,
                                        int(split16), _p(frame_map), rows_per_frame, _p(x_copy),
                                        float(drop[0]) if drop else 0.0, (int(drop[1]) & 0xFFFFFFFF) if drop else 0,
-                                       int(drop[2]) if drop else 0, dt_code(dtype), _st())
+                                       int(drop[2]) if drop else 0, int(valid_cols), dt_code(dtype), _st())
     check(rc, "mico_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
-                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0):
+                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0):
     """frame_map: dx_add / dx32 are the full stream, addressed through the frame scatter; dy / x / mean / rstd are compact."""
     rows, cols = x.shape[0], x.shape[1]
     ws = None
@@ -203,7 +203,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=N
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=x.device)
     rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), dy_scale, _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
                                        _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
-                                       _p(ws), rows, cols, _p(frame_map), rows_per_frame, dt_code(dtype), _st())
+                                       _p(ws), rows, cols, _p(frame_map), rows_per_frame, int(valid_cols), dt_code(dtype), _st())
     check(rc, "mico_layernorm_bwd")
 
 

@@ -488,6 +488,9 @@ def main(which):
         if want("loss"):
             loss_fixture(mg, "g14_d2")
         del mg
+    if want("vitl"):     # EVA02-CLIP-L/14 (mico.py:336-340): RoPE + sub-LN + SwiGLU with the 2730-wide hidden layer (not a multiple of 8)
+        del_me = vit_fixture("evaclip02_large", 2, "l14_d2")
+        del del_me
     if want("full"):
         vit_full_fixture()
     if want("ckpt"):

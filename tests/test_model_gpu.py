@@ -56,6 +56,33 @@ def test_vit_tower(setup, cuda, dtype):
     print(f"{tag} {dtype} worst grad err {worst:.2e}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vit_tower_large(cuda, dtype):
+    """EVA02-CLIP-L/14 (mico.py:336-340): RoPE + sub-LN + SwiGLU with hidden = int(1024 * 2.6667) = 2730, which is not a multiple of 8 -
+    the engine runs it in 2752-wide zero-padded buffers (functional.TowerSpec.hidden_pad; LayerNorm statistics over the 2730 valid
+    columns).  Same gates as the other towers, against the reference's own outputs (tests/golden/vit_l14_d2.pt)."""
+    m, sd = build_model("evaclip02_large", 2, device=cuda)
+    fx = golden("vit_l14_d2.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    w = torch.randn(fx["out"].shape, generator=g) / fx["out"].numel() ** 0.5
+    m.zero_grad(set_to_none=True)
+    with runtime.precision(dtype):
+        out = m.vision_encoder.visual(x.to(cuda), return_all_features=True)
+        assert out.shape == fx["out"].shape
+        e = rel_err(out, fx["out"])
+        print(f"l14_d2 {dtype} fwd rel err {e:.2e}")
+        assert e < FWD_TOL[dtype]
+        (out * w.to(cuda)).sum().backward()
+    named = dict(m.vision_encoder.visual.named_parameters())
+    worst = 0.0
+    for n, d in fx["grads"].items():
+        ge = grad_digest_check(d, named[n].grad, None)
+        worst = max(worst, ge)
+        assert ge < GRAD_TOL[dtype], (n, ge)
+    print(f"l14_d2 {dtype} worst grad err {worst:.2e}")
+
+
 def test_bert(setup, cuda):
     vtype, tag, m, sd = setup
     if tag != "b16_d2":

@@ -110,6 +110,7 @@ def test_grad_scaler_matches_torch_semantics(cuda):
             p.grad = g * sc.get_scale()        # what scaler.scale(loss).backward() leaves in .grad
             r.grad = g.clone()
         # torch's scaler on a dummy parameter that carries the same overflow pattern: the scale trajectory to match
+        tsc.scale(torch.zeros(1, device=cuda))       # (torch's scaler creates its scale tensor lazily, at the first scale() call)
         dummy.param_groups[0]["params"][0].grad = torch.full((1,), float("inf") if step in (2, 4) else 1.0, device=cuda) * tsc.get_scale()
         tsc.step(dummy)
         tsc.update()

@@ -38,6 +38,21 @@ def test_vit_tower(setup):
         assert grad_digest_check(d, sd["vision_encoder.visual." + n].grad, TOL) < 5e-5, n
 
 
+def test_vit_tower_large():
+    """EVA02-CLIP-L/14 (mico.py:336-340; depth 2): the tower variant with the 2730-wide SwiGLU hidden layer."""
+    m, sd = build_model("evaclip02_large", 2)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    fx = golden("vit_l14_d2.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    out = O.eva_vit_forward(sd, x, O.ARCHS["evaclip02_large"])
+    assert rel_err(out, fx["out"]) < TOL
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    for n, d in fx["grads"].items():
+        assert grad_digest_check(d, sd["vision_encoder.visual." + n].grad, TOL) < 5e-5, n
+
+
 def test_bert(setup):
     vtype, tag, sd, arch = setup
     if tag != "b16_d2":
