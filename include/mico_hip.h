@@ -100,6 +100,10 @@ typedef struct mico_gemm_epilogue {
     float drop_p;
     unsigned drop_seed;
     int drop_site;
+    /* weight-gradient launches (ta = tb = 1, fp32 C) only: colsum_out[m] += alpha * sum_k A[k, m] - the bias gradient db = sum_rows dy
+     * of the layer whose dW = dy^T x this launch computes, taken from the dy panel the kernel stages anyway (the 192x256 kernel's
+     * producer waves sum the columns of tile column 0; other kernels run the stand-alone column-sum pass).  fp32 [M], accumulated. */
+    float* colsum_out;
 } mico_gemm_epilogue;
 
 /* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256

@@ -967,6 +967,32 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const T* __restrict__ x,
 // K-tile depth: 32 (4-stage ring) when both operands are reduction-major (their DMA rows are 512 bytes anyway); 64 (2 stages)
 // when an operand is k-contiguous, so that its DMA rows are whole 128-byte lines instead of 64-byte halves (fill ceiling 95-128
 // instead of 58-77 GB/s per CU, tools/probes/dma_fill.hip) - with producers the shallower ring costs the consumers nothing.
+// Column sums of one reduction-major A tile image ([32 k-rows][256 columns], key_tr swizzle) for the producer waves of the weight-gradient
+// kernel: lane = column.  The bias gradient db = sum_rows dy is the column sum of the very dy panel the dW GEMM stages for its A operand,
+// so the workgroups of tile column 0 take it along (mico_gemm_epilogue::colsum_out) instead of a separate pass over dy (2.5 % of the
+// step as `colsum_kernel`).  Inline-asm reads with their own wait: the compiler would put `vmcnt(0)` in front of an LDS read it cannot
+// tell from the DMA destinations, draining the producers' queue (tools/probes/README.md).
+template <typename T>
+__device__ __forceinline__ void tile_colsum32(float (&cs)[8], unsigned a_even, unsigned a_odd, int rg) {
+    // the 256 producer lanes = 32 chunk columns (8 matrix columns each) x 8 row groups: lane (lc, rg) reads its chunk of rows rg, rg + 8,
+    // rg + 16, rg + 24 - four 16-byte reads per K-tile instead of 32 two-byte ones (those took the dW kernel from 792 to 726 TFLOP/s) -
+    // and keeps 8 running sums; the row groups are folded when the kernel ends.  key_tr(r) depends on r & 3 (= rg & 3, fixed per lane)
+    // and on bit 3 of r, i.e. on the parity of j in r = rg + 8 j: two addresses per lane.
+    u32x4 v0, v1, v2, v3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:12288\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a_even), "v"(a_odd) : "memory");
+    (void)rg;
+    const u32x4 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float f[8];
+        unpack8<T>(__builtin_bit_cast(s16x8, vv[j]), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[k] += f[k];
+    }
+}
+
 template <int BK_> struct Wide {
     static constexpr int BM = 192, BN = 256, BK = BK_, STAGES = BK_ == 32 ? 4 : 2, MT = 6, KSTEPS = BK_ / 32;
     static constexpr int CWAVES = 8, PWAVES = 4, THREADS = (CWAVES + PWAVES) * 64, PTHREADS = PWAVES * 64;
@@ -1052,6 +1078,13 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
         };
         constexpr int AHEAD = CFG::STAGES - 1;   // K-tiles in flight
         for (int i = 0; i < AHEAD && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
+        // bias gradient riding along (tile column 0 only): this lane's column of the A image, its 8 swizzled chunk offsets
+        const bool do_colsum = TA && TB && BK == 32 && g.e.colsum_out != nullptr && tile_n == 0;
+        const int pid = pw * 64 + lane, lc = pid & 31, rg = pid >> 5;
+        // row r = rg + 8 j of the image: byte r * 512 + ((lc ^ key_tr(r)) << 4); key_tr(r) = ((r & 3) | (bit 3 of r) << 2) << 1
+        const unsigned cbase = (unsigned)(uintptr_t)lds + (unsigned)rg * 512u;
+        const unsigned cx_even = cbase + (unsigned)((lc ^ ((rg & 3) << 1)) << 4), cx_odd = cbase + (unsigned)((lc ^ (((rg & 3) | 4) << 1)) << 4);
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int bo = 0;
         for (int t = 0; t < T_; ++t) {
             asm volatile("" : "+s"(bo));
@@ -1066,6 +1099,10 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             // the buffer of tile t-1: every consumer retired its reads of it before the barrier above
             if (t + AHEAD < T_) stage(kt0 + t + AHEAD, (bo + AHEAD * CFG::STAGE_BYTES) & (RING - 1));
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TA && TB && BK == 32) {
+                if (do_colsum) tile_colsum32<T>(cs, cx_even + (unsigned)bo, cx_odd + (unsigned)bo, rg);   // tile t is published and stays until the next iteration's barrier
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 2 * CFG::KSTEPS - 1; ++r) {   // the consumers' remaining barriers of this K-tile
                 __builtin_amdgcn_s_barrier();
@@ -1074,6 +1111,14 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
         }
         __builtin_amdgcn_s_barrier();   // the consumers' end-of-loop barrier
+        if (do_colsum) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = cs[k] + __shfl_xor(cs[k], 32, 64);     // the wave's two row groups (lanes l and l + 32 share lc)
+                const int col = lc * 8 + k;
+                if (lane < 32 && col < BM && m0 + col < g.M) unsafeAtomicAdd(g.e.colsum_out + m0 + col, v * g.e.alpha);
+            }
+        }
         return;
     }
 
@@ -1609,6 +1654,7 @@ extern "C" int mico_struct_layout(int* out, int n) {
         OFF(mico_gemm_epilogue, remap_offset), OFF(mico_gemm_epilogue, alpha), OFF(mico_gemm_epilogue, accumulate), OFF(mico_gemm_epilogue, nseg),
         OFF(mico_gemm_epilogue, kseg), OFF(mico_gemm_epilogue, a_seg_off), OFF(mico_gemm_epilogue, b_seg_off), OFF(mico_gemm_epilogue, row_map),
         OFF(mico_gemm_epilogue, rows_per_map), OFF(mico_gemm_epilogue, drop_p), OFF(mico_gemm_epilogue, drop_seed), OFF(mico_gemm_epilogue, drop_site),
+        OFF(mico_gemm_epilogue, colsum_out),
         -1,
         (int)sizeof(mico_attn_params),
         OFF(mico_attn_params, B), OFF(mico_attn_params, H), OFF(mico_attn_params, Sq), OFF(mico_attn_params, Sk), OFF(mico_attn_params, hd),
@@ -1783,6 +1829,14 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (g.e.pos) MICO_CHECK(g.e.pos_rows > 0, "mico_gemm: pos_rows must be > 0");
     MICO_CHECK(g.e.drop_p >= 0.f && g.e.drop_p < 1.f, "mico_gemm: drop_p must be in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
+    if (g.e.colsum_out) {
+        MICO_CHECK(ta && tb && c_dtype == MICO_F32, "mico_gemm: colsum_out belongs to the weight-gradient orientation (ta = tb = 1, fp32 C)");
+        if (!pc || pc_bk(ta, tb) != 32) {   // not the kernel that takes it along: the stand-alone column-sum pass, same result
+            const int rc = mico_colsum(A, dtype, lda, K, (int)M, g.e.colsum_out, g.e.alpha, 1, stream);
+            if (rc != MICO_OK) return rc;
+            g.e.colsum_out = nullptr;
+        }
+    }
     g_mico_last_gemm_kernel = w4 ? 3 : pc ? 2 : (big ? 1 : 0);
 #ifdef MICO_GEMM_W4
     if (w4 && deep) DISPATCH_T16(dtype, (launch_w4<T, 1>(ta, tb, g, st)));

@@ -66,12 +66,13 @@ class GradArena:
         return tuple(self.views)
 
 
-def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None):
-    """dw[N_out, N_in] += inv_s * dy16^T x16   (reduction over the rows)."""
+def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None, dbias=None):
+    """dw[N_out, N_in] += inv_s * dy16^T x16   (reduction over the rows);  dbias[N_out] += inv_s * column sums of dy16 in the same launch
+    (the weight-gradient kernel stages the dy panel anyway; mico_gemm_epilogue::colsum_out)."""
     n_out = n_out or dw.shape[0]
     n_in = n_in or dw.shape[1]
     ops.gemm(dy16, x16, dw, ta=True, tb=True, M=n_out, N=n_in, K=dy16.shape[0], accumulate=True, alpha=inv_s,
-             split_k=0)   # 0 = let the library size the K split in whole waves of resident workgroups
+             split_k=0, colsum_out=dbias)   # 0 = let the library size the K split in whole waves of resident workgroups
 
 
 # ======================================================================================================================
@@ -425,12 +426,10 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 del dhln, dhsw, dx1, dx2, pend
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
-                linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s)
-                ops.colsum(g16, G(b + "mlp.fc2.bias"), scale=inv_s, accumulate=True)
+                linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
                 _gemm_dx(g16, [w2], "w", dh, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
-                linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s)
-                ops.colsum(dh, G(b + "mlp.fc1.bias"), scale=inv_s, accumulate=True)
+                linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
                 _gemm_dx(dh, [w1], "w", dln2)
                 del dh
             ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
@@ -445,8 +444,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             ops.gather_rows_cast(g, g16, row_scale=a["sc1"], rows_per_scale=N, scale=S, frame_map=fmap1, rows_per_frame=N)
             wp = P(b + "attn.proj.weight")
             proj_in = a["aln"] if arch["subln"] else a["ao"]
-            linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s)
-            ops.colsum(g16, G(b + "attn.proj.bias"), scale=inv_s, accumulate=True)
+            linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s, dbias=G(b + "attn.proj.bias"))
             dao = _empty((M1, D), dt, dev)
             _gemm_dx(g16, [wp], "w", dao)
             if arch["subln"]:
@@ -463,18 +461,17 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             if spec.rope is not None:
                 ops.rope(dqkv, N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
                 ops.rope(dqkv[:, D:], N * 3 * D, 3 * D, B1, N, H, hd, spec.rope[0], spec.rope[1], inverse=True)
-            dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
-            ops.colsum(dqkv, dbias, scale=inv_s)
-            G(b + "attn.q_bias").add_(dbias[:D])
-            G(b + "attn.v_bias").add_(dbias[2 * D:])
+            dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)      # filled by the qkv weight-gradient launch below
             if arch["subln"]:
                 dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
-                linear_wgrad(dqkv, a["ln1"], dwf, inv_s)
+                linear_wgrad(dqkv, a["ln1"], dwf, inv_s, dbias=dbias)
                 G(b + "attn.q_proj.weight").add_(dwf[:D])
                 G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
                 G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
             else:
-                linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s)
+                linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s, dbias=dbias)
+            G(b + "attn.q_bias").add_(dbias[:D])
+            G(b + "attn.v_bias").add_(dbias[2 * D:])
             dln1 = _empty((M1, D), torch.float32, dev)
             _gemm_dx(dqkv, _qkv_params(P, b, arch), "qkv", dln1)
             ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,

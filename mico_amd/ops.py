@@ -57,7 +57,7 @@ def pad8(n):
 
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
          row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
-         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0, drop=None):
+         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0, drop=None, colsum_out=None):
     """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
     leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
     dtype = dtype or A.dtype
@@ -89,6 +89,7 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.rows_per_map = rows_per_map
     if drop is not None:   # (p, seed, site)
         e.drop_p, e.drop_seed, e.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
+    e.colsum_out = _p(colsum_out)
     if ksegs is not None:   # (kseg, a_offsets, b_offsets)
         e.kseg, e.nseg = ksegs[0], len(ksegs[1])
         for i, (ao, bo) in enumerate(zip(ksegs[1], ksegs[2])):

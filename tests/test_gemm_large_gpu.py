@@ -92,3 +92,22 @@ def test_large_epilogues(cuda, dtype):
         ops.gemm(x2[:, :Kp], w2[:, :Kp], out, ksegs=(Kp, [0, Kp, 0], [0, 0, Kp]))
         ref = xx.double() @ ww.double().t()
         assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,n_out,n_in", [(257 * 37, 1408, 2816), (257 * 64 + 3, 1408 + 8, 1408), (700, 256, 128), (257 * 40, 200, 1408)])
+def test_weight_gradient_with_bias_colsum(cuda, dtype, rows, n_out, n_in):
+    """mico_gemm_epilogue::colsum_out: db += alpha * sum_rows dy in the launch that computes dW += alpha * dy^T x - summed by the producer
+    waves of the 192x256 kernel from the staged dy panel (large problems, incl. a ragged last K-tile, a ragged M edge and split-K) or by
+    the stand-alone pass the library falls back to (small problems) - against fp32 sums."""
+    from mico_amd import ops
+    torch.manual_seed(8)
+    dy = (0.1 * torch.randn(rows, ops.pad8(n_out), device=cuda)).to(dtype)
+    x = torch.randn(rows, n_in, device=cuda).to(dtype)
+    dw = torch.randn(n_out, n_in, device=cuda)
+    db = torch.randn(n_out, device=cuda)
+    ref_w = dw + 0.25 * (dy[:, :n_out].float().t() @ x.float())
+    ref_b = db + 0.25 * dy[:, :n_out].float().sum(0)
+    ops.gemm(dy, x, dw, ta=True, tb=True, M=n_out, N=n_in, K=rows, accumulate=True, alpha=0.25, split_k=0, colsum_out=db)
+    assert rel_err(dw, ref_w) < 2e-5 * math.sqrt(rows)
+    assert rel_err(db, ref_b) < 2e-5 * math.sqrt(rows)
