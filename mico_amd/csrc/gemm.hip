@@ -425,8 +425,6 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / CFG::WN, wn = wave % CFG::WN;
-    const int wrow = wm * (BM / CFG::WM), wcol = wn * 64;
 
     PHASE_STAMP(0);
     // ---- workgroup -> (k-split, tile) : XCD-contiguous remap (bijective), then grouped row-panel order ----
@@ -448,6 +446,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
         tile_n = in / gm;
     }
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    // Half-width edge tiles (N = 1408 = 5.5 x 256: every sixth tile of the towers' N = 1408 GEMMs): the 8 waves regroup as 4 x 2 over the
+    // valid 256 x 128 half, 64 x 64 outputs each - half the MFMAs and fragment reads per wave on all four SIMDs - instead of four waves
+    // multiplying zero-filled columns.  Same LDS images and DMA (the out-of-bounds half of the B image costs no memory traffic).
+    const bool halfn = PINGPONG && (g.N - n0) * 2 <= BN;
+    const int wm = halfn ? (wave >> 1) : wave / CFG::WN, wn = halfn ? (wave & 1) : wave % CFG::WN;
+    const int wrow = halfn ? wm * 64 : wm * (BM / CFG::WM), wcol = wn * 64;
     const int kt0 = ks * g.ktiles_per_split;
     const int kt1 = min(g.ktiles, kt0 + g.ktiles_per_split);
     const int T_ = kt1 - kt0;
@@ -503,7 +507,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
     };
 
     s16x8 fa[MT], fb[4];   // fragments of ONE 32-deep k-step
-    auto read_k = [&](int bo, int kk) {
+    auto read_k = [&](int bo, int kk, auto mtv) {
+        constexpr int MV = decltype(mtv)::value;   // 16-row tiles this wave owns (MT, or MT / 2 on a half-width edge tile)
         if (MICO_GEMM_ABLATE == 2 && g.K > 0) {   // ablation: no LDS reads (keep fragments opaque)
 #pragma unroll
             for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[i]));
@@ -515,11 +520,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
         LDS_AS const char* tb = ta + CFG::A_BYTES;
         const int abase = kk ? ab.b1 : ab.b0, bbase = kk ? bb.b1 : bb.b0;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = read_frag_b<TA, BM, BK>(ta, abase, i);
+        for (int i = 0; i < MV; ++i) fa[i] = read_frag_b<TA, BM, BK>(ta, abase, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag_b<TB, BN, BK>(tb, bbase, j);
     };
-    auto mma_k = [&]() {
+    auto mma_k = [&](auto mtv) {
+        constexpr int MV = decltype(mtv)::value;
         if (MICO_GEMM_ABLATE == 3 && g.K > 0) {   // ablation: no MFMA (keep operands live)
 #pragma unroll
             for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
@@ -528,10 +534,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
             return;
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MV; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[j], fa[i], acc[i][j]);
     };
+    using FullT = std::integral_constant<int, MT>;
+    using HalfT = std::integral_constant<int, MT / 2>;
 
     if constexpr (!PINGPONG) {
         int bo = 0;
@@ -541,8 +549,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
             if (t + 1 < T_) stage(kt0 + t + 1, bo ^ CFG::STAGE_BYTES);
 #pragma unroll
             for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-                read_k(bo, kk);
-                mma_k();
+                read_k(bo, kk, FullT{});
+                mma_k(FullT{});
             }
             bo ^= CFG::STAGE_BYTES;
         }
@@ -571,31 +579,35 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
         };
         for (int i = 0; i < 3 && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
         PHASE_STAMP(1);
-        int bo = 0;   // ring offset of tile t (kept opaque so LDS addresses are not hoisted per buffer)
-        if (grp == 0) {
-            for (int t = 0; t < T_; ++t) {
-                asm volatile("" : "+s"(bo));
-                head(t);
-                read_k(bo, 0);
-                if (t + 3 < T_) stage(kt0 + t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));   // buffer of tile t-1: free
-                bar();
-                mma_k();
-                __builtin_amdgcn_sched_barrier(0);
-                bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+        auto k_loop = [&](auto mtv) {
+            int bo = 0;   // ring offset of tile t (kept opaque so LDS addresses are not hoisted per buffer)
+            if (grp == 0) {
+                for (int t = 0; t < T_; ++t) {
+                    asm volatile("" : "+s"(bo));
+                    head(t);
+                    read_k(bo, 0, mtv);
+                    if (t + 3 < T_) stage(kt0 + t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));   // buffer of tile t-1: free
+                    bar();
+                    mma_k(mtv);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+                }
+            } else {
+                for (int t = 0; t < T_; ++t) {
+                    asm volatile("" : "+s"(bo));
+                    head(t);
+                    if (t > 0) mma_k(mtv);      // tile t-1 (fragments read in the second phase of that tile)
+                    bar();
+                    read_k(bo, 0, mtv);
+                    if (t + 3 < T_) stage(kt0 + t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
+                }
+                if (T_ > 0) mma_k(mtv);
             }
-        } else {
-            for (int t = 0; t < T_; ++t) {
-                asm volatile("" : "+s"(bo));
-                head(t);
-                if (t > 0) mma_k();      // tile t-1 (fragments read in the second phase of that tile)
-                bar();
-                read_k(bo, 0);
-                if (t + 3 < T_) stage(kt0 + t + 3, (bo + 3 * CFG::STAGE_BYTES) & (RING - 1));
-                __builtin_amdgcn_sched_barrier(0);
-                bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
-            }
-            if (T_ > 0) mma_k();
-        }
+        };
+        if (halfn) k_loop(HalfT{});
+        else k_loop(FullT{});
     }
 
     PHASE_STAMP(2);
@@ -609,12 +621,14 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
     }
     if (g.split_k > 1) {   // split-K partials carry no bias / activation / residual (checked on the host side)
 #pragma unroll
-        for (int h = 0; h < MT / 4; ++h) gemm_epilogue_atomic(g, &acc[h * 4], m0 + wrow + h * 64, n0 + wcol, lane);
+        for (int h = 0; h < MT / 4; ++h)
+            if (h == 0 || !halfn) gemm_epilogue_atomic(g, &acc[h * 4], m0 + wrow + h * 64, n0 + wcol, lane);
     } else {
         __syncthreads();   // every wave is done with the operand tiles (and the DMA queue is empty) before LDS is reused
         PHASE_STAMP(4);
 #pragma unroll
         for (int h = 0; h < MT / 4; ++h) {
+            if (h > 0 && halfn) break;
             gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
             if (h == 0) PHASE_STAMP(5);
         }
