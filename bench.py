@@ -47,11 +47,16 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROAR
 PRECISIONS = {   # --dtype -> (torch dtype, split_fp16, split_mode, description)
     "fp8": ("bfloat16", False, "full", "block-scaled MX fp8 (e4m3, E8M0 per 32) MFMA for the forward and input-gradient GEMMs of the towers and "
                                        "BERT's large projections; weight gradients, attention and everything else as bf16"),
-    "fp16": ("float16", False, "full", "fp16 MFMA operands (plain), fp32 accumulate / residual stream / LN / softmax"),
+    "fp16": ("float16", False, "full", "fp16 MFMA operands, fp32 accumulate / residual stream / LN / softmax; forward GEMMs of the first 4 of the "
+                                       "40 tower blocks as x W_hi + x W_lo (runtime.CFG.head_split_blocks)"),
+    "fp16-plain": ("float16", False, "full", "fp16 MFMA operands (plain everywhere), fp32 accumulate / residual stream / LN / softmax"),
     "bf16": ("bfloat16", False, "full", "bf16 MFMA operands, fp32 accumulate / residual stream / LN / softmax"),
     "fp16-split-w": ("float16", True, "weights", "fp16 MFMA, forward GEMMs x W_hi + x W_lo (weights hi/lo split, 2 k-segments)"),
     "fp16-split": ("float16", True, "full", "fp16 MFMA, forward GEMMs x_hi W_hi + x_lo W_hi + x_hi W_lo (3 k-segments)"),
 }
+
+
+HEAD_SPLIT_BLOCKS = 4
 
 
 def parse():
@@ -181,6 +186,7 @@ def set_precision(name):
     runtime.set_compute_dtype(getattr(torch, dt))
     runtime.CFG.split_fp16, runtime.CFG.split_mode = split, mode
     runtime.CFG.fp8 = name == "fp8"
+    runtime.CFG.head_split_blocks = HEAD_SPLIT_BLOCKS if name == "fp16" else 0
     runtime.clear_weight_cache()
 
 
@@ -460,7 +466,21 @@ def main():
         el2, _ = timed_steps(k2)
         res["parity_config"] = dict(precision=PRECISIONS[pc][3], value=b * k2 / el2, unit="samples/s", steps=k2, warmup=1,
                                     ms_per_step=el2 / k2 * 1e3, **{"parity": measure_parity(model, dev)})
+        # ---- other precisions of the same step, for orientation (not gated configurations unless their parity says so) ----
+        others = {}
+        for oc in ("fp16-plain", "fp8"):
+            if oc == args.dtype:
+                continue
+            try:
+                set_precision(oc)
+                step()
+                elo, _ = timed_steps(k2)
+                others[oc] = dict(precision=PRECISIONS[oc][3], value=b * k2 / elo, unit="samples/s", steps=k2, warmup=1, ms_per_step=elo / k2 * 1e3,
+                                  parity=measure_parity(model, dev))
+            except Exception as e:
+                others[oc] = {"error": repr(e)}
         set_precision(args.dtype)
+        res["other_precisions"] = others
         # ---- secondary: one rank's share of BASELINE configs[3] (14 frames per sample: image + 8 video frames + depth + 4 audio windows) ----
         try:
             wo = WORKLOADS["omni"]

@@ -223,6 +223,9 @@ class DropPlan:
         return sum(self.counts) / float(len(self.counts) * self.n_frames)
 
 
+_TAIL_EXP = None   # experiment hook (tools/precision_probe.py --tail)
+
+
 def _tower_forward(spec, groups, dp_scale, params, save):
     """One pass of the tower over the frames in `groups`.  save=False keeps nothing for a backward (chunked forward)."""
     dt = runtime.compute_dtype()
@@ -262,9 +265,14 @@ def _tower_forward(spec, groups, dp_scale, params, save):
 
     acts = []
     Hd = spec.hidden
+    pstate = runtime.snapshot()   # per-block precision: runtime.enter_block; the callers restore the pass-wide state
     for i in range(depth):
         b = f"blocks.{i}."
         a = {}
+        runtime.enter_block(i, pstate)
+        if _TAIL_EXP is not None:
+            runtime.CFG.split_fp16 = (i >= depth - _TAIL_EXP[0]) if _TAIL_EXP[0] >= 0 else (i < -_TAIL_EXP[0])
+            runtime.CFG.split_mode = _TAIL_EXP[1]
         # --- attention branch: x <- x + s1 * proj(attn(LN1 x)) on the kept frames ---
         B1, fmap1, sc1 = branch_io(i, 0)
         a.update(B1=B1, fmap1=fmap1, sc1=sc1)
@@ -341,6 +349,7 @@ def _tower_forward(spec, groups, dp_scale, params, save):
         if save:
             acts.append(a)
         del a
+    runtime.restore(pstate)
     out = _empty((M, D), torch.float32, dev)
     mean_n, rstd_n = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
     ops.layernorm_fwd(x, P("norm.weight"), P("norm.bias"), spec.eps, out32=out, mean=mean_n, rstd=rstd_n, dtype=dt)
@@ -380,9 +389,11 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
     saved["final"] = None
     del x_last
     Hd = spec.hidden
+    pstate = runtime.snapshot()
     for i in reversed(range(arch["depth_built"])):
         b = f"blocks.{i}."
         a = saved["acts"].pop()
+        runtime.enter_block(i, pstate)   # the block's weights in the layout its forward used
         # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
         if a["B2"] > 0:
             M2, fmap2 = a["B2"] * N, a["fmap2"]
@@ -482,6 +493,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
         if hook is not None:      # every gradient of block i is final: its arena slice can be reduced now
             i0, i1 = block_range[i]
             hook(grads.span(i0, i1), params[i0:i1])
+    runtime.restore(pstate)
     # ---------------- patch embedding ----------------
     dpos = torch.zeros(N * D, dtype=torch.float32, device=dev)
     ops.colsum(g, dpos, rows=Bf, cols=N * D, ld=N * D)
@@ -547,6 +559,11 @@ class EvaTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, groups, dp_scale, *params):
         runtime.remember_precision(ctx)
+        with runtime.using(runtime.snapshot()):   # the block loop switches the state per block (runtime.enter_block)
+            return EvaTowerFn._forward(ctx, spec, groups, dp_scale, *params)
+
+    @staticmethod
+    def _forward(ctx, spec, groups, dp_scale, *params):
         Bf = sum(g.shape[0] for g in groups)
         needs_grad = any(ctx.needs_input_grad)    # False under torch.no_grad(): nothing is kept for a backward then
         chunk = tower_chunk_frames(spec, Bf, params[0].device) if needs_grad else Bf

@@ -24,6 +24,8 @@ class _Cfg:
     # what is split when split_fp16 is on: "full" = weights AND LayerNorm outputs (3 k-segments, x_hi W_hi + x_lo W_hi + x_hi W_lo),
     # "weights" = weights only (2 k-segments, x W_hi + x W_lo: removes the weight-rounding half of the error at 2x the MFMA work)
     split_mode = "full"
+    head_split_blocks = 0     # plain fp16 only: the first n tower blocks in a split mode (see enter_block)
+    head_split_mode = "weights"
     # BASELINE.json configs[4] ("fp8 MFMA"): the ViT towers' and BERT's forward and input-gradient GEMMs run on the block-scaled fp8 MFMA
     # (OCP MX e4m3, one E8M0 scale per 32 reduction elements; mico_gemm_mx8) - weight gradients, attention, LayerNorm, the residual stream
     # and every loss stay as in the 16-bit configuration of compute_dtype.  Off by default (the 16-bit path is the parity path).
@@ -60,7 +62,11 @@ def precision(dtype):
 
 def snapshot():
     """The precision state a forward pass ran under; see using()."""
-    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8)
+    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8, CFG.head_split_blocks)
+
+
+def restore(state):
+    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8, CFG.head_split_blocks = state
 
 
 @contextlib.contextmanager
@@ -69,11 +75,24 @@ def using(state):
     so the backward must take its weights, its gradient scale and its split mode from the same state even when it runs outside the
     `with precision(...)` block the forward ran in (fp16 activations were otherwise multiplied by bf16-bit weights)."""
     old = snapshot()
-    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8 = state
+    restore(state)
     try:
         yield
     finally:
-        CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8 = old
+        restore(old)
+
+
+def enter_block(i, base):
+    """Precision state of tower block i under the pass-wide state `base` (a snapshot()): with CFG.head_split_blocks = n the first n
+    blocks of a plain-fp16 tower run their forward GEMMs as x W_hi + x W_lo (the weights-split mode).  Rounding errors made in the
+    first blocks pass through every later block; on the 40-block g/14 golden four such blocks take plain fp16 from 7.1e-4 / 1.0e-3
+    (token rows / feat_v) to 7.4e-4 / 7.5e-4 for +2 % step time, where the same four blocks at the END of the tower change nothing
+    (tools/precision_probe.py --tail).  The tower loops call this at the top of every block and restore(base) when they leave."""
+    dt, split, mode, fp8, n = base
+    if n and i < n and dt == torch.float16 and not split and not fp8:
+        restore((dt, True, CFG.head_split_mode, False, n))
+    else:
+        restore(base)
 
 
 def saved_precision(backward):

@@ -22,6 +22,7 @@ CONFIGS = [("fp16 split=full", torch.float16, True, "full"), ("fp16 split=weight
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--tail", default="", help="experiment: comma list of n:mode - split only the last n (first -n) blocks of the full g/14 tower")
     a = ap.parse_args()
     cuda = torch.device("cuda:0")
     for vtype, tag in (("evaclip02_base", "b16_d2"), ("evaclip01_giant", "g14_d2")):
@@ -56,6 +57,17 @@ def main():
                 feat = l2_normalize(m.contra_head_v(m.pool_vision_for_contra(out)))
             e_rows = ((out[0, 0, [0, 1, 128, 256]].float().cpu() - fx["rows"]).abs().max() / fx["amax"]).item()
             print(f"g14_full {name:20s} token rows {e_rows:.2e}   feat_v {rel_err(feat, fx['feat_v']):.2e}", flush=True)
+        from mico_amd import functional as Fn
+        for item in [t for t in a.tail.split(",") if t]:
+            n, mode = item.split(":")
+            Fn._TAIL_EXP = (int(n), mode)
+            runtime.clear_weight_cache()
+            with runtime.precision(torch.float16), torch.no_grad():
+                out = m.forward_vision_encoder(x)
+                feat = l2_normalize(m.contra_head_v(m.pool_vision_for_contra(out)))
+            Fn._TAIL_EXP = None
+            e_rows = ((out[0, 0, [0, 1, 128, 256]].float().cpu() - fx["rows"]).abs().max() / fx["amax"]).item()
+            print(f"g14_full tail {item:12s} token rows {e_rows:.2e}   feat_v {rel_err(feat, fx['feat_v']):.2e}", flush=True)
     runtime.CFG.split_fp16, runtime.CFG.split_mode = True, "full"
 
 
