@@ -56,6 +56,35 @@ def test_vit_tower(setup, cuda, dtype):
     print(f"{tag} {dtype} worst grad err {worst:.2e}")
 
 
+@pytest.mark.parametrize("chunk", [None, 1])
+def test_vit_tower_head_split(setup, cuda, chunk):
+    """bench.py's timed precision: plain fp16 with the first blocks' forward GEMMs weights-split (runtime.CFG.head_split_blocks; here block 0
+    split, block 1 plain) - forward and parameter gradients against the reference goldens, also through the chunked-recompute path (the
+    recomputed forward and the backward must pick the same per-block weight layouts)."""
+    vtype, tag, m, sd = setup
+    fx = golden(f"vit_{tag}.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    w = torch.randn(fx["out"].shape, generator=g) / fx["out"].numel() ** 0.5
+    m.zero_grad(set_to_none=True)
+    old = runtime.snapshot()
+    try:
+        runtime.CFG.split_fp16, runtime.CFG.head_split_blocks = False, 1
+        runtime.set_tower_chunk(chunk)
+        with runtime.precision(torch.float16):
+            out = m.vision_encoder.visual(x.to(cuda), return_all_features=True)
+            assert runtime.snapshot()[1:] == (False, old[2], old[3], 1)      # the per-block state does not leak out of the tower
+            e = rel_err(out, fx["out"])
+            (out * w.to(cuda)).sum().backward()
+    finally:
+        runtime.set_tower_chunk(None)
+        runtime.restore(old)
+    named = dict(m.vision_encoder.visual.named_parameters())
+    worst = max(grad_digest_check(d, named[n].grad, None) for n, d in fx["grads"].items())
+    print(f"{tag} head-split fwd rel err {e:.2e} worst grad err {worst:.2e}")
+    assert e < 1.3e-3 and worst < GRAD_TOL[torch.float16]      # depth-2 towers in plain fp16: 0.6-1.2e-3 (B/16 is the noisier one)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_vit_tower_large(cuda, dtype):
     """EVA02-CLIP-L/14 (mico.py:336-340): RoPE + sub-LN + SwiGLU with hidden = int(1024 * 2.6667) = 2730, which is not a multiple of 8 -
