@@ -347,6 +347,26 @@ int mico_adamw_step(const mico_adamw_tensor* tensors, int n_tensors, const int* 
 int mico_grads_finite(const mico_adamw_tensor* tensors, int n_tensors, const int* chunk_tensor, const int64_t* chunk_start,
                       int nchunks, int chunk_elems, float* flag, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Swin tower pieces (model/swin.py).  Everything else of the tower runs on the entry points above (patch
+ * embedding = mico_im2row + mico_gemm, LayerNorm, qkv / proj / MLP GEMMs with their epilogues).
+ *  mico_win_attn_fwd / _bwd: (shifted-)window multi-head self-attention, 7x7 windows, head dim 32 (Swin-T/S/B/L), replacing the chain
+ *     roll -> window_partition -> WindowAttention core -> window_reverse -> roll of swin.py:258-289 + :134-152 without any permuted copy:
+ *     qkv [batch*res*res, 3*heads*32] is the qkv Linear's output in token order (q | k | v, head-major), out / dout [batch*res*res, heads*32]
+ *     in the same token order; scores = scale * q k^T + bias_table[rel_index, head] (+ the -100 shifted-window mask of :232-253, computed
+ *     from the geometry when shift > 0); lse [batch*res*res, heads] fp32 is the softmax log-sum-exp the backward reuses.
+ *     Backward writes dqkv completely (same layout and gradient scale as dout) and ADDS dbias_scale * dS, binned by relative position,
+ *     to dbias_table [169, heads] (fp32, caller zero-fills).  res must be a multiple of 7; shift = 0 when res == 7 (swin.py:206-209).
+ *  mico_patch_merge: the 2x2 neighbourhood gather of PatchMerging (swin.py:340-346) on the fp32 stream:
+ *     out[b, (y, x), q*C + c] = in[b, (2y + (q & 1), 2x + (q >> 1)), c]; backward = 1 runs the map in reverse (in = merged gradient,
+ *     out = token-grid gradient; the map is a bijection, so no accumulation).  channels % 4 == 0.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mico_win_attn_fwd(const void* qkv, void* out, float* lse, const float* bias_table, int batch, int res, int heads, int shift,
+                      float scale, int dtype, void* stream);
+int mico_win_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* bias_table, void* dqkv, float* dbias_table,
+                      int batch, int res, int heads, int shift, float scale, float dbias_scale, int dtype, void* stream);
+int mico_patch_merge(const float* in, float* out, int batch, int res, int channels, int backward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,9 @@ PROTOTYPES = {
     "mico_bert_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp],
     "mico_embed_scatter_add": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_f, c_vp],
     "mico_itm_sample": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "mico_win_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
+    "mico_win_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_f, c_int, c_vp],
+    "mico_patch_merge": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "mico_ce_fwd_bwd": [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_int, c_i64,
                         c_vp, c_f, c_int, c_vp],
     "mico_sgemm_small": [c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f, c_f, c_vp, c_vp],

@@ -259,7 +259,8 @@ void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, con
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else if (cols <= 2048) LNB(8);
-    else LNB(11);
+    else if (cols <= 2816) LNB(11);
+    else LNB(12);   // 3072 = the 4C of Swin-L's last PatchMerging norm (only user)
 #undef LNB
 }
 
@@ -302,7 +303,7 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     if (rows <= 0) return MICO_OK;
     if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_bwd: frame_map needs rows_per_frame > 0");
     MICO_CHECK(dy && x && gamma && mean && rstd, "mico_layernorm_bwd: null pointer");
-    MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 2816, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 2816 (got %d)", cols);
+    MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 3072, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 3072 (got %d)", cols);
     MICO_CHECK((dy_dtype == MICO_F32 || dy_dtype == dtype) && (x_dtype == MICO_F32 || x_dtype == dtype), "mico_layernorm_bwd: bad in dtype");
     MICO_CHECK(!(dgamma || dbeta) || ws, "mico_layernorm_bwd: dgamma/dbeta need a workspace");
     if (rows <= 0) return MICO_OK;

@@ -769,6 +769,13 @@ def cls_pool(tokens):
     return _ClsPool.apply(tokens)
 
 
+def mean_pool(tokens):
+    """feature.mean(2).mean(1) - the Swin branch of pool_*_for_contra (mico.py:161-163): every frame has the same token count, so the mean of
+    the per-frame means is the mean over all n * N token rows, which the CLS-pool kernel computes when each token is its own 'frame'."""
+    b, n, N, D = tokens.shape
+    return _ClsPool.apply(tokens.reshape(b, n * N, 1, D))
+
+
 # ======================================================================================================================
 # condition packing: Linear(Dv -> 768) + LN(1e-12) + frame embedding + type embedding   (mico.py:187-243, 400-403)
 # ======================================================================================================================

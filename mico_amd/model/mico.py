@@ -120,8 +120,24 @@ class MMGeneralModule(nn.Module):
         t = self.config.vision_encoder_type
         if t.startswith("evaclip"):
             self.load_clip_model()
-        else:   # clip_* needs jit weights at absolute paths, swin/videoswin loaders are undefined in the reference's model/
+        elif t.startswith("swin"):
+            self.load_swin_model()
+        else:   # clip_* needs jit weights at absolute paths, the videoswin loader is undefined in the reference's model/
             raise NotImplementedError(f"vision_encoder_type {t!r} is not supported on the MI355X path")
+
+    def load_swin_model(self):
+        """mico.py:85-86 calls this, but the reference defines it only in the VAST sibling (data/model/general_module.py:528-578): the Swin-B /
+        Swin-L 22k-224 towers of model/swin.py, built from the shape constants of their yaml files (pretrained weights are loaded by
+        name through load_state_dict like every other checkpoint here)."""
+        from .swin import SWIN_CONFIGS, SwinTransformer
+        t = self.config.vision_encoder_type
+        key = next((k for k in SWIN_CONFIGS if t.startswith(k)), None)
+        if key is None:
+            raise NotImplementedError(t)
+        c = SWIN_CONFIGS[key]
+        self.vision_encoder = SwinTransformer(img_size=self.config.vision_resolution, patch_size=4, in_chans=3, embed_dim=c["embed_dim"],
+                                              depths=c["depths"], num_heads=c["num_heads"], window_size=7, drop_path_rate=c["drop_path_rate"])
+        self.vision_dim = self.vision_encoder.num_features
 
     def load_clip_model(self):
         t = self.config.vision_encoder_type
@@ -149,6 +165,9 @@ class MMGeneralModule(nn.Module):
     # ---- encoders (mico.py:115-155) ----
     def forward_vision_encoder(self, vision_pixels):
         b, n, _, h, w = vision_pixels.shape
+        if self.config.vision_encoder_type.startswith("swin"):      # mico.py:124-126
+            out = self.vision_encoder(vision_pixels.reshape(b * n, 3, h, w))
+            return out.reshape(b, -1, *out.shape[-2:])
         if not self.config.vision_encoder_type.startswith("evaclip"):
             raise NotImplementedError()
         out = self.vision_encoder.visual(vision_pixels.reshape(b * n, 3, h, w), return_all_features=True)
@@ -158,6 +177,8 @@ class MMGeneralModule(nn.Module):
         # reference: unsqueeze(2).repeat(1,1,3,1,1) then the vision tower (mico.py:139-143); here the single channel meets
         # channel-summed patch weights - algebraically identical, no 3x copy.
         b, n, h, w = audio_spectrograms.shape
+        if self.config.vision_encoder_type.startswith("swin"):      # the reference's own route: 3 identical channels (mico.py:139-140)
+            return self.forward_vision_encoder(audio_spectrograms.unsqueeze(2).repeat(1, 1, 3, 1, 1))
         out = self.vision_encoder.visual.forward_groups([audio_spectrograms.reshape(b * n, 1, h, w)])
         return out.reshape(b, n, *out.shape[-2:])
 
@@ -171,6 +192,8 @@ class MMGeneralModule(nn.Module):
 
     # ---- pooling (mico.py:157-185) ----
     def pool_vision_for_contra(self, feature):
+        if self.config.vision_encoder_type.startswith("swin"):      # no CLS token: token mean, then frame mean (mico.py:161-163)
+            return Fn.mean_pool(feature)
         return Fn.cls_pool(feature)
 
     pool_audio_for_contra = pool_vision_for_contra

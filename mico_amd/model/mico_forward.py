@@ -53,13 +53,18 @@ def encode_batch(self, batch):
         dps = (batch.get("_injected") or {}).get("drop_path_scale")
         if dps is not None:
             dps = torch.cat([dps[m].float().cpu() for m, _, _ in meta], dim=-1)
-        tokens = self.vision_encoder.visual.forward_groups(groups, drop_path_scale=dps)
+        if self.config.vision_encoder_type.startswith("swin"):
+            # one tower pass as well; spectrograms take the reference's route of three identical channels (mico.py:139-140)
+            frames = torch.cat([g.expand(-1, 3, -1, -1) if g.shape[1] == 1 else g for g in groups], dim=0)
+            tokens = self.vision_encoder.forward_features(frames, drop_path_scale=dps)
+        else:
+            tokens = self.vision_encoder.visual.forward_groups(groups, drop_path_scale=dps)
         f0 = 0
         for m, b, n in meta:
             o = tokens[f0:f0 + b * n].view(b, n, *tokens.shape[-2:])
             f0 += b * n
             enc["output_" + m] = o
-            enc["pooled_" + m] = Fn.cls_pool(o)
+            enc["pooled_" + m] = self.pool_vision_for_contra(o)
             enc["condition_feats_" + m] = self._pack(COND_MODALITY[m], o)
     if "subtitle_ids" in batch or "raw_subtitles" in batch:   # vast.py:96-104,168-174: subtitles through the text BERT
         if "subtitle_ids" not in batch:

@@ -355,6 +355,23 @@ def itm_sample(sim, diag_offset, u):
     return out
 
 
+def win_attn_fwd(qkv, out, lse, bias_table, batch, res, heads, shift, scale):
+    """Swin (shifted-)window attention in token order; see mico_win_attn_fwd."""
+    check(_lib.lib().mico_win_attn_fwd(_p(qkv), _p(out), _p(lse), _p(bias_table), batch, res, heads, shift, float(scale), dt_code(qkv.dtype),
+                                       _st()), "mico_win_attn_fwd")
+
+
+def win_attn_bwd(qkv, dout, lse, bias_table, dqkv, dbias_table, batch, res, heads, shift, scale, dbias_scale=1.0):
+    check(_lib.lib().mico_win_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(bias_table), _p(dqkv), _p(dbias_table), batch, res, heads, shift,
+                                       float(scale), float(dbias_scale), dt_code(qkv.dtype), _st()), "mico_win_attn_bwd")
+
+
+def patch_merge(x, out, batch, res, channels, backward=False):
+    """PatchMerging's 2x2 gather on the fp32 stream ([batch, res*res, C] -> [batch, res*res/4, 4C]) or its inverse (backward)."""
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    check(_lib.lib().mico_patch_merge(_p(x), _p(out), batch, res, channels, int(bool(backward)), _st()), "mico_patch_merge")
+
+
 def l2norm_fwd(x, y, inv_norm):
     check(_lib.lib().mico_l2norm_fwd(_p(x), _p(y), _p(inv_norm), x.shape[0], x.shape[1], _st()), "mico_l2norm_fwd")
 

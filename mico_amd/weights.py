@@ -22,7 +22,7 @@ def synth_tensor(name, shape, seed=0):
     return 0.02 * torch.randn(shape, generator=g)
 
 
-SKIP_SUFFIXES = ("position_ids", "freqs_cos", "freqs_sin")
+SKIP_SUFFIXES = ("position_ids", "freqs_cos", "freqs_sin", "relative_position_index", "attn_mask")
 
 
 def synth_state_dict(shapes, seed=0, tie_lm_head=True):

@@ -30,9 +30,10 @@ def fill(model, seed=0):
     sd = synth_state_dict(shapes, seed)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     # transformers==4.31 ties the LM decoder to the word embeddings (model/bert.py:1038-1041); 5.x does not -> tie here
-    me = model.multimodal_encoder
-    me.cls.predictions.decoder.weight = me.bert.embeddings.word_embeddings.weight
-    me.cls.predictions.decoder.bias = me.cls.predictions.bias
+    if hasattr(model, "multimodal_encoder"):
+        me = model.multimodal_encoder
+        me.cls.predictions.decoder.weight = me.bert.embeddings.word_embeddings.weight
+        me.cls.predictions.decoder.bias = me.cls.predictions.bias
     return sd
 
 
@@ -460,6 +461,39 @@ def subtitle_fixture():
     print("wrote subtitle_b16.pt")
 
 
+def swin_fixture():
+    """Reference model/swin.py SwinTransformer (the options data/model/general_module.py:559-576 passes) at fixture size: embed_dim 64,
+    depths 2-2-2-2, heads 2-4-8-16 (head dim 32 and 7x7 windows as in Swin-B / Swin-L; both the plain and the shifted-window block of
+    every stage, all three PatchMerging layers).  Output tokens, per-stage taps, gradient digests."""
+    ns = ref_import.load()
+    with ns.cwd():
+        import model.swin as ref_swin
+    torch.manual_seed(0)
+    m = ref_swin.SwinTransformer(img_size=224, patch_size=4, in_chans=3, num_classes=0, embed_dim=64, depths=[2, 2, 2, 2],
+                                 num_heads=[2, 4, 8, 16], window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                                 drop_path_rate=0.0, ape=False, norm_layer=torch.nn.LayerNorm, patch_norm=True, use_checkpoint=False,
+                                 fused_window_process=False).eval()
+    fill(m)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    taps = []
+    hooks = [layer.register_forward_hook(lambda mod, i, o: taps.append(o.detach())) for layer in m.layers]
+    for p in m.parameters():
+        p.requires_grad_(True)
+    out = m(x)
+    for h in hooks:
+        h.remove()
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    named = dict(m.named_parameters())
+    fx = dict(out=out.detach().clone(), tap_mean=torch.stack([t.mean() for t in taps]), tap_amax=torch.stack([t.abs().max() for t in taps]),
+              tap_rows=[t[:, [0, 1, 17]].clone() for t in taps],
+              grads={n: grad_digest(p.grad) for n, p in named.items() if p.grad is not None},
+              meta=dict(arch="swin_tiny_test", input_seed=77))
+    torch.save(fx, os.path.join(OUT, "swin_tiny.pt"))
+    print("wrote swin_tiny.pt", tuple(out.shape), float(out.abs().max()), len(fx["grads"]), "gradient digests")
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -491,6 +525,8 @@ def main(which):
     if want("vitl"):     # EVA02-CLIP-L/14 (mico.py:336-340): RoPE + sub-LN + SwiGLU with the 2730-wide hidden layer (not a multiple of 8)
         del_me = vit_fixture("evaclip02_large", 2, "l14_d2")
         del del_me
+    if want("swin"):
+        swin_fixture()
     if want("full"):
         vit_full_fixture()
     if want("ckpt"):

@@ -155,6 +155,114 @@ def eva_vit_forward(sd, x, arch, pre="vision_encoder.visual.", drop_path_scale=N
 
 
 # --------------------------------------------------------------------------------------------------------------
+# Swin tower (model/swin.py; reachable only through data/model/general_module.py:528-578 - SURVEY.md section 8 row f4b)
+# --------------------------------------------------------------------------------------------------------------
+SWIN_ARCHS = {   # swin_{base,large}_patch4_window7_224_22k.yaml shape constants; swin_tiny_test is the fixture-sized variant
+    "swin_base_22k_224": dict(embed_dim=128, depths=[2, 2, 18, 2], heads=[4, 8, 16, 32]),
+    "swin_large_22k_224": dict(embed_dim=192, depths=[2, 2, 18, 2], heads=[6, 12, 24, 48]),
+    "swin_tiny_test": dict(embed_dim=64, depths=[2, 2, 2, 2], heads=[2, 4, 8, 16]),
+}
+SWIN_EPS = 1e-5   # nn.LayerNorm default (swin.py:513)
+
+
+def swin_window_partition(x, ws):
+    """swin.py:45-57: [B, H, W, C] -> [B * nW, ws, ws, C]"""
+    B, H, W, C = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, C)
+
+
+def swin_window_reverse(w, ws, H, W):
+    """swin.py:60-74"""
+    B = w.shape[0] // ((H // ws) * (W // ws))
+    return w.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+def swin_shift_mask(res, ws, shift):
+    """swin.py:232-253: region ids painted on the rolled grid, -100 between different regions inside a window"""
+    img = torch.zeros((1, res, res, 1))
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = swin_window_partition(img, ws).view(-1, ws * ws)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+
+
+def swin_rel_index(ws):
+    """swin.py:104-114"""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swin_block(sd, p, x, res, heads, shift, ws=7, scale1=None, scale2=None):
+    """SwinTransformerBlock.forward (swin.py:255-294) with WindowAttention.forward (:125-156) and Mlp (:36-42), eval mode.
+    scale1 / scale2: optional per-sample [B] multipliers standing in for DropPath's train-mode draw."""
+    B, L, C = x.shape
+    h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], SWIN_EPS).view(B, res, res, C)
+    if shift > 0:
+        h = torch.roll(h, shifts=(-shift, -shift), dims=(1, 2))
+    xw = swin_window_partition(h, ws).view(-1, ws * ws, C)
+    Bw, N = xw.shape[0], ws * ws
+    qkv = F.linear(xw, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(Bw, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (C // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    bias = sd[p + "attn.relative_position_bias_table"][swin_rel_index(ws).view(-1)].view(N, N, -1).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if shift > 0:
+        mask = swin_shift_mask(res, ws, shift)
+        nW = mask.shape[0]
+        attn = (attn.view(Bw // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    attn = attn.softmax(dim=-1)
+    a = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
+    a = F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]).view(-1, ws, ws, C)
+    a = swin_window_reverse(a, ws, res, res)
+    if shift > 0:
+        a = torch.roll(a, shifts=(shift, shift), dims=(1, 2))
+    a = a.view(B, L, C)
+    if scale1 is not None:
+        a = a * scale1.view(B, 1, 1)
+    x = x + a
+    m = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], SWIN_EPS)
+    m = F.linear(gelu(F.linear(m, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    if scale2 is not None:
+        m = m * scale2.view(B, 1, 1)
+    return x + m
+
+
+def swin_forward(sd, x, arch, pre="vision_encoder.", drop_path_scale=None, taps=None, ws=7):
+    """SwinTransformer.forward_features (swin.py:588-600): PatchEmbed (:467-475, conv 4x4 / 4 + LayerNorm), the stages
+    (BasicLayer.forward :415-423: blocks, then PatchMerging :331-352), final LayerNorm.  Returns [B, 49, 8 * embed_dim]."""
+    B = x.shape[0]
+    t = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"], stride=4).flatten(2).transpose(1, 2)
+    if (pre + "patch_embed.norm.weight") in sd:
+        t = layer_norm(t, sd[pre + "patch_embed.norm.weight"], sd[pre + "patch_embed.norm.bias"], SWIN_EPS)
+    res = x.shape[-1] // 4
+    bi = 0
+    for s, (depth, heads) in enumerate(zip(arch["depths"], arch["heads"])):
+        for j in range(depth):
+            shift = ws // 2 if (j % 2 == 1 and res > ws) else 0       # swin.py:403, :206-209
+            sc = drop_path_scale[bi] if drop_path_scale is not None else (None, None)
+            t = swin_block(sd, pre + f"layers.{s}.blocks.{j}.", t, res, heads, shift, ws, sc[0], sc[1])
+            bi += 1
+        if taps is not None:
+            taps.append(t)
+        d = pre + f"layers.{s}.downsample."
+        if (d + "reduction.weight") in sd:
+            C = t.shape[-1]
+            g = t.view(B, res, res, C)
+            g = torch.cat([g[:, 0::2, 0::2], g[:, 1::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
+            t = F.linear(layer_norm(g, sd[d + "norm.weight"], sd[d + "norm.bias"], SWIN_EPS), sd[d + "reduction.weight"])
+            res //= 2
+    return layer_norm(t, sd[pre + "norm.weight"], sd[pre + "norm.bias"], SWIN_EPS)
+
+
+# --------------------------------------------------------------------------------------------------------------
 # BERT with cross-attention
 # --------------------------------------------------------------------------------------------------------------
 def extended_mask(attention_mask):

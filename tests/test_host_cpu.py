@@ -158,8 +158,9 @@ def test_modify_checkpoint_remap_and_interpolation():
 
 def test_unknown_encoder_type_raises():
     from mico_amd.model import MiCo, default_cfg
-    with pytest.raises(NotImplementedError):
-        MiCo(default_cfg("swin_base_22k_224"))
+    for t in ("videoswin_base_k600_22k", "clip_vit_base_16", "evaclip02_bige", "swin_small_1k"):   # mico.py:83-90 accepts none of these here
+        with pytest.raises(NotImplementedError):
+            MiCo(default_cfg(t))
 
 
 def test_frame_embedding_nearest_index_matches_interpolate():

@@ -53,6 +53,42 @@ def test_vit_tower_large():
         assert grad_digest_check(d, sd["vision_encoder.visual." + n].grad, TOL) < 5e-5, n
 
 
+def swin_state_dict():
+    """the synthetic weights of the fixture-sized Swin tower under the reference's own (prefix-free) SwinTransformer keys"""
+    from mico_amd.model.swin import SWIN_CONFIGS, SwinTransformer
+    from mico_amd.weights import synth_state_dict
+    c = SWIN_CONFIGS["swin_tiny_test"]
+    m = SwinTransformer(embed_dim=c["embed_dim"], depths=c["depths"], num_heads=c["num_heads"], drop_path_rate=0.0)
+    return m, synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+
+
+def test_swin_tower():
+    """model/swin.py SwinTransformer (row f4b) at fixture size: the oracle's restatement against the reference's own output, per-stage
+    taps and all 119 parameter-gradient digests (tests/golden/swin_tiny.pt)."""
+    m, sd = swin_state_dict()
+    # the product module's buffers are its own arithmetic: they must equal what the reference computes with its loops
+    for name, buf in m.named_buffers():
+        if name.endswith("relative_position_index"):
+            assert torch.equal(buf, O.swin_rel_index(7))
+        elif name.endswith("attn_mask") and buf is not None:
+            res = {0: 56, 1: 28, 2: 14}[int(name.split(".")[1])]
+            assert torch.equal(buf, O.swin_shift_mask(res, 7, 3)), name
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    fx = golden("swin_tiny.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    taps = []
+    out = O.swin_forward(sd, x, O.SWIN_ARCHS["swin_tiny_test"], pre="", taps=taps)
+    assert out.shape == fx["out"].shape and rel_err(out, fx["out"]) < TOL
+    # the reference's per-stage hook fires after the stage's PatchMerging; the oracle taps before it: compare the last stage (no merge)
+    assert rel_err(taps[-1][:, [0, 1, 17]], fx["tap_rows"][-1]) < TOL
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    assert len(fx["grads"]) == 119
+    for n, d in fx["grads"].items():
+        assert grad_digest_check(d, sd[n].grad, TOL) < 5e-5, n
+
+
 def test_bert(setup):
     vtype, tag, sd, arch = setup
     if tag != "b16_d2":

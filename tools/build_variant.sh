@@ -7,5 +7,5 @@ tag=$1; shift
 mkdir -p tools/probes/bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -c mico_amd/csrc/gemm.hip -o tools/probes/bin/gemm_$tag.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/probes/bin/gemm_$tag.o mico_amd/csrc/build/layernorm.o mico_amd/csrc/build/elementwise.o \
-    mico_amd/csrc/build/attention.o mico_amd/csrc/build/loss.o -o tools/probes/bin/libmico_$tag.so
+    mico_amd/csrc/build/attention.o mico_amd/csrc/build/loss.o mico_amd/csrc/build/swin.o -o tools/probes/bin/libmico_$tag.so
 rm -f tools/probes/bin/gemm_$tag.o
