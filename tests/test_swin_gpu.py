@@ -148,3 +148,34 @@ def test_mico_with_swin_encoder(cuda):
     gtab = m.vision_encoder.layers[0].blocks[1].attn.relative_position_bias_table.grad
     gpe = m.vision_encoder.patch_embed.proj.weight.grad
     assert gtab is not None and gpe is not None and torch.isfinite(gtab).all() and gtab.abs().sum() > 0 and gpe.abs().sum() > 0
+
+
+@pytest.mark.parametrize("name,B", [("swin_base_22k_224", 4), ("swin_large_22k_224", 2)])
+def test_swin_full_size_vs_oracle(cuda, name, B):
+    """Swin-B / Swin-L at the sizes data/model/general_module.py:532-539 selects (24 blocks, 1024 / 1536 output channels; Swin-L's last
+    PatchMerging norm is the 3072-column LayerNorm) against the oracle: tokens, and parameter gradients of the first / last block, the patch
+    embedding, one PatchMerging layer and a shifted block's bias table through autograd on the oracle."""
+    torch.set_num_threads(32)
+    c = SWIN_CONFIGS[name]
+    m = SwinTransformer(embed_dim=c["embed_dim"], depths=c["depths"], num_heads=c["num_heads"], drop_path_rate=0.0)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd, strict=False)
+    m = m.to(cuda).eval()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((B, 3, 224, 224), generator=g)
+    w = torch.randn((B, 49, m.num_features), generator=g) / (B * 49 * m.num_features) ** 0.5
+    watch = ["patch_embed.proj.weight", "layers.0.blocks.0.attn.qkv.weight", "layers.0.blocks.1.attn.relative_position_bias_table",
+             "layers.1.downsample.reduction.weight", "layers.2.downsample.norm.weight", "layers.2.blocks.17.mlp.fc1.weight",
+             "layers.3.blocks.1.attn.proj.bias", "norm.weight"]
+    sdo = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    ref = O.swin_forward(sdo, x, O.SWIN_ARCHS[name], pre="")
+    (ref * w).sum().backward()
+    with runtime.precision(torch.float16):
+        out = m(x.to(cuda))
+        e = rel_err(out, ref.detach())
+        (out * w.to(cuda)).sum().backward()
+    named = dict(m.named_parameters())
+    ge = {n: rel_err(named[n].grad, sdo[n].grad) for n in watch}
+    print(f"{name}: fwd {e:.2e}  grads {max(ge.values()):.2e}")
+    assert e < 1e-3
+    assert max(ge.values()) < 2e-2, ge
