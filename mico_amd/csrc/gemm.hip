@@ -1147,6 +1147,13 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     const FragBase bb = frag_base<TB, 256, BK>(wn * 64, lane);
     s16x8 fa[MT], fb[4];
     auto read_k = [&](int bo, int kk) {
+        if (MICO_GEMM_ABLATE == 2 && g.K > 0) {   // ablation: no LDS reads (keep fragments opaque)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fb[j]));
+            return;
+        }
         LDS_AS const char* ta = lds + bo;
         LDS_AS const char* tb = ta + CFG::A_BYTES;
         const int a1 = kk ? ab.b1 : ab.b0, a2 = kk ? ab2.b1 : ab2.b0, b1 = kk ? bb.b1 : bb.b0;
