@@ -1014,6 +1014,11 @@ template <int BK_> struct Wide {
     static constexpr int NDMA = A_BYTES / 16 / PTHREADS;   // DMA instructions per producer thread per 256-row operand image
 };
 
+#if MICO_GEMM_ABLATE == 10   // ablation: no DMA in the steady state AND no workgroup barriers (wrong results; what the barriers cost)
+#define PC_BARRIER() do {} while (0)
+#else
+#define PC_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 template <typename T, bool TA, bool TB, int BKW>
 __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmArgs g) {
     using CFG = Wide<BKW>;
@@ -1024,12 +1029,19 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    int bid = blockIdx.x;
-    const int ks = bid / g.ntiles;
-    bid -= ks * g.ntiles;
+    // workgroup -> (k-split, tile).  The hardware deals workgroups to the 8 XCDs round robin; each XCD gets a CONTIGUOUS chunk of the
+    // split-major (k-split, tile) list, so the 32 workgroups an XCD runs at a time are one K-range of a compact block of tiles (8 rows x 4
+    // columns in the grouped order below: 80 operand columns fetched per tile and k through that XCD's private L2, where the per-split
+    // remap of round 1 mixed two K-ranges per XCD at 128).  This kernel is power-limited (GRBM clock 1.85 GHz with the operand traffic,
+    // 2.12 without - tools/probes/README.md), so L2-miss bytes are clock.
+    int bid;
+    int ks;
     {
-        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+        const int W = g.ntiles * g.split_k, b0 = blockIdx.x;
+        const int nx = 8, q = W / nx, r = W % nx, x = b0 % nx, o = b0 / nx;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+        ks = lin / g.ntiles;
+        bid = lin - ks * g.ntiles;
     }
     int tile_m, tile_n;
     {
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
         constexpr int PTI = NA + ND;
         const int nseg = g.e.nseg, kseg = g.e.kseg;
         const bool ktail = (g.K % BK) != 0;
-        auto stage = [&](int kt, int bo) {
+        auto stage = [&](int kt, int bo, int part = 3) {   // part: bit 0 = the A image, bit 1 = the B image
             const int k0 = kt * BK;
             int ka = k0, kb = k0;
             int64_t kda = g.K, kdb = g.K;
@@ -1079,16 +1091,16 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
                 kda = g.e.a_seg_off[sg] + kseg;
                 kdb = g.e.b_seg_off[sg] + kseg;
             }
-            if (MICO_GEMM_ABLATE == 1 && kt >= kt0 + 3) return;
+            if ((MICO_GEMM_ABLATE == 1 || MICO_GEMM_ABLATE == 10 || MICO_GEMM_ABLATE == 11) && kt >= kt0 + 3) return;
             if (ktail && kt == g.ktiles - 1) {   // ragged last K-tile: masked path (issues ND + ND instructions; it is waited with vmcnt(0))
-                stage_tile<TA, 256, PTH, BK>(rsa, lds + bo, pw, lane, lda_b, ka, kda, a_crem);
-                stage_tile<TB, 256, PTH, BK>(rsb, lds + bo + CFG::A_BYTES, pw, lane, ldb_b, kb, kdb, b_crem);
+                if (part & 1) stage_tile<TA, 256, PTH, BK>(rsa, lds + bo, pw, lane, lda_b, ka, kda, a_crem);
+                if (part & 2) stage_tile<TB, 256, PTH, BK>(rsb, lds + bo + CFG::A_BYTES, pw, lane, ldb_b, kb, kdb, b_crem);
                 return;
             }
             const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
             const unsigned kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
-            dma_issue<PTH, ND, NA>(rsa, lds + bo, pw, voa, koa);
-            dma_issue<PTH, ND, ND>(rsb, lds + bo + CFG::A_BYTES, pw, vob, kob);
+            if (part & 1) dma_issue<PTH, ND, NA>(rsa, lds + bo, pw, voa, koa);
+            if (part & 2) dma_issue<PTH, ND, ND>(rsb, lds + bo + CFG::A_BYTES, pw, vob, kob);
         };
         constexpr int AHEAD = CFG::STAGES - 1;   // K-tiles in flight
         for (int i = 0; i < AHEAD && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
@@ -1108,10 +1120,14 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             if (AHEAD >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PTI) : "memory");
             else if (AHEAD >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PTI) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            PC_BARRIER();
             __builtin_amdgcn_sched_barrier(0);
-            // the buffer of tile t-1: every consumer retired its reads of it before the barrier above
-            if (t + AHEAD < T_) stage(kt0 + t + AHEAD, (bo + AHEAD * CFG::STAGE_BYTES) & (RING - 1));
+            // the buffer of tile t-1: every consumer retired its reads of it before the barrier above.  The refill is issued in two
+            // halves, one per consumer phase: every data-moving LDS-DMA instruction stalls its wave ~50 cycles, and all 8 of a K-tile in
+            // the first phase (~400 cycles) made the producers the last arrivals at the mid-tile barrier of a 384-cycle MFMA phase.
+            const bool refill = t + AHEAD < T_;
+            const int rbo = (bo + AHEAD * CFG::STAGE_BYTES) & (RING - 1);
+            if (refill) stage(kt0 + t + AHEAD, rbo, CFG::KSTEPS == 1 ? 1 : 3);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (TA && TB && BK == 32) {
                 if (do_colsum) tile_colsum32<T>(cs, cx_even + (unsigned)bo, cx_odd + (unsigned)bo, rg);   // tile t is published and stays until the next iteration's barrier
@@ -1119,12 +1135,14 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 2 * CFG::KSTEPS - 1; ++r) {   // the consumers' remaining barriers of this K-tile
-                __builtin_amdgcn_s_barrier();
+                PC_BARRIER();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (CFG::KSTEPS == 1 && refill) stage(kt0 + t + AHEAD, rbo, 2);
+            __builtin_amdgcn_sched_barrier(0);
             bo = (bo + CFG::STAGE_BYTES) & (RING - 1);
         }
-        __builtin_amdgcn_s_barrier();   // the consumers' end-of-loop barrier
+        PC_BARRIER();   // the consumers' end-of-loop barrier
         if (do_colsum) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1172,13 +1190,13 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     };
     auto head = [&]() {   // own LDS reads of the buffer about to be refilled have returned; then the producers' barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PC_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
     };
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PC_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
     };
     int bo = 0;
@@ -1220,7 +1238,7 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave is done with the operand tiles: LDS may be reused by the epilogue
+    PC_BARRIER();   // every wave is done with the operand tiles: LDS may be reused by the epilogue
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: three 32-row blocks per consumer ----
 #pragma unroll
