@@ -36,6 +36,11 @@
 #ifndef MICO_W4_STAGGER
 #define MICO_W4_STAGGER 1
 #endif
+#ifndef MICO_BIG_MIDBAR   // 8-wave kernel: the barrier between the two phases of a K-tile (aligns the two wave groups; no data hazard needs
+                          // it).  1 = always, 0 = never, 2 = only with a k-contiguous B operand (forward orientation): measured in one run,
+                          // forward 968 with / 909 without, dX (reduction-major W, transposing reads) 978 with / 1003 without
+#define MICO_BIG_MIDBAR 2
+#endif
 #ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
                            // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles,
                            // 6 = no epilogue
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
         auto bar = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (MICO_BIG_MIDBAR == 1 || (MICO_BIG_MIDBAR == 2 && !TB)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
         for (int i = 0; i < 3 && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
@@ -1019,6 +1024,14 @@ template <int BK_> struct Wide {
 #else
 #define PC_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+#ifndef MICO_PC_MIDBAR
+#define MICO_PC_MIDBAR 0
+#endif
+#if MICO_PC_MIDBAR   // the mid-tile barrier only aligns the two consumer groups' phases (no data hazard depends on it)
+#define PC_MIDBAR() PC_BARRIER()
+#else
+#define PC_MIDBAR() do {} while (0)
+#endif
 template <typename T, bool TA, bool TB, int BKW>
 __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmArgs g) {
     using CFG = Wide<BKW>;
@@ -1135,7 +1148,7 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 2 * CFG::KSTEPS - 1; ++r) {   // the consumers' remaining barriers of this K-tile
-                PC_BARRIER();
+                PC_MIDBAR();
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (CFG::KSTEPS == 1 && refill) stage(kt0 + t + AHEAD, rbo, 2);
@@ -1196,7 +1209,7 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
-        PC_BARRIER();
+        PC_MIDBAR();
         __builtin_amdgcn_sched_barrier(0);
     };
     int bo = 0;
