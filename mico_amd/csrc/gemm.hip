@@ -1811,7 +1811,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // the parallelism, so the big tile pays as soon as K is long
     // (at least 16 big tiles: BERT's 768 x 768 layers over the step's ~15 k text rows do no better on the 192x256 tiles, whose fp32
     // atomics then outweigh their K loops, than on the small-tile kernel with small_acc_split(); in situ 156 vs 160 us)
-    const bool long_k_acc = split_k <= 0 && c_dtype == MICO_F32 && g.e.accumulate && K >= 8192 && big_tiles >= 16;
+    const bool long_k_acc = c_dtype == MICO_F32 && g.e.accumulate && K >= 8192 && big_tiles >= 16;
     const bool big = (big_tiles >= 128 || long_k_acc) && N >= 192;
     // the producer/consumer kernel (192x256) takes every large problem; MICO_GEMM_NO_PC (ablation builds) keeps the 8-wave kernel
 #ifdef MICO_GEMM_NO_PC
@@ -1847,7 +1847,10 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (split_k <= 0) {
         if (!(c_dtype == MICO_F32 && g.e.accumulate)) split_k = 1;
         else if (!big && g.ntiles <= 512) split_k = small_acc_split(g.ntiles, g.ktiles);
-        else split_k = auto_split(g.ntiles, g.ktiles, slots, big ? 1024 / BKc : 16, big ? 768 / BKc : 12);
+        // fixed cost of one more wave of workgroups, in K-tiles: fitted on split sweeps of the ViT-g/14 weight-gradient shapes
+        // (tools/gemm_bench.py --split-k; 0.59 us per 32-deep K-tile, ~100 us per wave of 256 atomic epilogues = 170 K-tiles - the old
+        // 24 took the qkv gradient to 9 splits at 664 TFLOP/s where 3 splits run at 815)
+        else split_k = auto_split(g.ntiles, g.ktiles, slots, big ? 1024 / BKc : 16, big ? 5440 / BKc : 12);
     }
     if (split_k > g.ktiles) split_k = g.ktiles;
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--m", type=int, default=82240)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--split-k", type=int, default=0, help="K split of the weight-gradient launches (0 = the library's choice)")
     ap.add_argument("--mx8", action="store_true", help="forward GEMMs on the block-scaled fp8 MFMA (+ the activation quantisation pass)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -34,7 +35,7 @@ def main():
         dx = torch.empty(M, K, device=dev, dtype=dt)
         dw = torch.zeros(N, K, device=dev)
         bias = torch.randn(N, device=dev)
-        sk = 0
+        sk = a.split_k
         if a.mx8:
             qx, qw = ops.quant_mx8(x), ops.quant_mx8(w)
         cases = {
