@@ -104,6 +104,12 @@ typedef struct mico_gemm_epilogue {
      * of the layer whose dW = dy^T x this launch computes, taken from the dy panel the kernel stages anyway (the 192x256 kernel's
      * producer waves sum the columns of tile column 0; other kernels run the stand-alone column-sum pass).  fp32 [M], accumulated. */
     float* colsum_out;
+    /* split-K scratch (optional, caller-owned, fp32, 16-byte aligned): with at least split_k * M * N * 4 bytes the large weight-gradient
+     * kernel writes each K-split's partial tile with plain full-line stores into its own [M, N] slab and a reduction pass adds the slabs
+     * into C (C += alpha * sum) - a wave of 256 atomic epilogues costs ~100 us, the same tiles as plain stores ~20 us + one streaming
+     * pass.  NULL / too small: fp32 atomics into C.  When the library sizes the split itself (split_k = 0) it stays within the scratch. */
+    void* splitk_ws;
+    int64_t splitk_ws_bytes;
 } mico_gemm_epilogue;
 
 /* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256

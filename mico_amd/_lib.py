@@ -28,6 +28,7 @@ class GemmEpilogue(C.Structure):
         ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
         ("row_map", c_vp), ("rows_per_map", c_int),
         ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("colsum_out", c_vp),
+        ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64),
     ]
 
 

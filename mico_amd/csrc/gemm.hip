@@ -41,6 +41,9 @@
                           // forward 968 with / 909 without, dX (reduction-major W, transposing reads) 978 with / 1003 without
 #define MICO_BIG_MIDBAR 2
 #endif
+#ifndef MICO_SLAB_FIXED   // split-K slab path: fixed cost of a wave of workgroups in 32-deep K-tiles (see mico_gemm)
+#define MICO_SLAB_FIXED 48
+#endif
 #ifndef MICO_GEMM_ABLATE   // benchmark-only ablation builds (tools/): 1 = no steady-state DMA, 2 = no LDS reads, 3 = no MFMA,
                            // 4 = DMA issued but out of bounds (no memory traffic; zero operands), 5 = DMA re-reads two K-tiles,
                            // 6 = no epilogue
@@ -1257,8 +1260,18 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
 #pragma unroll
     for (int hb = 0; hb < 3; ++hb) {
         const int64_t mrow = m0 + (hb < 2 ? wm * 64 + hb * 32 : 128 + wm * 32);
-        if (g.split_k > 1) gemm_epilogue_atomic<2>(g, &acc[hb * 2], mrow, n0 + wn * 64, lane);
-        else gemm_epilogue_block<T, 2, ACT_LEAN>(g, &acc[hb * 2], lds + wave * 8192, mrow, n0 + wn * 64, lane);   // see `pc` in mico_gemm
+        if (g.split_k > 1 && g.e.splitk_ws == nullptr) gemm_epilogue_atomic<2>(g, &acc[hb * 2], mrow, n0 + wn * 64, lane);
+        else if (g.split_k > 1) {
+            // this K-split's partial tile -> its own fp32 [M, N] slab of the scratch, whole lines through the LDS-transposing epilogue;
+            // splitk_reduce_kernel adds the slabs into C afterwards
+            GemmArgs gp = g;
+            gp.C = (char*)g.e.splitk_ws + (int64_t)ks * g.M * g.N * 4;
+            gp.ldc = g.N;
+            gp.c_dtype = MICO_F32;
+            gp.e.alpha = 1.f;
+            gp.e.accumulate = 0;
+            gemm_epilogue_block<T, 2, ACT_LEAN>(gp, &acc[hb * 2], lds + wave * 8192, mrow, n0 + wn * 64, lane);
+        } else gemm_epilogue_block<T, 2, ACT_LEAN>(g, &acc[hb * 2], lds + wave * 8192, mrow, n0 + wn * 64, lane);   // see `pc` in mico_gemm
     }
 }
 
@@ -1577,6 +1590,19 @@ __global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
 
 constexpr int pc_bk(int, int) { return 32; }
 
+// C[m, n] += alpha * sum_s ws[s][m][n]   (the split-K slabs of the weight-gradient kernel; N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t M, int64_t N, float* __restrict__ C,
+                                                            int64_t ldc, float alpha) {
+    const int64_t n4 = N / 4, total = M * n4, slab = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / n4, n = (i - m * n4) * 4;
+        f32x4 acc = *(const f32x4*)(ws + m * N + n);
+        for (int s = 1; s < nsplit; ++s) acc += *(const f32x4*)(ws + s * slab + m * N + n);
+        f32x4* cp = (f32x4*)(C + m * ldc + n);
+        *cp = *cp + acc * alpha;
+    }
+}
+
 template <typename T>
 void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     // only the weight-gradient orientation is routed here (see mico_gemm); the kernel template also covers k-contiguous operands
@@ -1647,13 +1673,14 @@ void launch_w4(int ta, int tb, const GemmArgs& g, hipStream_t st) {
 
 // split factor for fp32-accumulating (weight-gradient) GEMMs: fill `slots` resident workgroups in whole waves.
 // cost(s) = waves(s) * (k-tiles per split + fixed prologue / atomic-epilogue cost in k-tile units)
-int auto_split(int tiles, int ktiles, int slots, int min_tiles, int fixed) {
+// per_split: cost of one more split that does not scale with the number of waves (the slab reduction pass reads one [M, N] slab per split)
+int auto_split(int tiles, int ktiles, int slots, int min_tiles, int fixed, int max_split = 32, int per_split = 0) {
     int best = 1;
     long best_cost = -1;
-    for (int s = 1; s <= 32; ++s) {
+    for (int s = 1; s <= 32 && s <= max_split; ++s) {
         if (s > 1 && ktiles / s < min_tiles) break;
         const long waves = ((long)tiles * s + slots - 1) / slots;
-        const long cost = waves * ((ktiles + s - 1) / s + fixed);
+        const long cost = waves * ((ktiles + s - 1) / s + fixed) + (long)(s > 1 ? s * per_split : 0);
         if (best_cost < 0 || cost < best_cost) { best = s; best_cost = cost; }
     }
     return best;
@@ -1706,7 +1733,7 @@ extern "C" int mico_struct_layout(int* out, int n) {
         OFF(mico_gemm_epilogue, remap_offset), OFF(mico_gemm_epilogue, alpha), OFF(mico_gemm_epilogue, accumulate), OFF(mico_gemm_epilogue, nseg),
         OFF(mico_gemm_epilogue, kseg), OFF(mico_gemm_epilogue, a_seg_off), OFF(mico_gemm_epilogue, b_seg_off), OFF(mico_gemm_epilogue, row_map),
         OFF(mico_gemm_epilogue, rows_per_map), OFF(mico_gemm_epilogue, drop_p), OFF(mico_gemm_epilogue, drop_seed), OFF(mico_gemm_epilogue, drop_site),
-        OFF(mico_gemm_epilogue, colsum_out),
+        OFF(mico_gemm_epilogue, colsum_out), OFF(mico_gemm_epilogue, splitk_ws), OFF(mico_gemm_epilogue, splitk_ws_bytes),
         -1,
         (int)sizeof(mico_attn_params),
         OFF(mico_attn_params, B), OFF(mico_attn_params, H), OFF(mico_attn_params, Sq), OFF(mico_attn_params, Sk), OFF(mico_attn_params, hd),
@@ -1850,12 +1877,20 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         // fixed cost of one more wave of workgroups, in K-tiles: fitted on split sweeps of the ViT-g/14 weight-gradient shapes
         // (tools/gemm_bench.py --split-k; 0.59 us per 32-deep K-tile, ~100 us per wave of 256 atomic epilogues = 170 K-tiles - the old
         // 24 took the qkv gradient to 9 splits at 664 TFLOP/s where 3 splits run at 815)
+        else if (pc && g.e.splitk_ws && g.e.splitk_ws_bytes >= 2 * M * N * 4) {
+            // slab path (mico_gemm_epilogue::splitk_ws): a wave of plain-store epilogues + pipeline fill ~ MICO_SLAB_FIXED K-tiles, the
+            // reduction pass ~ M * N * 4 bytes per split at ~4 TB/s (0.59 us per K-tile)
+            const int max_s = (int)std::min<int64_t>(32, g.e.splitk_ws_bytes / (M * N * 4));
+            split_k = auto_split(g.ntiles, g.ktiles, slots, 1024 / BKc, MICO_SLAB_FIXED, max_s, (int)(M * N / 590000) + 8);
+        }
         else split_k = auto_split(g.ntiles, g.ktiles, slots, big ? 1024 / BKc : 16, big ? 5440 / BKc : 12);
     }
     if (split_k > g.ktiles) split_k = g.ktiles;
     g.ktiles_per_split = (g.ktiles + split_k - 1) / split_k;
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
     g.split_k = split_k;
+    // the slab path needs the producer/consumer kernel, a real split and room for every split's slab; otherwise atomics
+    if (!(pc && split_k > 1 && g.e.splitk_ws && g.e.splitk_ws_bytes >= (int64_t)split_k * M * N * 4 && N % 4 == 0)) g.e.splitk_ws = nullptr;
     g.ka_rows = g.kb_rows = K;
     if (g.e.nseg > 0) {
         MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % 64 == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
@@ -1898,7 +1933,15 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else if (w4) DISPATCH_T16(dtype, (launch_w4<T, 0>(ta, tb, g, st)));
     else
 #endif
-    if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
+    if (pc) {
+        DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
+        if (g.e.splitk_ws) {
+            MICO_LAUNCH_CHECK();
+            const int64_t total = M * (N / 4);
+            MICO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, (const float*)g.e.splitk_ws,
+                        g.split_k, M, N, (float*)C, ldc, g.e.alpha);
+        }
+    }
     else if (big) {
         // persistent form when every CU gets several tiles and nothing is split (variant 4 forces it off, for A/B runs)
         bool done = false;

@@ -55,6 +55,18 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_scratch(nbytes, device):
+    """One fp32 scratch buffer per device, grown on demand and kept (launches on one stream use it one after the other)."""
+    t = _SPLITK_WS.get(device)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _SPLITK_WS[device] = t
+    return t
+
+
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
          row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
          accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0, drop=None, colsum_out=None):
@@ -90,6 +102,10 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     if drop is not None:   # (p, seed, site)
         e.drop_p, e.drop_seed, e.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     e.colsum_out = _p(colsum_out)
+    if accumulate and out.dtype == torch.float32 and split_k != 1 and ta and tb:
+        # scratch for the split-K slabs of the large weight-gradient kernel (mico_gemm_epilogue::splitk_ws): room for 8 splits
+        ws = _splitk_scratch(8 * M * N * 4, out.device)
+        e.splitk_ws, e.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     if ksegs is not None:   # (kseg, a_offsets, b_offsets)
         e.kseg, e.nseg = ksegs[0], len(ksegs[1])
         for i, (ao, bo) in enumerate(zip(ksegs[1], ksegs[2])):
