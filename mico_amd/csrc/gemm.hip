@@ -627,7 +627,18 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    if (g.split_k > 1) {   // split-K partials carry no bias / activation / residual (checked on the host side)
+    if (!PINGPONG && g.split_k > 1 && g.e.splitk_ws != nullptr) {
+        // small-tile kernel, split-K slab path (see gemm_pc_kernel): this split's partial tile -> its fp32 [M, N] slab, plain stores
+        __syncthreads();
+        GemmArgs gp = g;
+        gp.C = (char*)g.e.splitk_ws + (int64_t)ks * g.M * g.N * 4;
+        gp.ldc = g.N;
+        gp.c_dtype = MICO_F32;
+        gp.e.alpha = 1.f;
+        gp.e.accumulate = 0;
+#pragma unroll
+        for (int h = 0; h < MT / 4; ++h) gemm_epilogue_block<T, 4, ACT>(gp, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
+    } else if (g.split_k > 1) {   // split-K partials carry no bias / activation / residual (checked on the host side)
 #pragma unroll
         for (int h = 0; h < MT / 4; ++h)
             if (h == 0 || !halfn) gemm_epilogue_atomic(g, &acc[h * 4], m0 + wrow + h * 64, n0 + wcol, lane);
@@ -1691,6 +1702,21 @@ int auto_split(int tiles, int ktiles, int slots, int min_tiles, int fixed, int m
 // not hidden behind other workgroups' K loops: measured ~4 us per MB of fp32 atomics (tools/probes/README.md), against ~1 us per
 // 64-deep K-tile of a workgroup that has its CU to itself.  Cost in microseconds; the old rule (as many splits as fill the chip) paid
 // 134 us where one pass takes 85 (3072 x 768 x 4928; in situ 143 -> 107) and 97 where three splits take 81 (768 x 768 x 4928, in situ).
+// The same with the split-K slab path (mico_gemm_epilogue::splitk_ws): plain-store epilogues (~0.03 us per 128x128 tile at a few TB/s),
+// then one reduction pass over s slabs of mn fp32 elements (~4 TB/s) + its launch.
+int small_slab_split(int tiles, int ktiles, double mn, int max_split) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 32 && s <= ktiles && s <= max_split; ++s) {
+        const double wgs = (double)tiles * s;
+        const double compute = ((ktiles + s - 1) / s) * 1.0 * (wgs > 512.0 ? wgs / 512.0 : 1.0) + 3.0;   // 2 workgroups per CU; pipeline fill
+        const double slabs = s > 1 ? wgs * 0.03 + s * mn * 1e-6 + 4.0 : 0.0;
+        const double cost = compute + slabs;
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 int small_acc_split(int tiles, int ktiles) {
     int best = 1;
     double best_cost = 1e30;
@@ -1873,6 +1899,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.ktiles = (int)((K + BKc - 1) / BKc);
     if (split_k <= 0) {
         if (!(c_dtype == MICO_F32 && g.e.accumulate)) split_k = 1;
+        else if (!big && g.ntiles <= 512 && g.e.splitk_ws && g.e.splitk_ws_bytes >= 2 * M * N * 4 && N % 4 == 0)
+            split_k = small_slab_split(g.ntiles, g.ktiles, (double)M * N, (int)std::min<int64_t>(32, g.e.splitk_ws_bytes / (M * N * 4)));
         else if (!big && g.ntiles <= 512) split_k = small_acc_split(g.ntiles, g.ktiles);
         // fixed cost of one more wave of workgroups, in K-tiles: fitted on split sweeps of the ViT-g/14 weight-gradient shapes
         // (tools/gemm_bench.py --split-k; 0.59 us per 32-deep K-tile, ~100 us per wave of 256 atomic epilogues = 170 K-tiles - the old
@@ -1890,7 +1918,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
     g.split_k = split_k;
     // the slab path needs the producer/consumer kernel, a real split and room for every split's slab; otherwise atomics
-    if (!(pc && split_k > 1 && g.e.splitk_ws && g.e.splitk_ws_bytes >= (int64_t)split_k * M * N * 4 && N % 4 == 0)) g.e.splitk_ws = nullptr;
+    if (!((pc || !big) && split_k > 1 && g.e.splitk_ws && g.e.splitk_ws_bytes >= (int64_t)split_k * M * N * 4 && N % 4 == 0)) g.e.splitk_ws = nullptr;
     g.ka_rows = g.kb_rows = K;
     if (g.e.nseg > 0) {
         MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % 64 == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
@@ -1933,15 +1961,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else if (w4) DISPATCH_T16(dtype, (launch_w4<T, 0>(ta, tb, g, st)));
     else
 #endif
-    if (pc) {
-        DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
-        if (g.e.splitk_ws) {
-            MICO_LAUNCH_CHECK();
-            const int64_t total = M * (N / 4);
-            MICO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, (const float*)g.e.splitk_ws,
-                        g.split_k, M, N, (float*)C, ldc, g.e.alpha);
-        }
-    }
+    if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (big) {
         // persistent form when every CU gets several tiles and nothing is split (variant 4 forces it off, for A/B runs)
         bool done = false;
@@ -1950,6 +1970,12 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         else DISPATCH_T16(dtype, (launch<T, Big>(ta, tb, g, st)));
     }
     else DISPATCH_T16(dtype, (launch<T, Small>(ta, tb, g, st)));
+    if (g.e.splitk_ws) {   // split-K slab path: add the slabs into C
+        MICO_LAUNCH_CHECK();
+        const int64_t total = M * (N / 4);
+        MICO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, (const float*)g.e.splitk_ws,
+                    g.split_k, M, N, (float*)C, ldc, g.e.alpha);
+    }
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

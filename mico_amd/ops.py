@@ -103,8 +103,9 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
         e.drop_p, e.drop_seed, e.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     e.colsum_out = _p(colsum_out)
     if accumulate and out.dtype == torch.float32 and split_k != 1 and ta and tb:
-        # scratch for the split-K slabs of the large weight-gradient kernel (mico_gemm_epilogue::splitk_ws): room for 8 splits
-        ws = _splitk_scratch(8 * M * N * 4, out.device)
+        # scratch for the split-K slabs of the weight-gradient kernels (mico_gemm_epilogue::splitk_ws): room for 8 splits of the towers'
+        # large layers, 32 of BERT's small ones
+        ws = _splitk_scratch((32 if M * N * 4 * 32 <= (256 << 20) else 8) * M * N * 4, out.device)
         e.splitk_ws, e.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     if ksegs is not None:   # (kseg, a_offsets, b_offsets)
         e.kseg, e.nseg = ksegs[0], len(ksegs[1])
