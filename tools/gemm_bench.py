@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--m", type=int, default=82240)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--split-k", type=int, default=0, help="K split of the weight-gradient launches (0 = the library's choice)")
+    ap.add_argument("--resid", action="store_true", help="forward GEMMs with the towers' output-projection epilogue: fp32 out = resid + row_scale * "
+                                                          "(acc + bias), scattered through a frame map (kept-frame compaction)")
     ap.add_argument("--mx8", action="store_true", help="forward GEMMs on the block-scaled fp8 MFMA (+ the activation quantisation pass)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -38,8 +40,17 @@ def main():
         sk = a.split_k
         if a.mx8:
             qx, qw = ops.quant_mx8(x), ops.quant_mx8(w)
+        if a.resid:
+            frames = M // 257
+            stream = torch.randn(frames * 257 + 257 * 8, N, device=dev)
+            fmap = torch.arange(frames, device=dev, dtype=torch.int32) + (torch.arange(frames, device=dev, dtype=torch.int32) // 8)   # skips every 9th frame
+            fmap = fmap.clamp_max(stream.shape[0] // 257 - 1).contiguous()
+            rscale = torch.full((stream.shape[0] // 257,), 1.25, device=dev)
+            Mr = frames * 257
         cases = {
-            "fwd": (lambda: ops.gemm_mx8(qx, qw, y, dtype=dt, bias=bias)) if a.mx8 else (lambda: ops.gemm(x, w, y, bias=bias)),
+            "fwd": (lambda: ops.gemm_mx8(qx, qw, y, dtype=dt, bias=bias)) if a.mx8 else
+                   ((lambda: ops.gemm(x[:Mr], w, stream, bias=bias, resid=stream, row_scale=rscale, rows_per_scale=257, row_map=fmap, rows_per_map=257))
+                    if a.resid else (lambda: ops.gemm(x, w, y, bias=bias))),
             **({"quant": lambda: ops.quant_mx8(x)} if a.mx8 else {}),
             "dx": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N),
             "dw": lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=sk),
