@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
         constexpr int AHEAD = CFG::STAGES - 1;   // K-tiles in flight
         for (int i = 0; i < AHEAD && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
         // bias gradient riding along (tile column 0 only): this lane's column of the A image, its 8 swizzled chunk offsets
-        const bool do_colsum = TA && TB && BK == 32 && g.e.colsum_out != nullptr && tile_n == 0;
+        const bool do_colsum = TA && TB && g.e.colsum_out != nullptr && tile_n == 0;
         const int pid = pw * 64 + lane, lc = pid & 31, rg = pid >> 5;
         // row r = rg + 8 j of the image: byte r * 512 + ((lc ^ key_tr(r)) << 4); key_tr(r) = ((r & 3) | (bit 3 of r) << 2) << 1
         const unsigned cbase = (unsigned)(uintptr_t)lds + (unsigned)rg * 512u;
@@ -1156,8 +1156,11 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             const int rbo = (bo + AHEAD * CFG::STAGE_BYTES) & (RING - 1);
             if (refill) stage(kt0 + t + AHEAD, rbo, CFG::KSTEPS == 1 ? 1 : 3);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TA && TB && BK == 32) {
-                if (do_colsum) tile_colsum32<T>(cs, cx_even + (unsigned)bo, cx_odd + (unsigned)bo, rg);   // tile t is published and stays until the next iteration's barrier
+            if constexpr (TA && TB) {
+                if (do_colsum) {   // tile t is published and stays until the next iteration's barrier
+                    tile_colsum32<T>(cs, cx_even + (unsigned)bo, cx_odd + (unsigned)bo, rg);
+                    if constexpr (BK == 64) tile_colsum32<T>(cs, cx_even + (unsigned)bo + 32u * 512u, cx_odd + (unsigned)bo + 32u * 512u, rg);   // rows 32..63: same keys
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1599,7 +1602,10 @@ __global__ __launch_bounds__(W4::THREADS) __attribute__((amdgpu_waves_per_eu(1, 
 
 #endif   // MICO_GEMM_W4 (kernel)
 
-constexpr int pc_bk(int, int) { return 32; }
+#ifndef MICO_PC_BK
+#define MICO_PC_BK 32
+#endif
+constexpr int pc_bk(int, int) { return MICO_PC_BK; }
 
 // C[m, n] += alpha * sum_s ws[s][m][n]   (the split-K slabs of the weight-gradient kernel; N % 4 == 0)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t M, int64_t N, float* __restrict__ C,
@@ -1619,7 +1625,7 @@ void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     // only the weight-gradient orientation is routed here (see mico_gemm); the kernel template also covers k-contiguous operands
     // with 64-deep K-tiles (measured slower than the 8-wave kernel on the forward / dX shapes, hence not instantiated)
     const dim3 grid(g.ntiles * g.split_k), block(Wide<32>::THREADS);
-    if (ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, true, true, 32>), grid, block, 0, st, g);
+    if (ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, true, true, MICO_PC_BK>), grid, block, 0, st, g);
 #ifdef MICO_GEMM_PC_ALL   // experiment build: every large problem through the producer/consumer kernel (32-deep K-tiles)
     else if (!ta && !tb) MICO_LAUNCH((gemm_pc_kernel<T, false, false, 32>), grid, block, 0, st, g);
     else if (!ta && tb) MICO_LAUNCH((gemm_pc_kernel<T, false, true, 32>), grid, block, 0, st, g);
@@ -1949,7 +1955,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     hipStream_t st = (hipStream_t)stream;
     if (g.e.colsum_out) {
         MICO_CHECK(ta && tb && c_dtype == MICO_F32, "mico_gemm: colsum_out belongs to the weight-gradient orientation (ta = tb = 1, fp32 C)");
-        if (!pc || pc_bk(ta, tb) != 32) {   // not the kernel that takes it along: the stand-alone column-sum pass, same result
+        if (!pc) {   // not the kernel that takes it along: the stand-alone column-sum pass, same result
             const int rc = mico_colsum(A, dtype, lda, K, (int)M, g.e.colsum_out, g.e.alpha, 1, stream);
             if (rc != MICO_OK) return rc;
             g.e.colsum_out = nullptr;
