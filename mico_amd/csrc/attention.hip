@@ -1257,6 +1257,206 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
     }
 }
 
+// ======================================================================================================================
+// backward dK / dV, Q/dO-resident variant (the towers' unmasked self-attention; same eligibility as the K/V-resident kernels above).
+// The tiled kernel gives every 64-key block its own workgroup, which stages all of Q and dO through LDS again (two barriers per 64
+// queries) - five workgroups per head at 257 keys, the fifth for ONE key.  Here persistent 8-wave workgroups walk over (b, h) items with
+// all of Q and dO of the head in LDS (2 x 288 rows x 256 B, staged once per item), wave w owns keys 32 w .. 32 w + 31 (two 16-key blocks,
+// K / V fragments in registers), and nothing synchronises inside the query loop.  Keys 256.. (the 257th token) form one more 16-key block
+// that is split over the QUERIES: wave t takes query tile t, the partial dK / dV rows are summed through LDS.
+// ======================================================================================================================
+template <typename T, int HDP>
+__device__ __forceinline__ void dkv_tile(LDS_AS const char* qt, LDS_AS const char* dot, LDS_AS const float* lse_t, LDS_AS const float* del_t,
+                                         const int nti, const bool fast, const int i0, const int j, const int Sq, const int Sk, const float sc2,
+                                         const float scale, const s16x8 (&kf)[Cfg<HDP>::KS], const s16x8 (&vf)[Cfg<HDP>::KS],
+                                         f32x4 (&dkacc)[Cfg<HDP>::TD], f32x4 (&dvacc)[Cfg<HDP>::TD], const int lane) {
+    using C = Cfg<HDP>;
+    const int g = lane >> 4;
+    f32x4 s[4], dp[4], pr[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        s[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ti < nti) {
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                s[ti] = T16<T>::mfma(lds_row_frag<HDP>(qt, ti * 16, ks, lane), kf[ks], s[ti]);
+                dp[ti] = T16<T>::mfma(lds_row_frag<HDP>(dot, ti * 16, ks, lane), vf[ks], dp[ti]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + ti * 16 + g * 4);
+        const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + ti * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[ti][r], sc2, -lv[r]));
+            float ds = pv * fmaf(dp[ti][r], scale, -dv4[r]);
+            if (!fast && !(i0 + ti * 16 + g * 4 + r < Sq && j < Sk)) { pv = 0.f; ds = 0.f; }
+            pr[ti][r] = pv;
+            s[ti][r] = ds;
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (2 * s2 >= nti) continue;
+        const s16x8 pf = pack_pair<T>(pr[2 * s2], pr[2 * s2 + 1]);
+        const s16x8 df = pack_pair<T>(s[2 * s2], s[2 * s2 + 1]);
+#pragma unroll
+        for (int td = 0; td < C::TD; ++td) {
+            dvacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(dot, td, s2, lane), pf, dvacc[td]);
+            dkacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(qt, td, s2, lane), df, dkacc[td]);
+        }
+    }
+}
+
+template <typename T, int HDP>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkv_res_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                                  const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                                  const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
+                                                                  const mico_attn_params p) {
+    using C = Cfg<HDP>;
+    constexpr int CPR = HDP / 8, QR = RES_KR;
+    constexpr int NLD = (QR * CPR + 511) / 512;
+    __shared__ __attribute__((aligned(16))) char smem[2 * QR * C::RS + 2 * QR * 4 + 8 * 2 * HDP * 4];
+    LDS_AS char* qt = (LDS_AS char*)smem;
+    LDS_AS char* dot = qt + QR * C::RS;
+    LDS_AS float* lse_t = (LDS_AS float*)(dot + QR * C::RS);
+    LDS_AS float* del_t = lse_t + QR;
+    LDS_AS float* part = del_t + QR;   // [wave][dK | dV][HDP]: partial rows of key 256
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const int nitems = p.B * p.H;
+    const int nt = (p.Sq + 63) / 64;
+    const bool ragged = p.Sk > 256;
+    const int nwg = gridDim.x;
+    int item = (int)blockIdx.x, item_step = nwg;
+    if ((nwg & 7) == 0 && nitems % nwg == 0) {   // XCD-contiguous runs of items (see attn_fwd_res_kernel)
+        const int per_wg = nitems / nwg;
+        item = ((int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3)) * per_wg;
+        item_step = 1;
+    }
+    const int item_end = item_step == 1 ? item + nitems / nwg : nitems;
+    for (; item < item_end; item += item_step) {
+        const int b = item / p.H, h = item - b * p.H;
+        const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
+        const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
+        const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+        const T* dob = d_o + (int64_t)b * p.o_bs + h * p.hd;
+        const int64_t stat_base = ((int64_t)b * p.H + h) * p.Sq;
+        // ---- Q, dO of the head -> registers -> LDS (zero beyond Sq / hd); lse * log2(e) and delta * scale next to them ----
+        {
+            s16x8 qr[NLD], dor[NLD];
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int c = it * 512 + tid;
+                const int row = c / CPR, ch = c - row * CPR;
+                s16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, d = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (row < p.Sq && ch * 8 < p.hd) {
+                    a = *(const s16x8*)(qb + (int64_t)row * p.q_rs + ch * 8);
+                    d = *(const s16x8*)(dob + (int64_t)row * p.o_rs + ch * 8);
+                }
+                qr[it] = a;
+                dor[it] = d;
+            }
+            float sl = 0.f, sd = 0.f;
+            if (tid < QR && tid < p.Sq) { sl = lse[stat_base + tid] * LOG2E; sd = delta[stat_base + tid] * p.scale; }
+            __syncthreads();   // the previous item's readers are done with the LDS images (and its key-256 partials are consumed)
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int c = it * 512 + tid;
+                const int row = c / CPR, ch = c - row * CPR;
+                if (row < QR) {
+                    const int off = row * C::RS + ((ch ^ ((row & 7) << 1)) << 4);
+                    *(LDS_AS s16x8*)(qt + off) = qr[it];
+                    *(LDS_AS s16x8*)(dot + off) = dor[it];
+                }
+            }
+            if (tid < QR) { lse_t[tid] = sl; del_t[tid] = sd; }
+        }
+        __syncthreads();
+        // this wave's keys: two 16-key blocks, one after the other (one block's accumulators and K / V fragments live at a time: with both
+        // blocks in flight the kernel spilled 129 registers)
+#pragma unroll 1
+        for (int rb = 0; rb < 2; ++rb) {
+            const int kb0 = wave * 32 + rb * 16;
+            if (kb0 >= p.Sk) break;   // wave-uniform
+            const int j = kb0 + (lane & 15);
+            s16x8 kf[C::KS], vf[C::KS];
+            f32x4 dkacc[C::TD], dvacc[C::TD];
+            row_frags<T, HDP>(kf, kb, p.k_rs, j, p.Sk, p.hd, lane);
+            row_frags<T, HDP>(vf, vb, p.v_rs, j, p.Sk, p.hd, lane);
+#pragma unroll
+            for (int t = 0; t < C::TD; ++t) {
+                dkacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dvacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int t = 0; t < nt; ++t) {
+                const int nti = (t == nt - 1 && (p.Sq & 63)) ? ((p.Sq - t * 64 + 15) >> 4) : 4;
+                dkv_tile<T, HDP>(qt + t * C::TILE, dot + t * C::TILE, lse_t + t * 64, del_t + t * 64, nti, t * 64 + 64 <= p.Sq && kb0 + 16 <= p.Sk, t * 64, j,
+                                 p.Sq, p.Sk, sc2, p.scale, kf, vf, dkacc, dvacc, lane);
+            }
+            if (j < p.Sk) {
+                T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * p.hd;
+                T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * p.hd;
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td) {
+                    const int d = td * 16 + g * 4;
+                    if (d < p.hd) {
+                        *(s16x4*)(dkb + d) = pack4<T>(dkacc[td][0], dkacc[td][1], dkacc[td][2], dkacc[td][3]);
+                        *(s16x4*)(dvb + d) = pack4<T>(dvacc[td][0], dvacc[td][1], dvacc[td][2], dvacc[td][3]);
+                    }
+                }
+            }
+        }
+        if (ragged) {
+            // ---- keys 256..: wave t takes query tile t, partial rows through LDS ----
+            f32x4 dkx[C::TD], dvx[C::TD];
+#pragma unroll
+            for (int t = 0; t < C::TD; ++t) {
+                dkx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dvx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (wave < nt) {
+                s16x8 kx[C::KS], vx[C::KS];
+                const int j = 256 + (lane & 15);
+                row_frags<T, HDP>(kx, kb, p.k_rs, j, p.Sk, p.hd, lane);
+                row_frags<T, HDP>(vx, vb, p.v_rs, j, p.Sk, p.hd, lane);
+                const int t = wave;
+                const int nti = (t == nt - 1 && (p.Sq & 63)) ? ((p.Sq - t * 64 + 15) >> 4) : 4;
+                dkv_tile<T, HDP>(qt + t * C::TILE, dot + t * C::TILE, lse_t + t * 64, del_t + t * 64, nti, false, t * 64, j, p.Sq, p.Sk, sc2, p.scale, kx,
+                                 vx, dkx, dvx, lane);
+            }
+            // rows of keys 256 + (lane & 15): up to 16 keys beyond 256 (Sk <= 272); each lane parks its 4 head-dim values per tile
+            LDS_AS float* pw = part + wave * 2 * HDP;
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pw[td * 16 + g * 4 + r] = dkx[td][r];
+                        pw[HDP + td * 16 + g * 4 + r] = dvx[td][r];
+                    }
+            }
+            __syncthreads();
+            if (tid < 2 * HDP / 4) {
+                const int which = tid / (HDP / 4), d = (tid - which * (HDP / 4)) * 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int w = 0; w < 8; ++w) {
+                    LDS_AS const float* pr = part + w * 2 * HDP + which * HDP + d;
+                    acc[0] += pr[0]; acc[1] += pr[1]; acc[2] += pr[2]; acc[3] += pr[3];
+                }
+                if (d < p.hd) {
+                    T* out = (which ? dv + (int64_t)b * p.v_bs + (int64_t)256 * p.v_rs : dk + (int64_t)b * p.k_bs + (int64_t)256 * p.k_rs) + h * p.hd + d;
+                    *(s16x4*)out = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+        }
+    }
+}
+
 int check_params(const mico_attn_params* p, const char* who) {
     MICO_CHECK(p, "%s: null params", who);
     MICO_CHECK(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Sk > 0, "%s: empty problem", who);
@@ -1347,6 +1547,16 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     } else
     DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP, true>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p); else MICO_LAUNCH((attn_bwd_dq_kernel<T, HDP, false>), gq, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, delta, *p); }));
     MICO_LAUNCH_CHECK();
+    static const bool no_dkv_res = getenv("MICO_ATTN_NODKVRES") != nullptr;   // A/B switch (tools/attn_bench.py)
+    if (res && !no_dkv_res && p->Sk <= 257 && p->hd > 64) {   // (keys beyond 256: one ragged key row is what the partial-row merge writes)
+        static const int n_cu2 = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int nitems = p->B * p->H;
+        const dim3 grid(nitems < n_cu2 ? nitems : n_cu2);
+        DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
+                                        (T*)dk, (T*)dv, *p));
+        MICO_LAUNCH_CHECK();
+        return MICO_OK;
+    }
     DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, { if (p->drop_p > 0.f) MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP, true>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p); else MICO_LAUNCH((attn_bwd_dkv_kernel<T, HDP, false>), gk, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, *p); }));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
