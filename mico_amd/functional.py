@@ -399,7 +399,9 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             M2, fmap2 = a["B2"] * N, a["fmap2"]
             g16 = _empty((M2, D), dt, dev)
             ops.gather_rows_cast(g, g16, row_scale=a["sc2"], rows_per_scale=N, scale=S, frame_map=fmap2, rows_per_frame=N)
-            dln2 = _empty((M2, D), torch.float32, dev)
+            # gradient at the LayerNorm output: 16-bit like every other gradient operand (dqkv, dH, g16 carry the same scale) - the input-gradient
+            # GEMM writes half the bytes and the LayerNorm backward reads half; the SwiGLU path accumulates two GEMMs into it and stays fp32
+            dln2 = _empty((M2, D), torch.float32 if (arch["swiglu"] or not runtime.CFG.ln_grad_16bit) else dt, dev)
             if arch["swiglu"]:
                 w1, w2, w3 = P(b + "mlp.w1.weight"), P(b + "mlp.w2.weight"), P(b + "mlp.w3.weight")
                 Hp = spec.hidden_pad
@@ -483,7 +485,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s, dbias=dbias)
             G(b + "attn.q_bias").add_(dbias[:D])
             G(b + "attn.v_bias").add_(dbias[2 * D:])
-            dln1 = _empty((M1, D), torch.float32, dev)
+            dln1 = _empty((M1, D), dt if runtime.CFG.ln_grad_16bit else torch.float32, dev)
             _gemm_dx(dqkv, _qkv_params(P, b, arch), "qkv", dln1)
             ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,

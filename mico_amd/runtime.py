@@ -6,6 +6,7 @@ compatible with the reference); a 16-bit copy of every GEMM weight is (re)materi
 version counter changes, i.e. once per optimiser step.
 """
 import contextlib
+import os
 import weakref
 
 import torch
@@ -24,6 +25,7 @@ class _Cfg:
     # what is split when split_fp16 is on: "full" = weights AND LayerNorm outputs (3 k-segments, x_hi W_hi + x_lo W_hi + x_hi W_lo),
     # "weights" = weights only (2 k-segments, x W_hi + x W_lo: removes the weight-rounding half of the error at 2x the MFMA work)
     split_mode = "full"
+    ln_grad_16bit = os.environ.get("MICO_LN_GRAD_FP32") is None   # gradient at the LayerNorm outputs stored 16-bit (functional._tower_backward)
     head_split_blocks = 0     # plain fp16 only: the first n tower blocks in a split mode (see enter_block)
     head_split_mode = "weights"
     # BASELINE.json configs[4] ("fp8 MFMA"): the ViT towers' and BERT's forward and input-gradient GEMMs run on the block-scaled fp8 MFMA
