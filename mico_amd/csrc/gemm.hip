@@ -72,7 +72,10 @@ extern "C" int mico_debug_w4_prof(unsigned long long* out) {
 
 namespace {
 
-constexpr int GROUP_M = 8;
+#ifndef MICO_GROUP_M
+#define MICO_GROUP_M 4   // row-tiles per group of the tile order: 4 x 8 blocks per XCD round measured +1-2 % over 8 x 4 on the forward / dX GEMMs (in situ 891 -> 901, 937 -> 958), 16 and 3 worse
+#endif
+constexpr int GROUP_M = MICO_GROUP_M;
 
 template <int BM_, int BN_, int WM_, int WN_, int BK_, int STAGES_> struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
