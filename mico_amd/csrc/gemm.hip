@@ -72,6 +72,9 @@ extern "C" int mico_debug_w4_prof(unsigned long long* out) {
 
 namespace {
 
+#ifndef MICO_MMA_PRIO   // s_setprio(1) around the MFMA bursts of the two ping-pong GEMM kernels
+#define MICO_MMA_PRIO 0
+#endif
 #ifndef MICO_GROUP_M
 #define MICO_GROUP_M 4   // row-tiles per group of the tile order: 4 x 8 blocks per XCD round measured +1-2 % over 8 x 4 on the forward / dX GEMMs (in situ 891 -> 901, 937 -> 958), 16 and 3 worse
 #endif
@@ -544,10 +547,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[j]));
             return;
         }
+        if (MICO_MMA_PRIO) __builtin_amdgcn_s_setprio(1);   // the wave entering its MFMA burst outranks the one issuing reads / DMA on the same SIMD
 #pragma unroll
         for (int i = 0; i < MV; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[j], fa[i], acc[i][j]);
+        if (MICO_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     using FullT = std::integral_constant<int, MT>;
     using HalfT = std::integral_constant<int, MT / 2>;
@@ -1216,10 +1221,12 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
         for (int j = 0; j < 4; ++j) fb[j] = read_frag_b<TB, 256, BK>(tb, b1, j);
     };
     auto mma_k = [&]() {
+        if (MICO_MMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[j], fa[i], acc[i][j]);
+        if (MICO_MMA_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto head = [&]() {   // own LDS reads of the buffer about to be refilled have returned; then the producers' barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
