@@ -56,6 +56,7 @@ def pad8(n):
 
 
 _SPLITK_WS = {}
+SPLITK_SLABS = True   # False: weight-gradient launches get no scratch and fall back to fp32 atomics (kept tested: the C-ABI makes the scratch optional)
 
 
 def _splitk_scratch(nbytes, device):
@@ -102,7 +103,7 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     if drop is not None:   # (p, seed, site)
         e.drop_p, e.drop_seed, e.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     e.colsum_out = _p(colsum_out)
-    if accumulate and out.dtype == torch.float32 and split_k != 1 and ta and tb:
+    if SPLITK_SLABS and accumulate and out.dtype == torch.float32 and split_k != 1 and ta and tb:
         # scratch for the split-K slabs of the weight-gradient kernels (mico_gemm_epilogue::splitk_ws): room for 8 splits of the towers'
         # large layers, 32 of BERT's small ones
         ws = _splitk_scratch((32 if M * N * 4 * 32 <= (256 << 20) else 8) * M * N * 4, out.device)

@@ -111,3 +111,41 @@ def test_weight_gradient_with_bias_colsum(cuda, dtype, rows, n_out, n_in):
     ops.gemm(dy, x, dw, ta=True, tb=True, M=n_out, N=n_in, K=rows, accumulate=True, alpha=0.25, split_k=0, colsum_out=db)
     assert rel_err(dw, ref_w) < 2e-5 * math.sqrt(rows)
     assert rel_err(db, ref_b) < 2e-5 * math.sqrt(rows)
+
+
+@pytest.mark.parametrize("rows,n_out,n_in,split", [(257 * 37, 1408, 2816, 0), (257 * 64 + 3, 1408 + 8, 1408, 5), (4928, 768, 768, 0), (4928, 3072, 768, 7)])
+def test_split_k_slabs_equal_atomics(cuda, rows, n_out, n_in, split):
+    """mico_gemm_epilogue::splitk_ws: the K-splits' partial tiles through the caller's scratch + one reduction pass (both weight-gradient
+    kernels: the 192x256 producer/consumer one and the 128x128 one) against the same launch without scratch (fp32 atomics) and against an
+    fp32 product; a scratch too small for the requested split count must fall back, not overrun."""
+    from mico_amd import ops
+    torch.manual_seed(11)
+    dt = torch.float16
+    dy = (0.1 * torch.randn(rows, n_out, device=cuda)).to(dt)
+    x = torch.randn(rows, n_in, device=cuda).to(dt)
+    base = torch.randn(n_out, n_in, device=cuda)
+    ref = base + 0.5 * (dy.float().t() @ x.float())
+    outs = []
+    for slabs in (True, False):
+        ops.SPLITK_SLABS = slabs
+        try:
+            dw = base.clone()
+            ops.gemm(dy, x, dw, ta=True, tb=True, M=n_out, N=n_in, K=rows, accumulate=True, alpha=0.5, split_k=split)
+        finally:
+            ops.SPLITK_SLABS = True
+        assert rel_err(dw, ref) < 2e-5 * math.sqrt(rows)
+        outs.append(dw)
+    assert rel_err(outs[0], outs[1]) < 1e-5
+    # undersized scratch: room for one slab only -> the library must not use it for a 5-way split
+    e = ops._lib.lib()
+    small = torch.empty(n_out * n_in, dtype=torch.float32, device=cuda)
+    old = ops._splitk_scratch
+    ops._splitk_scratch = lambda nbytes, device: small
+    try:
+        guard = torch.full((1024,), 7.0, device=cuda)
+        dw = base.clone()
+        ops.gemm(dy, x, dw, ta=True, tb=True, M=n_out, N=n_in, K=rows, accumulate=True, alpha=0.5, split_k=5)
+        torch.cuda.synchronize()
+    finally:
+        ops._splitk_scratch = old
+    assert rel_err(dw, ref) < 2e-5 * math.sqrt(rows) and bool((guard == 7.0).all())
