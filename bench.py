@@ -74,6 +74,7 @@ def parse():
                          "of configs[3]: image+video (9 vision frames) + depth + audio + text, 14 frames/sample (not the headline metric); "
                          "vid_cap_fp8 = one rank of configs[4]: 8 video frames + BERT generative head (CAP), b = 32, --dtype fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-comm", action="store_true", help="N = 1: skip the extra steps on a one-rank RCCL group (the `comm` object)")
     ap.add_argument("--no-extras", action="store_true", help="skip parity / parity_config / secondary (only the headline measurement)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="disable DropPath (parity-style run)")
@@ -346,9 +347,28 @@ def main():
             print(f"{str(key[0]):>14s} {key[1]:6d} {key[2]:6d} {key[3]:>10s} {key[4]:5d} {d[0]:8d} {d[3] / d[0]:8.0f} {d[2] / d[0] * 1e3:8.1f} "
                   f"{d[1] / d[2] / 1e9:8.1f} {d[2] / args.steps:8.2f}", file=sys.stderr)
 
-    # ---- communication figures (N > 1): exposed gradient-reduction wait per step, packed all-gather latency ----
+    # ---- communication figures: exposed gradient-reduction wait per step, packed all-gather latency.  N > 1: from the timed steps.
+    # N = 1: the SAME code on a one-rank RCCL group (mico_amd.distributed.force_dist: packed_all_gather's all_gather_into_tensor,
+    # fetch_rows' all_to_all_single, the reducer's in-place all_reduce(AVG) of the tower's arena slices + its buckets), a few extra steps
+    # after the headline measurement - what a 1-GPU box can say about the N > 1 path: that it runs on RCCL and what its overhead is.
     comm = None
-    if world > 1:
+    forced_ms = None
+    if world == 1 and not args.no_comm and rank == 0:
+        from mico_amd import distributed as D
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            D.force_dist(True)
+            reducer = GradBucketReducer(model.parameters())
+            step()
+            finish_ms.clear()
+            kc = max(2, args.steps // 2)
+            elc, _ = timed_steps(kc)
+            forced_ms = elc / kc * 1e3
+        except Exception as e:
+            comm = {"error": repr(e)}
+    if (world > 1 or forced_ms is not None) and comm is None:
         exposed = sum(e0.elapsed_time(e1) for e0, e1 in finish_ms) / max(1, len(finish_ms))
         feat = torch.randn(b, 512, device=dev)
         ids = batch["input_ids"]
@@ -366,6 +386,18 @@ def main():
                     grad_bytes=grad_bytes, grad_reduce_exposed_ms_per_step=exposed,
                     grad_reduce_note="time the step spends in GradBucketReducer.finish() waiting for reductions that did not hide behind "
                                      "the backward; the ViT blocks' arena slices are reduced in place from inside the backward")
+        if forced_ms is not None:
+            comm.update(forced_at_world_size_1=True, ms_per_step_with_collectives=forced_ms, steps=kc,
+                        ms_per_step_headline=elapsed / args.steps * 1e3,
+                        note="one-rank RCCL group with the N > 1 code paths forced (MICO_FORCE_DIST semantics): every collective of the "
+                             "data-parallel step executes on RCCL; latencies are one-rank figures, not xGMI figures")
+    if world == 1 and dist.is_initialized():
+        from mico_amd import distributed as D
+        D.force_dist(False)
+        if reducer is not None:
+            reducer.close()
+        reducer = None
+        dist.destroy_process_group()
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -376,7 +408,9 @@ def main():
     value = samples / elapsed
     kern = {0: "gemm_kernel<T,{ta},{tb},TileCfg<128,128,2,2,64,2>>", 1: "gemm_kernel<T,{ta},{tb},TileCfg<256,256,2,4,32,4>>",
             2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>", 4: "gemm_mx8_kernel<T> (fp8 e4m3 x E8M0/32, v_mfma_scale_f32_16x16x128)",
-            5: "gemm_persist_kernel<T,{ta},{tb}> (256x256 8-wave ping-pong, persistent)"}
+            5: "gemm_persist_kernel<T,{ta},{tb}> (256x256 8-wave ping-pong, persistent)",
+            6: "gemm_kernel<T,{ta},{tb},TileCfg<256,128,2,2,32,3>> (two workgroups per CU)",
+            7: "gemm_mid_kernel<T,{tb}> (256x128x64 unit ring, two workgroups per CU)"}
     role = {(0, 0): "y = x W^T (forward)", (0, 1): "dx = dy W", (1, 1): "dW = dy^T x", (1, 0): "x^T W"}
 
     def kname(key):
@@ -402,7 +436,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
-                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8", 5: "big"}[dom[0][2]]
+                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8", 5: "big", 6: "mid", 7: "mid"}[dom[0][2]]
                 if key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
                     break

@@ -107,17 +107,21 @@ typedef struct mico_gemm_epilogue {
     /* split-K scratch (optional, caller-owned, fp32, 16-byte aligned): with at least split_k * M * N * 4 bytes the large weight-gradient
      * kernel writes each K-split's partial tile with plain full-line stores into its own [M, N] slab and a reduction pass adds the slabs
      * into C (C += alpha * sum) - a wave of 256 atomic epilogues costs ~100 us, the same tiles as plain stores ~20 us + one streaming
-     * pass.  NULL / too small: fp32 atomics into C.  When the library sizes the split itself (split_k = 0) it stays within the scratch. */
+     * pass.  NULL / too small / C not 16-byte aligned: fp32 atomics into C.  When the library sizes the split itself (split_k = 0) it stays
+     * within the scratch.  SINGLE-STREAM: the slabs are written by the GEMM and read back by the reduction pass launched right behind it on
+     * `stream`; two launches that may run concurrently (different streams) must be given different scratch buffers. */
     void* splitk_ws;
     int64_t splitk_ws_bytes;
 } mico_gemm_epilogue;
 
 /* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256
- * producer/consumer, 3 = 256x256 one wave per SIMD (experiment builds), 4 = MX-fp8, 5 = 256x256 8-wave persistent (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
+ * producer/consumer, 3 = 256x256 one wave per SIMD (experiment builds), 4 = MX-fp8, 5 = 256x256 8-wave persistent, 6 / 7 = 256x128 four-wave kernels, two
+ * workgroups per CU (32-deep stages / 64-deep unit ring) (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
 int mico_gemm_last_kernel(void);
 /* kernel routing switch for A/B measurements (process-wide; returns the previous value): 0 = default routing, 1 = never the
  * one-wave-per-SIMD kernel, 2 / 3 = the one-wave-per-SIMD experiment kernel (builds with -DMICO_GEMM_W4 only) takes every large problem it
- * supports, 4 = never the persistent form of the 8-wave kernel */
+ * supports, 4 = never the persistent form of the 8-wave kernel, 5 / 6 and 8 / 9 = the 256x128 two-workgroups-per-CU kernels (32-deep stages /
+ * 64-deep unit ring) take every large forward / dX problem / only those with K <= 2048 */
 int mico_gemm_set_variant(int variant);
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,

@@ -103,8 +103,29 @@ class MicoHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 104   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+
+
+def _check_struct_layout(l):
+    """sizeof and every field offset of the ctypes parameter structs against the layout the library was compiled with."""
+    n = l.mico_struct_layout(None, 0)
+    buf = (c_int * n)()
+    l.mico_struct_layout(buf, n)
+    table, cur = [], []
+    for v in buf:
+        if v == -1:
+            table.append(cur)
+            cur = []
+        else:
+            cur.append(v)
+    for cls, (size, *offs) in zip((GemmEpilogue, AttnParams), table):
+        mine = [getattr(cls, name).offset for name, _ in cls._fields_]
+        if C.sizeof(cls) != size or mine != offs:
+            raise MicoHipError(f"ctypes {cls.__name__} does not match the compiled struct (size {C.sizeof(cls)} vs {size}, offsets {mine} vs {offs})")
+
+
 def lib():
-    """Loads libmico_hip.so once; raises (never falls back) when it is missing."""
+    """Loads libmico_hip.so once; raises (never falls back) when it is missing, stale (ABI version) or laid out differently."""
     global _lib
     if _lib is not None:
         return _lib
@@ -117,6 +138,11 @@ def lib():
         fn = getattr(l, name)   # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
+    # the C ABI is versioned: a stale .so under new Python (or the reverse) would misread positional arguments silently
+    if l.mico_version() != ABI_VERSION:
+        raise MicoHipError(f"{LIB_PATH} reports ABI version {l.mico_version()}, this binding was written for {ABI_VERSION}: rebuild it "
+                           "(`make -C mico_amd/csrc`)")
+    _check_struct_layout(l)
     _lib = l
     if os.environ.get("MICO_GEMM_VARIANT"):      # A/B runs of whole test files / benches without touching their code
         l.mico_gemm_set_variant(int(os.environ["MICO_GEMM_VARIANT"]))

@@ -79,6 +79,18 @@ namespace {
 #define MICO_GROUP_M 4   // row-tiles per group of the tile order: 4 x 8 blocks per XCD round measured +1-2 % over 8 x 4 on the forward / dX GEMMs (in situ 891 -> 901, 937 -> 958), 16 and 3 worse
 #endif
 constexpr int GROUP_M = MICO_GROUP_M;
+#ifndef MICO_MID_DB   // MID kernel: both k-steps' fragments of a K-tile read up front (48 more registers): layer forward 951 -> 985, dX 989 -> 1040 TFLOP/s
+#define MICO_MID_DB 1
+#endif
+#ifndef MICO_MID_PRIO   // MID kernel: 1 = static priority for alternate rounds of workgroups, 2 = s_setprio(1) around the MFMA bursts
+#define MICO_MID_PRIO 0
+#endif
+#ifndef MICO_MID_IL   // MID kernel: the refill DMA dealt out between the second k-step's MFMAs
+#define MICO_MID_IL 0
+#endif
+#ifndef MICO_MID_GROUP_M
+#define MICO_MID_GROUP_M 4   // row-tiles per group of the MID kernel's tile order (64 tiles of 256x128 per XCD at a time): 4 -> 8 -> 16 = layer forward 1020 / 986 / 910 TFLOP/s
+#endif
 
 template <int BM_, int BN_, int WM_, int WN_, int BK_, int STAGES_> struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, STAGES = STAGES_;
@@ -92,6 +104,11 @@ template <int BM_, int BN_, int WM_, int WN_, int BK_, int STAGES_> struct TileC
 };
 using Big = TileCfg<256, 256, 2, 4, 32, 4>;
 using Small = TileCfg<128, 128, 2, 2, 64, 2>;
+// MID 256x128x32, 4 waves (2x2, 128x64 per wave), 3-stage ring of 24 KiB K-tiles (72 KiB): TWO workgroups per CU.  The 8-wave kernel
+// spends ~20 us of prologue + epilogue + dispatch gap per 256x256 tile with the matrix pipes idle (a CU stores at ~10 B/clk whatever
+// the store shape) around ~26 us of K loop at K = 1408; with two independent workgroups per CU one's epilogue / prologue runs under
+// the other's K loop, and 128-wide tiles fit N = 1408 / 4224 / 6144 exactly (no half-empty sixth tile column).
+using Mid = TileCfg<256, 128, 2, 2, 32, 3>;
 
 struct GemmArgs {
     const char* A;
@@ -100,6 +117,7 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc;
     int ntm, ntn, ntiles, split_k, ktiles, ktiles_per_split;
     int c_dtype;
+    int group_m;                // MID kernel: row-tiles per group of the tile order
     int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
 };
@@ -557,7 +575,30 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
     using FullT = std::integral_constant<int, MT>;
     using HalfT = std::integral_constant<int, MT / 2>;
 
-    if constexpr (!PINGPONG) {
+    if constexpr (!PINGPONG && CFG::STAGES == 3) {
+        // one barrier per 32-deep K-tile; tiles t+1 (and, from its issue on, t+2) stay in flight across it: counted vmcnt + raw s_barrier.
+        // Order inside an iteration: fragment reads of tile t, THEN the DMA of tile t+2 into the buffer of tile t-1 (every wave has passed
+        // this iteration's barrier, i.e. retired its reads of t-1) - hipcc waits vmcnt(0) in front of the first transposing read after an
+        // LDS-DMA (tools/probes/README.md), which with this order costs the dX orientation one tile of lookahead, not two.
+        static_assert(CFG::KSTEPS == 1, "Mid path: one k-step per tile");
+        constexpr int PT = CFG::A_DMA + CFG::B_DMA;
+        for (int i = 0; i < 2 && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
+        int bo = 0, bn = 2 * CFG::STAGE_BYTES;
+        for (int t = 0; t < T_; ++t) {
+            asm volatile("" : "+s"(bo), "+s"(bn));
+            if (t + 1 < T_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_k(bo, 0, FullT{});
+            if (t + 2 < T_) stage(kt0 + t + 2, bn);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_k(FullT{});
+            __builtin_amdgcn_sched_barrier(0);
+            bo = bo == 2 * CFG::STAGE_BYTES ? 0 : bo + CFG::STAGE_BYTES;
+            bn = bn == 2 * CFG::STAGE_BYTES ? 0 : bn + CFG::STAGE_BYTES;
+        }
+    } else if constexpr (!PINGPONG) {
         int bo = 0;
         if (T_ > 0) stage(kt0, 0);
         for (int t = 0; t < T_; ++t) {
@@ -818,6 +859,182 @@ __global__ __launch_bounds__(Big::THREADS, 2) void gemm_persist_kernel(const Gem
     }
 }
 #endif   // MICO_GEMM_PERSIST
+
+// ======================================================================================================================
+// "MID" kernel (round 3): 256x128 output tile, 64-deep K-tiles, FOUR waves (2x2, 128x64 each), TWO workgroups per CU.
+// Why: (1) around its K loop the 8-wave kernel spends ~11 us per 256x256 tile (prologue, a 12 us epilogue - a CU stores at ~10 B/clk
+// whatever the store shape - and the dispatch gap) with the matrix pipes idle, against ~37 us of K loop at K = 1408; with two independent
+// workgroups per CU one's epilogue / prologue runs under the other's K loop.  (2) 128-wide tiles fit N = 1408 / 4224 / 6144 exactly.
+// (3) k-contiguous operands arrive in whole 128-byte lines (the fill path moves 61 B/clk/CU in 128-byte row segments, 37 in the 64-byte
+// segments of 32-deep stages - tools/probes/dma_fill.hip).  A 64-deep K-tile of this tile is 48 KiB and a workgroup owns 80 KiB, so the
+// LDS is a ring of FIVE 16 KiB units - A rows 0-127 | A rows 128-255 | B - filled unit by unit: tile t occupies three consecutive ring
+// slots and the DMA of {B(t+1), A-top(t+2), A-bottom(t+2)} goes into them as soon as every wave has read its fragments of tile t
+// (second barrier of the iteration), i.e. 1 2/3 K-tiles are resident or in flight at any time.  Counted vmcnt, raw barriers.
+// Forward (B k-contiguous) and dX (B reduction-major, transposing reads) orientations; K % 64 == 0; no split-K.
+// ======================================================================================================================
+struct Mid64 {
+    static constexpr int BM = 256, BN = 128, BK = 64, THREADS = 256, MT = 8, UNIT = 128 * 64 * 2, NUNITS = 5, LDS_BYTES = NUNITS * UNIT;
+    static constexpr int UD = UNIT / 16 / THREADS;   // DMA instructions per thread per unit (4)
+};
+
+template <typename T, bool TB, int ACT>
+__global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmArgs g) {
+    constexpr int BM = Mid64::BM, BN = Mid64::BN, BK = Mid64::BK, THREADS = Mid64::THREADS, MT = Mid64::MT, UNIT = Mid64::UNIT, UD = Mid64::UD;
+    __shared__ __attribute__((aligned(16))) char smem[Mid64::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // workgroup -> tile: XCD-contiguous remap (bijective), then grouped row-panel order (as gemm_kernel; 64 tiles per XCD at a time)
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    int tile_m, tile_n;
+    {
+        const int gsz = g.group_m * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * g.group_m;
+        const int gm = min(g.ntm - first, g.group_m);
+        const int in = bid - grp * gsz;
+        tile_m = first + in % gm;
+        tile_n = in / gm;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int T_ = g.ktiles;
+
+    const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+    const char* a_base = g.A + m0 * lda_b;
+    const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
+    int64_t a_bytes = (g.M - m0) * lda_b;
+    int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+    if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+    if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing inside a unit: a wave reads all 128 rows of ITS A unit (wm picks the unit) and 64 of the B unit's 128 rows / columns
+    const FragBase ab = frag_base<false, 128, BK>(0, lane), bb = frag_base<TB, 128, BK>(wn * 64, lane);
+    unsigned voa[UD], vob[UD];
+    dma_offsets<false, 128, THREADS, BK, UD>(voa, wave, lane, lda_b, 128);
+    dma_offsets<TB, 128, THREADS, BK, UD>(vob, wave, lane, ldb_b, g.N - n0);
+    const unsigned a_half = (unsigned)(128 * lda_b);
+    const int nseg = g.e.nseg, kseg = g.e.kseg;
+    // unit u = 3 t + w (w: 0 A-top, 1 A-bottom, 2 B) -> ring slot u % 5; cs = slot of tile t's A-top = 3 t mod 5
+    auto k_of = [&](int t, int& ka, int& kb) {
+        const int k0 = t * BK;
+        ka = k0; kb = k0;
+        if (nseg > 0) {
+            const int sg = k0 / kseg, kin = k0 - sg * kseg;
+            ka = g.e.a_seg_off[sg] + kin;
+            kb = g.e.b_seg_off[sg] + kin;
+        }
+    };
+    auto issue = [&](int t, int w, int slot) {
+        int ka, kb;
+        k_of(t, ka, kb);
+        LDS_AS char* dst = lds + slot * UNIT;
+        if (w < 2) dma_issue<THREADS, UD>(rsa, dst, wave, voa, (unsigned)(ka * 2) + (w ? a_half : 0u));
+        else dma_issue<THREADS, UD>(rsb, dst, wave, vob, TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2));
+    };
+    // prologue: A-top / A-bottom / B of tile 0, A-top / A-bottom of tile 1 -> slots 0..4
+    if (T_ > 0) { issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); }
+    if (T_ > 1) { issue(1, 0, 3); issue(1, 1, 4); }
+
+#if MICO_MID_DB
+    s16x8 fa[2][MT], fb[2][4];   // both k-steps' fragments of a K-tile (all 24 reads issued up front; k-step 1's land under k-step 0's MFMAs)
+#else
+    s16x8 fa[1][MT], fb[1][4];
+#endif
+    auto read_k = [&](int sa, int sb, int kk) {
+        LDS_AS const char* ta = lds + sa * UNIT;
+        LDS_AS const char* tb = lds + sb * UNIT;
+        const int abase = kk ? ab.b1 : ab.b0, bbase = kk ? bb.b1 : bb.b0;
+        const int s = MICO_MID_DB ? kk : 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[s][i] = read_frag_b<false, 128, BK>(ta, abase, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[s][j] = read_frag_b<TB, 128, BK>(tb, bbase, j);
+    };
+    auto mma_k = [&](int kk) {
+        const int s = MICO_MID_DB ? kk : 0;
+        if (MICO_GEMM_ABLATE == 3 && g.K > 0) {   // ablation: no MFMA (keep operands live)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[s][i]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[s][j]));
+            return;
+        }
+        if (MICO_MID_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = T16<T>::mfma(fb[s][j], fa[s][i], acc[i][j]);
+        if (MICO_MID_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    };
+#if MICO_MID_PRIO == 1   // static priority for every other round of workgroups (block b and b + 256 are the likely co-residents of a CU)
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+    int cs = 0;   // slot of tile t's first unit
+    for (int t = 0; t < T_; ++t) {
+        asm volatile("" : "+s"(cs));
+        // tile t has landed (this wave's pieces; the barrier publishes everyone's): at most the two A units of tile t+1 stay in flight
+        if (t + 1 < T_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int s1 = cs + 1, s2 = cs + 2;
+        if (s1 >= 5) s1 -= 5;
+        if (s2 >= 5) s2 -= 5;
+        const int sa = wm ? s1 : cs;
+        read_k(sa, s2, 0);
+#if MICO_MID_DB
+        read_k(sa, s2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        mma_k(0);
+        __builtin_amdgcn_sched_barrier(0);
+#if !MICO_MID_DB
+        read_k(sa, s2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile t have returned ...
+        __builtin_amdgcn_s_barrier();                          // ... and so have everyone's: the three slots are free
+        __builtin_amdgcn_sched_barrier(0);
+        // B(t+1) -> slot of A-top(t), A-top(t+2) -> slot of A-bottom(t), A-bottom(t+2) -> slot of B(t)
+        if (MICO_GEMM_ABLATE != 1) {   // (ablation 1: no DMA in the steady state)
+            if (t + 1 < T_) issue(t + 1, 2, cs);
+            if (t + 2 < T_) { issue(t + 2, 0, s1); issue(t + 2, 1, s2); }
+        }
+#if MICO_MID_IL
+        mma_k(1);
+        // the 12 DMA instructions dealt out between the 32 MFMAs (each data-moving LDS-DMA instruction stalls its wave for tens of cycles:
+        // behind an MFMA it has just issued that stall costs this wave's matrix-pipe slot nothing)
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 VMEM
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#else
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        cs += 3;
+        if (cs >= 5) cs -= 5;
+    }
+    __syncthreads();   // every wave is done with the operand units (and the DMA queue is empty) before LDS is reused
+#pragma unroll
+    for (int h = 0; h < 2; ++h) gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+}
 
 // ======================================================================================================================
 // MX-fp8 GEMM (BASELINE.json configs[4]: "fp8 MFMA"): C = epilogue(A B^T) with A [M, K] and B [N, K] in OCP e4m3 and one E8M0 scale per
@@ -1676,6 +1893,18 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     else MICO_LAUNCH((gemm_kernel<T, true, false, CFG>), grid, block, 0, st, g);
 }
 
+template <typename T>
+void launch_mid(int tb, const GemmArgs& g, hipStream_t st) {
+    const dim3 grid(g.ntiles), block(Mid64::THREADS);
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_mid_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
+    if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_mid_kernel<T, true, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
+    const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    if (lean && !tb) MICO_LAUNCH((gemm_mid_kernel<T, false, ACT_LEAN>), grid, block, 0, st, g);
+    else if (lean) MICO_LAUNCH((gemm_mid_kernel<T, true, ACT_LEAN>), grid, block, 0, st, g);
+    else if (!tb) MICO_LAUNCH((gemm_mid_kernel<T, false, 0>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_mid_kernel<T, true, 0>), grid, block, 0, st, g);
+}
+
 #ifdef MICO_GEMM_W4
 #ifndef MICO_W4_P1
 #define MICO_W4_P1 16
@@ -1760,9 +1989,10 @@ int mico_set_err(int code, const char* fmt, ...) {
 
 thread_local int g_mico_last_gemm_kernel = 0;
 static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-wave-per-SIMD kernel; 2 = it takes every large problem
-extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant; g_mico_gemm_variant = v; return old; }
+static int g_mico_mid_group = 0;       // sweeps: variant / 100 overrides the MID kernel's tile-order group height
+extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant + 100 * g_mico_mid_group; g_mico_gemm_variant = v % 100; g_mico_mid_group = v / 100; return old; }
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 103; }
+extern "C" int mico_version(void) { return 104; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {
@@ -1906,12 +2136,19 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
 #endif
     const bool w4 = w4_built && big && g_mico_gemm_variant >= 2 && (ta || K % 64 == 0) && (tb || K % 64 == 0) && a_ext < 0x7FFFFF00ll && b_ext < 0x7FFFFF00ll;
     if (w4) pc = false;
-    const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = big ? 256 : 128;
-    const int slots = big ? 256 : 512;
+    // the 256x128 two-workgroups-per-CU kernel: forward / dX orientation, no split (variant 5: every such problem, 6: K <= 2048 only, 7: off)
+    const bool no_split = !(c_dtype == MICO_F32 && g.e.accumulate) && split_k <= 1;
+    const bool mid = big && !pc && !w4 && !ta && no_split && N % 128 == 0 &&
+                     (g_mico_gemm_variant == 5 || (g_mico_gemm_variant == 6 && K <= 2048));
+    // the 64-deep unit-ring form of it (variant 8: every such problem, 9: K <= 2048 only)
+    const bool mid64 = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
+                       (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048));
+    const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = (mid || mid64) ? 128 : (big ? 256 : 128);
+    const int slots = big && !mid && !mid64 ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
     g.ntiles = g.ntm * g.ntn;
     const bool deep = g_mico_gemm_variant == 3;
-    const int BKc = w4 ? (deep ? 32 : 64) : pc ? pc_bk(ta, tb) : (big ? Big::BK : Small::BK);
+    const int BKc = w4 ? (deep ? 32 : 64) : pc ? pc_bk(ta, tb) : mid64 ? Mid64::BK : mid ? Mid::BK : (big ? Big::BK : Small::BK);
     g.ktiles = (int)((K + BKc - 1) / BKc);
     if (split_k <= 0) {
         if (!(c_dtype == MICO_F32 && g.e.accumulate)) split_k = 1;
@@ -1934,8 +2171,12 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     split_k = (g.ktiles + g.ktiles_per_split - 1) / g.ktiles_per_split;
     g.split_k = split_k;
     // the slab path needs the producer/consumer kernel, a real split and room for every split's slab; otherwise atomics
-    if (!((pc || !big) && split_k > 1 && g.e.splitk_ws && g.e.splitk_ws_bytes >= (int64_t)split_k * M * N * 4 && N % 4 == 0)) g.e.splitk_ws = nullptr;
+    // (splitk_reduce_kernel reads and writes C with 16-byte accesses: a C that is only 4-byte aligned stays on the atomics path)
+    if (!((pc || !big) && split_k > 1 && g.e.splitk_ws && g.e.splitk_ws_bytes >= (int64_t)split_k * M * N * 4 && N % 4 == 0 &&
+          ((uintptr_t)C & 15) == 0 && ((uintptr_t)g.e.splitk_ws & 15) == 0))
+        g.e.splitk_ws = nullptr;
     g.ka_rows = g.kb_rows = K;
+    g.group_m = g_mico_mid_group > 0 ? g_mico_mid_group : MICO_MID_GROUP_M;
     if (g.e.nseg > 0) {
         MICO_CHECK(g.e.nseg <= 3 && g.e.kseg > 0 && g.e.kseg % 64 == 0 && (int64_t)g.e.nseg * g.e.kseg == K,
                    "mico_gemm: k-segments need nseg <= 3, kseg %% 64 == 0 and nseg * kseg == K");
@@ -1978,6 +2219,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else
 #endif
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
+    else if (mid64) { g_mico_last_gemm_kernel = 7; DISPATCH_T16(dtype, (launch_mid<T>(tb, g, st))); }
+    else if (mid) { g_mico_last_gemm_kernel = 6; DISPATCH_T16(dtype, (launch<T, Mid>(ta, tb, g, st))); }
     else if (big) {
         // persistent form when every CU gets several tiles and nothing is split (variant 4 forces it off, for A/B runs)
         bool done = false;

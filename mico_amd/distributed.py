@@ -9,10 +9,24 @@ over xGMI on ROCm; "gloo" on CPU for the tests).  Mirrors data/utils/distributed
   packed_all_gather     new       one collective for all per-step small tensors (features, ids, masks) instead of 4-6
                                   latency-bound launches.
 
-Every function degrades to the identity when torch.distributed is not initialised (W = 1).
+Every function degrades to the identity when torch.distributed is not initialised (W = 1) - unless `force_dist(True)` /
+MICO_FORCE_DIST=1 is set: then an initialised process group of ONE rank takes the N > 1 code paths too (the collectives, the
+row exchange, the in-place arena-slice reduction), so that a 1-GPU box can run RCCL's `all_gather_into_tensor` /
+`all_to_all_single` / `all_reduce(AVG)` calls exactly as an 8-GPU job issues them (tests/test_distributed_gpu.py, bench.py `comm`).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_FORCE = os.environ.get("MICO_FORCE_DIST", "0") == "1"
+
+
+def force_dist(on=True):
+    """Take the distributed code paths at world size 1 as well (needs an initialised process group).  Returns the old setting."""
+    global _FORCE
+    old, _FORCE = _FORCE, bool(on)
+    return old
 
 
 def _nccl():
@@ -20,7 +34,7 @@ def _nccl():
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -184,12 +198,21 @@ class GradBucketReducer:
         self._early = set()          # ids of parameters whose gradient was already reduced inside a backward (arena slices)
         self._early_handles = []
         self._early_slices = []      # (flat arena slice, its parameters) of those reductions: finish() checks the aliasing
+        self._hook_handles = []
         if is_dist():
             for p in self.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
             from . import runtime
             runtime.set_grad_slice_hook(self._reduce_slice)
         self.reset()
+
+    def close(self):
+        """Detaches the reducer from the parameters and the tower backward (before its process group goes away)."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        from . import runtime
+        runtime.set_grad_slice_hook(None)
 
     def _reduce_slice(self, flat, params):
         """runtime.grad_slice_hook: `flat` is the final gradient of `params` (one contiguous arena slice, e.g. a ViT block):
@@ -260,7 +283,9 @@ class GradBucketReducer:
             for p in params:
                 n = p.numel()
                 view = flat[o:o + n].view(p.shape)
-                if p.grad is None:
+                if not p.requires_grad:     # autograd left it without a gradient on purpose: nothing to hand over (an all-zero .grad would
+                    pass                    # block the early path next step and feed weight decay / moments of an optimizer that owns it)
+                elif p.grad is None:
                     p.grad = view
                 elif p.grad.data_ptr() != view.data_ptr():
                     p.grad.copy_(view)

@@ -57,14 +57,19 @@ def pad8(n):
 
 _SPLITK_WS = {}
 SPLITK_SLABS = True   # False: weight-gradient launches get no scratch and fall back to fp32 atomics (kept tested: the C-ABI makes the scratch optional)
+SPLITK_WS_CAP = 320 << 20   # bytes: room for 8+ slabs of the towers' largest layer gradient (6144 x 1408 fp32 = 35 MB); a smaller scratch only
+                            # bounds the split count (the library falls back to fewer splits / atomics cleanly)
 
 
 def _splitk_scratch(nbytes, device):
-    """One fp32 scratch buffer per device, grown on demand and kept (launches on one stream use it one after the other)."""
-    t = _SPLITK_WS.get(device)
+    """One fp32 scratch buffer per (device, stream), grown on demand and kept.  The weight-gradient kernel writes its split-K partial
+    tiles into it and the reduction pass reads them back: launches on ONE stream use it one after the other; launches on different
+    streams (or from threads with different current streams) must not share it - hence the stream in the key."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _SPLITK_WS.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _SPLITK_WS[device] = t
+        _SPLITK_WS[key] = t
     return t
 
 
@@ -106,7 +111,8 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     if SPLITK_SLABS and accumulate and out.dtype == torch.float32 and split_k != 1 and ta and tb:
         # scratch for the split-K slabs of the weight-gradient kernels (mico_gemm_epilogue::splitk_ws): room for 8 splits of the towers'
         # large layers, 32 of BERT's small ones
-        ws = _splitk_scratch((32 if M * N * 4 * 32 <= (256 << 20) else 8) * M * N * 4, out.device)
+        slab = M * N * 4
+        ws = _splitk_scratch(min(32, max(2, SPLITK_WS_CAP // slab)) * slab, out.device)
         e.splitk_ws, e.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     if ksegs is not None:   # (kseg, a_offsets, b_offsets)
         e.kseg, e.nseg = ksegs[0], len(ksegs[1])

@@ -165,6 +165,8 @@ class GradScaler:
             return
         if new_scale is not None:
             self._scale, self._good_steps = float(new_scale), 0
+        elif self._found_inf is None:
+            raise RuntimeError("GradScaler.update() before step(): no inf / nan check was recorded for this iteration")
         elif self._found_inf:
             self._scale, self._good_steps = self._scale * self._backoff, 0
         else:

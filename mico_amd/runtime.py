@@ -64,11 +64,11 @@ def precision(dtype):
 
 def snapshot():
     """The precision state a forward pass ran under; see using()."""
-    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8, CFG.head_split_blocks)
+    return (CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8, CFG.head_split_blocks, CFG.head_split_mode)
 
 
 def restore(state):
-    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8, CFG.head_split_blocks = state
+    CFG.compute_dtype, CFG.split_fp16, CFG.split_mode, CFG.fp8, CFG.head_split_blocks, CFG.head_split_mode = state
 
 
 @contextlib.contextmanager
@@ -90,9 +90,9 @@ def enter_block(i, base):
     first blocks pass through every later block; on the 40-block g/14 golden four such blocks take plain fp16 from 7.1e-4 / 1.0e-3
     (token rows / feat_v) to 7.4e-4 / 7.5e-4 for +2 % step time, where the same four blocks at the END of the tower change nothing
     (tools/precision_probe.py --tail).  The tower loops call this at the top of every block and restore(base) when they leave."""
-    dt, split, mode, fp8, n = base
+    dt, split, mode, fp8, n, hmode = base
     if n and i < n and dt == torch.float16 and not split and not fp8:
-        restore((dt, True, CFG.head_split_mode, False, n))
+        restore((dt, True, hmode, False, n, hmode))
     else:
         restore(base)
 

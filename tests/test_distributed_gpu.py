@@ -107,3 +107,83 @@ def test_two_ranks_one_gpu(cuda):
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for r in range(2):
         assert ret.get(r) == "ok", ret.get(r)
+
+
+def _rccl_worker(port, ret):
+    """ONE rank, backend nccl (= RCCL), force_dist: the alignment step through the real N > 1 code - packed_all_gather's
+    all_gather_into_tensor, fetch_rows' all_to_all_single (forward and mirrored backward), GradBucketReducer's in-place
+    all_reduce(AVG) of the tower's arena slices and its flat buckets - must equal the non-distributed step."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from common import build_model
+        from mico_amd import runtime, distributed as D
+        from mico_amd.weights import synth_inputs
+        runtime.set_compute_dtype(torch.float16)
+        m, _ = build_model("evaclip02_base", 2, device=dev)
+        b = 4
+        inp = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, vision=1, audio=1, S=12), seed=61).items()}
+        inj = {"tva": dict(neg_cond_idx=torch.tensor([(i + 1) % b for i in range(b)]), neg_text_idx=torch.tensor([(i + 2) % b for i in range(b)]))}
+        import random
+        from mico_amd.model import TokenMasker
+        mi, lab = TokenMasker(rng=random.Random(3))(inp["input_ids"].cpu(), 0.6)
+        inj["cap"] = dict(masked_ids=mi, labels=lab)
+
+        def run(dist_on):
+            D.force_dist(dist_on)
+            red = D.GradBucketReducer(m.parameters(), bucket_bytes=64 << 20) if dist_on else None
+            m.zero_grad(set_to_none=True)
+            batch = dict(inp)
+            batch["_injected"] = inj
+            out = m(batch, "ret%tva_cap%tva")
+            sum(out.values()).backward()
+            early = len(red._early) if red is not None else 0
+            if red is not None:
+                red.finish()
+            torch.cuda.synchronize()
+            return {k: float(v) for k, v in out.items()}, {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}, early
+
+        assert not D.is_dist()
+        l0, g0, _ = run(False)
+        l1, g1, early = run(True)
+        assert D.is_dist() and D.world_size() == 1 and dist.get_backend() == "nccl"
+        assert early > 10, "the tower's blocks must have gone through the arena-slice all_reduce(AVG)"
+        # the collectives themselves, against their identities at W = 1
+        x = torch.randn(5, 7, device=dev)
+        ids = torch.arange(10, device=dev).view(5, 2)
+        gx, gi = D.packed_all_gather([x, ids])
+        assert torch.equal(gx, x) and torch.equal(gi, ids)
+        loc = torch.randn(5, 3, 4, device=dev, requires_grad=True)
+        idx = torch.tensor([4, 0, 0, 2], device=dev)
+        rows = D.fetch_rows(loc, idx)
+        assert torch.equal(rows, loc.detach()[idx])
+        rows.sum().backward()
+        ref = torch.zeros_like(loc).index_add_(0, idx, torch.ones(4, 3, 4, device=dev))
+        assert torch.equal(loc.grad, ref)
+        D.force_dist(False)
+        for k in l0:
+            assert abs(l0[k] - l1[k]) <= 1e-6 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+        assert g0.keys() == g1.keys()
+        worst = max(((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-20)).item() for n in g0)
+        # same kernels, same order: atomics in split-K paths aside the two steps are the same arithmetic
+        assert worst < 1e-4, worst
+        ret[0] = "ok"
+    except Exception:   # noqa
+        import traceback
+        ret[0] = traceback.format_exc()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_world_size_one(cuda):
+    """RCCL on the hardware there is: a one-rank `nccl` group with the N > 1 code paths forced."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    assert ret.get(0) == "ok", ret.get(0)

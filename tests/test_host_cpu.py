@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes prototype table covers exactly the header
     assert sorted(_lib.PROTOTYPES) == syms
     l = _lib.lib()
-    assert l.mico_version() >= 100
+    assert l.mico_version() == _lib.ABI_VERSION     # lib() itself refuses any other version
 
 
 def test_ctypes_structs_match_the_compiled_layout():

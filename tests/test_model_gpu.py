@@ -73,7 +73,7 @@ def test_vit_tower_head_split(setup, cuda, chunk):
         runtime.set_tower_chunk(chunk)
         with runtime.precision(torch.float16):
             out = m.vision_encoder.visual(x.to(cuda), return_all_features=True)
-            assert runtime.snapshot()[1:] == (False, old[2], old[3], 1)      # the per-block state does not leak out of the tower
+            assert runtime.snapshot()[1:] == (False, old[2], old[3], 1, old[5])      # the per-block state does not leak out of the tower
             e = rel_err(out, fx["out"])
             (out * w.to(cuda)).sum().backward()
     finally:

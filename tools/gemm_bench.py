@@ -23,13 +23,38 @@ def main():
     ap.add_argument("--resid", action="store_true", help="forward GEMMs with the towers' output-projection epilogue: fp32 out = resid + row_scale * "
                                                           "(acc + bias), scattered through a frame map (kept-frame compaction)")
     ap.add_argument("--mx8", action="store_true", help="forward GEMMs on the block-scaled fp8 MFMA (+ the activation quantisation pass)")
+    ap.add_argument("--variants", default="", help="comma list of mico_gemm_set_variant values to A/B in this process, interleaved per shape (e.g. 0,5)")
+    ap.add_argument("--square", type=int, default=0, help="also time an n x n x n forward problem (the guide's 4096^3 / 8192^3 reference shapes)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     dev = torch.device("cuda:0")
     M = a.m
     shapes = [("qkv", 1408, 4224), ("proj", 1408, 1408), ("fc1", 1408, 6144), ("fc2", 6144, 1408)]
     res = []
+    variants = [int(v) for v in a.variants.split(",")] if a.variants else [None]
+    if a.square:
+        n = a.square
+        x = torch.randn(n, n, device=dev).to(dt)
+        w = torch.randn(n, n, device=dev).to(dt)
+        y = torch.empty(n, n, device=dev, dtype=dt)
+        for v in variants * 2:
+            if v is not None:
+                ops._lib.lib().mico_gemm_set_variant(v)
+            for _ in range(3):
+                ops.gemm(x, w, y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                ops.gemm(x, w, y)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"square fwd n={n} variant={v}: {ms:8.3f} ms  {2.0 * n ** 3 / ms / 1e9:7.1f} TFLOP/s", flush=True)
+        del x, w, y
+    ref_out = {}
     for name, K, N in shapes:
+        ref_out.clear()
         x = torch.randn(M, K, device=dev).to(dt)
         w = (0.02 * torch.randn(N, K, device=dev)).to(dt)
         dy = torch.randn(M, N, device=dev).to(dt)
@@ -55,9 +80,12 @@ def main():
             "dx": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N),
             "dw": lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=sk),
         }
-        for cname, fn in cases.items():
-            if (a.only and cname != a.only) or (a.mx8 and cname in ("dx", "dw")):
+        for cname, fn, var in [(c, f, v) for c, f in cases.items() for v in (variants * 2 if len(variants) > 1 else variants)]:
+            if (a.only and cname not in a.only.split(",")) or (a.mx8 and cname in ("dx", "dw")):
                 continue
+            if var is not None:
+                ops._lib.lib().mico_gemm_set_variant(var)
+                cname = f"{cname}@{var}"
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -77,11 +105,21 @@ def main():
             ms = e0.elapsed_time(e1) / a.iters
             tf = 2.0 * M * N * K / ms / 1e9
             res.append((name, cname, ms, tf))
-            print(f"{name:5s} {cname:3s} M={M} N={N} K={K} split_k={sk if cname == 'dw' else 1}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s", flush=True)
+            chk = ""
+            if var is not None and not a.resid and cname.split("@")[0] in ("fwd", "dx"):   # variants must agree (same k order: expect 0)
+                out = (y if cname.startswith("fwd") else dx).float()
+                key = (name, cname.split("@")[0])
+                if key not in ref_out:
+                    ref_out[key] = out.clone()
+                else:
+                    chk = f"  max|diff vs variant {variants[0]}| = {(out - ref_out[key]).abs().max().item():.3g}"
+            print(f"{name:5s} {cname:3s} M={M} N={N} K={K} split_k={sk if cname == 'dw' else 1}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s{chk}", flush=True)
     tot_f = sum(2.0 * M * (4224 + 1408 + 6144 + 6144) * 1408 for _ in range(1))
-    for c in ("fwd", "dx", "dw"):
-        ms = sum(r[2] for r in res if r[1] == c)
-        if ms:
+    for c in sorted(set(r[1] for r in res)):
+        rows = [r for r in res if r[1] == c]
+        reps = max(1, len(rows) // len(shapes))
+        ms = sum(r[2] for r in rows) / reps
+        if ms and len(rows) % len(shapes) == 0:
             print(f"layer {c}: {ms:.3f} ms  -> {tot_f / ms / 1e9:.1f} TFLOP/s")
 
 
