@@ -74,6 +74,7 @@ def parse():
                          "of configs[3]: image+video (9 vision frames) + depth + audio + text, 14 frames/sample (not the headline metric); "
                          "vid_cap_fp8 = one rank of configs[4]: 8 video frames + BERT generative head (CAP), b = 32, --dtype fp8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--diet", type=int, default=None, help="force the tower's saved-activation level (0 / 1 / 2; default: mico_amd.functional.tower_plan decides)")
     ap.add_argument("--no-comm", action="store_true", help="N = 1: skip the extra steps on a one-rank RCCL group (the `comm` object)")
     ap.add_argument("--no-extras", action="store_true", help="skip parity / parity_config / secondary (only the headline measurement)")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -270,6 +271,7 @@ def main():
     from mico_amd.distributed import GradBucketReducer, packed_all_gather
 
     set_precision(args.dtype)
+    runtime.set_activation_diet(args.diet)
     torch.manual_seed(rank)     # host RNG: stochastic-depth draws differ per rank (weights/inputs come from counter hashes)
     from mico_amd.functional import DropPlan
     DropPlan.skip_dropped = not args.dense_droppath
@@ -483,6 +485,7 @@ def main():
         "step_mfma_frac": (step_tflops / MFMA_PEAK_TFLOPS) if step_tflops else None,
         "losses": {k: float(v.detach()) for k, v in losses.items()},
         "peak_mem_gb": peak_mem,
+        "tower_plan": runtime.last_tower_plan,
         "roofline": roofline,
     }
     if comm is not None:
@@ -519,19 +522,48 @@ def main():
                 others[oc] = {"error": repr(e)}
         set_precision(args.dtype)
         res["other_precisions"] = others
-        # ---- secondary: one rank's share of BASELINE configs[3] (14 frames per sample: image + 8 video frames + depth + 4 audio windows) ----
+        # ---- the metric's own multi-GPU configuration: one rank's share of BASELINE configs[3] (14 frames per sample: image + 8 video
+        # frames + depth + 4 audio windows, b = 64 -> 896 tower frames), timed as a first-class object: >= 10 steps, its own executed-FLOP
+        # figure, MFMA fraction and GEMM roofline, and the tower plan it ran under (functional.tower_plan: frames per pass, activation diet)
         try:
             wo = WORKLOADS["omni"]
             torch.cuda.empty_cache()
             ob = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, **wo["shape"]), seed=4321).items()}
             step(ob, wo["task"])
-            k3 = 2
+            k3 = max(10, args.steps // 2)
             torch.cuda.reset_peak_memory_stats()
+            otimer = None if args.no_gemm_timer else ops.KernelTimer()
+            ops.GEMM_TIMER = otimer
+            DropPlan.stats[:] = [0, 0]
             el3, _ = timed_steps(k3, ob, wo["task"])
+            ops.GEMM_TIMER = None
+            okept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
+            onom = ALG_TFLOP_PER_SAMPLE[wo["key"]]
+            oexec = onom - wo["frames"] * 40 * 13.341 * 3 / 1e3 * (1.0 - okept)
+            if runtime.CFG.share_cross_kv and not args.eval_mode:
+                # shared cross-attention K/V: the reference projects 4 condition sets for tva (ITM triplet + captioning pass, E = 13 x 257
+                # tokens) and 3 for tvd (triplet only, E = 10 x 257), the engine 2 + 2: 12 layers x saved sets x E x 2*768*1536 flop x 3
+                oexec -= 12 * (2 * 13 * 257 + 1 * 10 * 257) * 2 * 768 * 1536 * 3 / 1e12
+            oval = b * k3 / el3
+            oroof = None
+            if otimer is not None:
+                summ = otimer.summary()
+                tf = sum(v["flops"] for v in summ.values())
+                tm = sum(v["ms"] for v in summ.values())
+                dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+                oroof = dict(bound="mfma", kernel=kname(dom[0]), achieved=dom[1]["flops"] / dom[1]["ms"] / 1e9, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=dom[1]["flops"] / dom[1]["ms"] / 1e9 / MFMA_PEAK_TFLOPS, launches=dom[1]["launches"],
+                             avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
+                             all_gemm=dict(tflops=tf / tm / 1e9, share_of_step_time=tm / 1e3 / el3))
             res["secondary"] = {"omni_configs3_rank_share": dict(
-                value=b * k3 / el3, unit="samples/s", ms_per_step=el3 / k3 * 1e3, steps=k3, warmup=1, frames_per_sample=wo["frames"],
-                task=wo["task"], peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, precision=PRECISIONS[args.dtype][3],
-                tower_chunk_frames=runtime.tower_chunk_override() or "auto (from free HBM)")}
+                value=oval, unit="samples/s", ms_per_step=el3 / k3 * 1e3, steps=k3, warmup=1, frames_per_sample=wo["frames"],
+                frames_per_sec=oval * wo["frames"], task=wo["task"], peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30,
+                precision=PRECISIONS[args.dtype][3], kept_branch_fraction=okept,
+                tflop_per_sample={"dense_nominal": onom, "executed": oexec}, step_executed_tflops_per_gpu=oexec * oval,
+                step_mfma_frac=oexec * oval / MFMA_PEAK_TFLOPS, roofline=oroof,
+                tower_plan=runtime.last_tower_plan,
+                tower_plan_note="frames_per_pass == frames: no chunked recompute; diet 1 / 2: MLP intermediates (and LayerNorm outputs) "
+                                "recomputed in the backward (mico_amd.runtime.set_activation_diet)")}
             del ob
         except Exception as e:   # the headline line must survive a failure of the secondary measurement
             res["secondary"] = {"omni_configs3_rank_share": {"error": repr(e)}}

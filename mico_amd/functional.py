@@ -226,8 +226,10 @@ class DropPlan:
 _TAIL_EXP = None   # experiment hook (tools/precision_probe.py --tail)
 
 
-def _tower_forward(spec, groups, dp_scale, params, save):
-    """One pass of the tower over the frames in `groups`.  save=False keeps nothing for a backward (chunked forward)."""
+def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
+    """One pass of the tower over the frames in `groups`.  save=False keeps nothing for a backward (chunked forward).
+    diet (plain-MLP towers): 1 = the MLP intermediates are not kept (the backward recomputes fc1 + GELU / GELU'), 2 = nor the LayerNorm
+    outputs (recomputed from the saved fp32 rows) - see runtime.set_activation_diet."""
     dt = runtime.compute_dtype()
     P = lambda n: params[spec.idx[n]]
     dev = params[0].device
@@ -236,7 +238,10 @@ def _tower_forward(spec, groups, dp_scale, params, save):
     depth = arch["depth_built"]
     Bf = sum(g.shape[0] for g in groups)
     M = Bf * N
-    plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
+    if plan is None:
+        plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
+    if arch["swiglu"]:
+        diet = 0      # (the SwiGLU towers keep everything: B/16 and L/14 frames are an order of magnitude smaller)
     x = _empty((M, D), torch.float32, dev)
     # ---- patch embedding: im2row + GEMM(+bias +pos, patch rows -> token rows) ; CLS rows ----
     pe_w, pe_b, pos = P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed")
@@ -301,7 +306,7 @@ def _tower_forward(spec, groups, dp_scale, params, save):
             x_mid = _empty((M, D), torch.float32, dev) if fmap1 is None else x
             _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=sc1,
                       rows_per_scale=N, row_map=fmap1, rows_per_map=N)
-            a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, ao=ao, lse=lse)
+            a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=None if diet >= 2 else ln1, qkv=qkv, ao=ao, lse=lse)
             x = x_mid
         # --- MLP branch ---
         B2, fmap2, sc2 = branch_io(i, 1)
@@ -343,8 +348,11 @@ def _tower_forward(spec, groups, dp_scale, params, save):
                 act = _empty((M2, Hd), dt, dev)
                 _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
                 _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), **epi)
-                a.update(h=h, act=act)
-            a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=ln2)
+                if diet == 0:
+                    a.update(h=h, act=act)
+                del h, act
+            a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=None if diet >= 2 else ln2,
+                     ln2b=ln2b if diet == 1 else None)
             x = x_out
         if save:
             acts.append(a)
@@ -439,6 +447,15 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 del dhln, dhsw, dx1, dx2, pend
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+                if "act" not in a:
+                    # activation diet: the LayerNorm output (level 2: from the saved fp32 rows - compact kept rows or the whole stream, in
+                    # either case exactly the M2 rows the forward normalised), then fc1 + GELU / GELU' exactly as the forward ran them
+                    ln2b = a["ln2b"]
+                    if ln2b is None:
+                        ln2b, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev)
+                    a["h"], a["act"] = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
+                    _gemm_fwd(ln2b, D, [w1], "w", a["act"], bias=P(b + "mlp.fc1.bias"), aux_out=a["h"], act=ops.ACT_GELU_SAVE_DERIV)
+                    del ln2b
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
                 _gemm_dx(g16, [w2], "w", dh, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
@@ -466,6 +483,8 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                                   dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
                                   grad_scale=inv_s, dtype=dt)
                 dao = dao2
+            if a["ln1"] is None:      # activation diet level 2
+                _, a["ln1"], _, _ = _ln16(a["x1"], P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev)
             qkv = a["qkv"]
             dqkv = _empty((M1, 3 * D), dt, dev)
             delta = _empty((B1, H, N), torch.float32, dev)
@@ -534,27 +553,53 @@ def _slice_groups(groups, c0, c1):
     return out
 
 
-def tower_chunk_frames(spec, n_frames, device):
-    """Frames per tower pass.  Saved activations cost depth * N * (20 D + 4 hidden) bytes per frame (542 MB for ViT-g/14:
-    two fp32 stream copies, LN outputs, qkv, attention output, the two MLP intermediates); when all frames do not fit in
-    the memory budget the tower runs in chunks: forward without saving (except the last chunk, whose activations are kept), and
-    in the backward the other chunks are recomputed with saving and differentiated - BASELINE configs[3] has 14 frames per
-    sample, 896 per GPU at b = 64."""
+def tower_plan(spec, n_frames, device, kept=1.0):
+    """-> (frames per tower pass, activation diet level).  Saved activations cost depth * N * (20 D + 4 hidden) bytes per kept frame (542 MB
+    for ViT-g/14: two fp32 stream copies, LN outputs, qkv, attention output, the two MLP intermediates).  When the step's frames do not fit
+    in the memory budget there are two ways to pay with recomputation, priced in tower-forward units:
+      * the activation diet - level 1 drops the MLP intermediates (4 hidden of the bytes; the backward re-runs fc1 + GELU: +0.33 of a tower
+        forward), level 2 the LayerNorm outputs as well (4 D; two more LayerNorm passes per block: +0.02);
+      * chunks - the tower runs in n equal chunks, forward without saving except for the last one, and in the backward the other chunks are
+        recomputed with saving and differentiated: +(n - 1) / n.
+    The cheapest combination that fits is taken: BASELINE configs[3] (14 frames per sample, 896 per GPU at b = 64, ~0.8 kept by stochastic
+    depth) runs in ONE pass at level 2 (166 GB of activations) where it used to take three chunks (+0.67).
+    kept: fraction of the (block, branch, frame) triples the step's stochastic-depth draw keeps (only those are evaluated and saved)."""
     if torch.device(device).type != "cuda":
         from ._lib import MicoHipError
         raise MicoHipError("the ViT tower runs on an MI355X device only (parameters are on %s): mico_amd has no CPU path" % device)
-    forced = runtime.tower_chunk_override()
-    if forced:
-        return forced
-    per_frame = spec.arch["depth_built"] * spec.N * (20 * spec.D + 4 * spec.hidden)
+    depth, N, D, Hd = spec.arch["depth_built"], spec.N, spec.D, spec.hidden
+    dietable = not spec.arch["swiglu"]
+    per_frame = {0: depth * N * (20 * D + 4 * Hd)}
+    if dietable:
+        per_frame[1] = depth * N * 20 * D
+        per_frame[2] = depth * N * 16 * D
+    extra = {0: 0.0, 1: 0.33, 2: 0.35}
+    forced_chunk, forced_diet = runtime.tower_chunk_override(), runtime.activation_diet_override()
+    levels = [forced_diet if forced_diet in per_frame else 0] if forced_diet is not None else sorted(per_frame)
+    if forced_chunk:
+        return forced_chunk, levels[0]
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)    # cached blocks are reusable
-    budget = int(0.70 * free)
-    if n_frames * per_frame <= budget:
-        return n_frames
-    most = max(1, budget // per_frame)
-    n_chunks = -(-n_frames // most)
-    return -(-n_frames // n_chunks)      # equal chunks: the one whose activations are kept is then as large as the others
+    # what the rest of the step needs next to the tower's saved activations - the backward's temporaries, BERT with its cross-attention K/V
+    # over frames x N condition tokens, the gradient arena: measured 23 GB at 320 frames (configs[2]: 162 GB peak, 139 GB of it activations)
+    # and 57 GB at 896 (one rank of configs[3]: 228 GB peak at level 2, 267 GB at level 1)
+    headroom = (12 << 30) + n_frames * (52 << 20)
+    budget = int(0.95 * max(free - headroom, free // 4))
+    kept = min(1.0, max(0.05, kept + 0.02))      # (a little slack: the draw differs from chunk to chunk)
+    best = None
+    for lv in levels:
+        pf = per_frame[lv] * kept
+        most = max(1, int(budget // pf))
+        n_chunks = -(-n_frames // most)
+        cost = extra[lv] + (n_chunks - 1) / n_chunks
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, -(-n_frames // n_chunks), lv)      # equal chunks: the one whose activations are kept is then as large as the others
+    return best[1], best[2]
+
+
+def tower_chunk_frames(spec, n_frames, device):
+    """Frames per tower pass (see tower_plan)."""
+    return tower_plan(spec, n_frames, device)[0]
 
 
 class EvaTowerFn(torch.autograd.Function):
@@ -568,12 +613,20 @@ class EvaTowerFn(torch.autograd.Function):
     def _forward(ctx, spec, groups, dp_scale, *params):
         Bf = sum(g.shape[0] for g in groups)
         needs_grad = any(ctx.needs_input_grad)    # False under torch.no_grad(): nothing is kept for a backward then
-        chunk = tower_chunk_frames(spec, Bf, params[0].device) if needs_grad else Bf
-        ctx.spec, ctx.params = spec, params
+        plan, chunk, diet = None, Bf, 0
+        if needs_grad:
+            plan = DropPlan(dp_scale, Bf, params[0].device) if dp_scale is not None else None
+            kept = plan.kept_fraction() if plan is not None else 1.0
+            chunk, diet = tower_plan(spec, Bf, params[0].device, kept)
+            runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet, kept_fraction=kept)
+        ctx.spec, ctx.params, ctx.diet = spec, params, diet
         if chunk >= Bf:
-            out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad)
+            out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad, diet=diet, plan=plan)
             ctx.chunked = None
             return out
+        if plan is not None:      # the chunks draw their own plans from their slices of dp_scale: this one only priced the step
+            DropPlan.stats[0] -= sum(plan.counts)
+            DropPlan.stats[1] -= len(plan.counts) * Bf
         outs = []
         ctx.saved = None
         starts = list(range(0, Bf, chunk))
@@ -581,7 +634,7 @@ class EvaTowerFn(torch.autograd.Function):
             c1 = min(Bf, c0 + chunk)
             sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
             keep = c0 == starts[-1]      # the last chunk's activations fit by construction: keep them, the backward starts there
-            o, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=keep)
+            o, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=keep, diet=diet)
             if keep:
                 ctx.saved = saved
             outs.append(o)
@@ -605,7 +658,7 @@ class EvaTowerFn(torch.autograd.Function):
                     saved, ctx.saved = ctx.saved, None
                 else:
                     sub_dp = dp_scale[:, :, c0:c1].contiguous() if dp_scale is not None else None
-                    _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True)
+                    _, saved = _tower_forward(spec, _slice_groups(groups, c0, c1), sub_dp, params, save=True, diet=ctx.diet)
                 _tower_backward(spec, params, saved, dout[c0:c1], grads, final=(c0 == starts[0]))
                 del saved
         return (None, None, None) + grads.result()

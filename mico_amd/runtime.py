@@ -309,6 +309,23 @@ def set_tower_chunk(frames):
     _tower_chunk = int(frames) if frames else None
 
 
+_activation_diet = None
+last_tower_plan = None      # (frames per pass, diet level, kept fraction, bytes per frame) of the most recent training-mode tower forward
+
+
+def activation_diet_override():
+    """Saved-activation level of the ViT tower forced by set_activation_diet (None = the cheapest level that fits the free memory)."""
+    return _activation_diet
+
+
+def set_activation_diet(level):
+    """0: keep everything the backward reads; 1: drop the two MLP intermediates (GELU output and GELU', 4 * hidden of the 20 D + 4 hidden
+    bytes per token and block) and recompute them in the backward with one fc1 GEMM; 2: also drop the LayerNorm outputs (recomputed from
+    the saved fp32 rows).  None: automatic (functional.tower_plan)."""
+    global _activation_diet
+    _activation_diet = None if level is None else int(level)
+
+
 _grad_slice_hook = None
 
 

@@ -128,3 +128,57 @@ def test_chunked_tower_recompute(cuda):
             assert set(g0) == set(g1)
             for n in g0:
                 assert rel_err(g1[n], g0[n]) < 2e-3, (chunk, use_dp, n, rel_err(g1[n], g0[n]))
+
+
+def test_activation_diet_recompute(cuda):
+    """runtime.set_activation_diet: level 1 drops the MLP intermediates (fc1 + GELU / GELU' re-run in the backward), level 2 the LayerNorm
+    outputs too (recomputed from the saved fp32 rows).  Plain-MLP tower (g/14 architecture), with and without stochastic depth (compact
+    kept-frame rows vs the whole stream as the saved LayerNorm input), also through chunks: the recomputed tensors are the forward's own
+    values, so outputs are identical and gradients agree to the summation order of the fp32 atomics."""
+    from mico_amd import runtime as rt
+    from mico_amd import functional as Fn
+    depth = 2
+    m, sd = build_model("evaclip01_giant", depth, device=cuda)
+    vis = m.vision_encoder.visual
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(3, 3, 224, 224, generator=g).to(cuda)
+    aud = torch.randn(2, 1, 224, 224, generator=g).to(cuda)
+    dps = _masks(depth, 5, 0.7, 23)
+    w = (torch.randn(5, 257, 1408, generator=g) / (5 * 257 * 1408) ** 0.5).to(cuda)
+    res = {}
+    try:
+        for diet, chunk in ((0, None), (1, None), (2, None), (2, 2)):
+            rt.set_activation_diet(diet)
+            rt.set_tower_chunk(chunk)
+            for use_dp in (False, True):
+                with rt.precision(torch.float16):
+                    m.zero_grad(set_to_none=True)
+                    out = vis.forward_groups([img, aud], drop_path_scale=dps if use_dp else None)
+                    assert rt.last_tower_plan["diet"] == diet
+                    (out * w).sum().backward()
+                res[(diet, chunk, use_dp)] = (out.detach().clone(), {n: p.grad.clone() for n, p in vis.named_parameters() if p.grad is not None})
+    finally:
+        rt.set_activation_diet(None)
+        rt.set_tower_chunk(None)
+    for use_dp in (False, True):
+        o0, g0 = res[(0, None, use_dp)]
+        for key in ((1, None), (2, None), (2, 2)):
+            o1, g1 = res[key + (use_dp,)]
+            assert torch.equal(o0, o1), (key, use_dp)
+            assert set(g0) == set(g1)
+            for n in g0:
+                assert rel_err(g1[n], g0[n]) < 2e-3, (key, use_dp, n, rel_err(g1[n], g0[n]))
+    # the plan: the cheapest combination that fits - everything fits here, so nothing is dropped
+    spec, _ = vis._tower_spec()
+    assert Fn.tower_plan(spec, 5, cuda) == (5, 0)
+    # and a step that cannot keep everything: one rank of BASELINE configs[3] on the full-depth architecture (896 frames, ~0.8 kept) - priced
+    # from the free memory of this box, it must come out as a single pass on the diet or as chunks, never as "keep everything in one pass"
+    import copy
+    big = copy.copy(spec)
+    big.arch = dict(spec.arch, depth_built=40)
+    chunk, diet = Fn.tower_plan(big, 896, cuda, kept=0.8)
+    free = torch.cuda.mem_get_info(cuda)[0] + torch.cuda.memory_reserved(cuda) - torch.cuda.memory_allocated(cuda)
+    per0 = 40 * 257 * (20 * 1408 + 4 * 6144)
+    if 896 * 0.82 * per0 > 0.72 * free:
+        assert diet > 0 or chunk < 896
+    print("configs[3] rank share on this box:", chunk, "frames per pass, diet", diet)
