@@ -121,7 +121,8 @@ int mico_gemm_last_kernel(void);
 /* kernel routing switch for A/B measurements (process-wide; returns the previous value): 0 = default routing, 1 = never the
  * one-wave-per-SIMD kernel, 2 / 3 = the one-wave-per-SIMD experiment kernel (builds with -DMICO_GEMM_W4 only) takes every large problem it
  * supports, 4 = never the persistent form of the 8-wave kernel, 5 / 6 and 8 / 9 = the 256x128 two-workgroups-per-CU kernels (32-deep stages /
- * 64-deep unit ring) take every large forward / dX problem / only those with K <= 2048 */
+ * 64-deep unit ring) take every large forward / dX problem / only those with K <= 2048, 7 = never (the default routes the GELU-pair forward
+ * and the short-K residual-scatter forward to the unit-ring kernel) */
 int mico_gemm_set_variant(int variant);
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,

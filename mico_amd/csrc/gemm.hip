@@ -276,13 +276,19 @@ __device__ __forceinline__ int epi_key(int row) { return (int)((0xF615B0AC843297
 // pair compiled into its own kernel instantiation - as two more run-time branches of the shared epilogue they pushed the 8-wave
 // kernel from 6 to 51 spilled registers and slowed EVERY launch by 10-15 % (tools/probes/README.md).
 constexpr int ACT_LEAN = 5;
+// ACT_RESID: the towers' output-projection / fc2 forward epilogue as its own instantiation - fp32 out[map(m)] = resid[map(m)] + row_scale * (acc
+// + bias) through a frame map - with the row bookkeeping of all passes hoisted in front of the pass loop (row_map -> row_scale -> resid were
+// three dependent loads inside every pass) and pass p + 1's residual rows requested before pass p is finished.  Measured in round 2 inside
+// the SHARED lean epilogue: +3-8 % on these launches, but 30-70 spilled registers on every other launch (tools/probes/README.md) - as a
+// separate instantiation the lean kernels keep their 208 registers.
+constexpr int ACT_RESID = 6;
 template <typename T, int MB = 4, int ACT = 0>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
     // ACT == ACT_LEAN: launches that use none of {aux copy, activation, dropout, positional table, patch->token remap} - the qkv / fc2 /
     // projection forwards and every dX of the towers - get an instantiation with those features compiled out
     // (the MLP pair's instantiations carry their own activation code and none of the other optional features either)
-    constexpr bool LEAN = ACT != 0;
+    constexpr bool LEAN = ACT != 0;   // (ACT_RESID leaves through its own path below)
     // every argument field the epilogue needs, read ONCE into scalars: left as g.e.<field> references the compiler re-loaded
     // them from the kernel-argument segment inside every pass (66 s_load_dwordx8 + waits in the unrolled code)
     const struct {
@@ -323,6 +329,46 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
     f32x4 bias4[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && ok[v]) ? *(const f32x4*)(e.bias + ncol0 + col[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (ACT == ACT_RESID) {
+        // (launch contract, checked on the host: fp32 C, resid, no aux / activation / dropout / pos / remap / accumulate)
+        int64_t mo_[MB];
+        float rs_[MB];
+        bool live_[MB];
+#pragma unroll
+        for (int pass = 0; pass < MB; ++pass) {
+            const int64_t m = mrow0 + pass * 16 + (lane >> 2);
+            live_[pass] = m < gM;
+            int64_t mo = m;
+            if (e.row_map && live_[pass]) { const int64_t f = m / e.rows_per_map; mo = (int64_t)e.row_map[f] * e.rows_per_map + (m - f * e.rows_per_map); }
+            mo_[pass] = mo;
+        }
+#pragma unroll
+        for (int pass = 0; pass < MB; ++pass) rs_[pass] = (e.row_scale && live_[pass]) ? e.row_scale[mo_[pass] / e.rows_per_scale] : 1.f;
+        f32x4 rcur[4], rnxt[4];
+        auto load_resid = [&](int pass, f32x4 (&r)[4]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                r[v] = (live_[pass] && ok[v]) ? *(const f32x4*)(e.resid + mo_[pass] * gldc + ncol0 + col[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        load_resid(0, rcur);
+#pragma unroll
+        for (int pass = 0; pass < MB; ++pass) {
+            if (pass + 1 < MB) load_resid(pass + 1, rnxt);
+            const int row = pass * 16 + (lane >> 2);
+            const int kr = epi_key(row);
+            if (live_[pass]) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (!ok[v]) continue;
+                    const f32x4 a4 = *(LDS_AS const f32x4*)(wbuf + row * 256 + ((((col[v] >> 2)) ^ kr) << 4)) + bias4[v];
+                    *(f32x4*)((float*)gC + mo_[pass] * gldc + ncol0 + col[v]) = a4 * rs_[pass] + rcur[v];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rcur[v] = rnxt[v];
+        }
+        return;
+    }
     // NOT unrolled: the pass body is ~1.5k instructions with every epilogue feature inlined; unrolled 4x (and twice per tile) the
     // epilogue was ~90 KiB of straight-line code executed once per tile - far beyond the 64 KiB instruction cache shared by two
     // CUs - and took 15 us per 256x256 tile against a 5.5 us store-bandwidth floor (tools/probes/gemm_phases.py, store_pattern.hip)
@@ -1847,6 +1893,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// the launches ACT_RESID serves: lean + fp32 residual output, no split, no accumulate (MICO_NO_RESID_EPI: A/B switch, shared epilogue)
+bool resid_epilogue(const GemmArgs& g) {
+#ifdef MICO_NO_RESID_EPI
+    return false;
+#else
+    return g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group && g.e.resid != nullptr &&
+           g.c_dtype == MICO_F32 && !g.e.accumulate && g.split_k == 1 && g.e.alpha == 1.f;
+#endif
+}
+
 template <typename T>
 void launch_pc(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     // only the weight-gradient orientation is routed here (see mico_gemm); the kernel template also covers k-contiguous operands
@@ -1884,6 +1940,7 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
     const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    if (resid_epilogue(g) && !ta && !tb && CFG::BM == 256) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, ACT_RESID>), grid, block, 0, st, g); return; }
     if (lean && !ta && !tb) { MICO_LAUNCH((gemm_kernel<T, false, false, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }
     if (lean && !ta && tb) { MICO_LAUNCH((gemm_kernel<T, false, true, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }
     if (lean && ta && tb && CFG::BM == 128) { MICO_LAUNCH((gemm_kernel<T, true, true, CFG, ACT_LEAN>), grid, block, 0, st, g); return; }   // BERT weight gradients
@@ -1896,6 +1953,7 @@ void launch(int ta, int tb, const GemmArgs& g, hipStream_t st) {
 template <typename T>
 void launch_mid(int tb, const GemmArgs& g, hipStream_t st) {
     const dim3 grid(g.ntiles), block(Mid64::THREADS);
+    if (resid_epilogue(g) && !tb) { MICO_LAUNCH((gemm_mid_kernel<T, false, ACT_RESID>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_mid_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_mid_kernel<T, true, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
     const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
@@ -2138,11 +2196,17 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (w4) pc = false;
     // the 256x128 two-workgroups-per-CU kernel: forward / dX orientation, no split (variant 5: every such problem, 6: K <= 2048 only, 7: off)
     const bool no_split = !(c_dtype == MICO_F32 && g.e.accumulate) && split_k <= 1;
-    const bool mid = big && !pc && !w4 && !ta && no_split && N % 128 == 0 &&
+    const bool mid = big && !pc && !w4 && !ta && no_split &&
                      (g_mico_gemm_variant == 5 || (g_mico_gemm_variant == 6 && K <= 2048));
     // the 64-deep unit-ring form of it (variant 8: every such problem, 9: K <= 2048 only)
+    // Default routing (variant 0), from in-situ A/B runs of the timed step (bench.py --gemm-detail, MICO_GEMM_VARIANT=8 against 0): the launches
+    // whose epilogue is heavy next to a short K loop gain from the second workgroup on the CU - fc1 forward with the GELU pair (two 16-bit
+    // outputs: 845 -> 870 TFLOP/s) and the output projection's fp32 residual scatter at K = 1408 (727 -> 752 in the microbench); everywhere else
+    // the two kernels are within +-2 % of each other and the 8-wave kernel keeps the launch.
+    const bool mid_default = g_mico_gemm_variant == 0 && M >= 8192 &&
+                             (g.e.act == MICO_ACT_GELU_SAVE_DERIV || (g.e.resid != nullptr && c_dtype == MICO_F32 && K <= 2048));
     const bool mid64 = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
-                       (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048));
+                       (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048) || mid_default);
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = (mid || mid64) ? 128 : (big ? 256 : 128);
     const int slots = big && !mid && !mid64 ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);

@@ -177,8 +177,6 @@ def test_activation_diet_recompute(cuda):
     big = copy.copy(spec)
     big.arch = dict(spec.arch, depth_built=40)
     chunk, diet = Fn.tower_plan(big, 896, cuda, kept=0.8)
-    free = torch.cuda.mem_get_info(cuda)[0] + torch.cuda.memory_reserved(cuda) - torch.cuda.memory_allocated(cuda)
-    per0 = 40 * 257 * (20 * 1408 + 4 * 6144)
-    if 896 * 0.82 * per0 > 0.72 * free:
-        assert diet > 0 or chunk < 896
+    assert diet > 0 or chunk < 896          # 896 x 0.82 x 542 MB = 398 GB of level-0 activations exceed the 288 GB of an MI355X
+    assert chunk * 0.82 * 40 * 257 * {0: 20 * 1408 + 4 * 6144, 1: 20 * 1408, 2: 16 * 1408}[diet] < torch.cuda.mem_get_info(cuda)[1]
     print("configs[3] rank share on this box:", chunk, "frames per pass, diet", diet)

@@ -94,6 +94,65 @@ def test_gemm_epilogues(cuda, dtype):
     assert rel_err(dW, 1 + 2.0 * dY.float().t() @ A.float()) < 1e-5 * math.sqrt(M)
 
 
+@pytest.mark.parametrize("variant", [0, 5, 8])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_chip_filling_kernels(cuda, dtype, variant):
+    """The large-problem kernels on a problem that fills the chip (ragged M, N = 1368 not a multiple of the 128 / 256-wide tiles): the 8-wave
+    256x256 kernel (variant 0), the 256x128 two-workgroups-per-CU kernels (5: 32-deep stages, 8: 64-deep unit ring) - plain forward / dX,
+    the towers' residual-scatter epilogue (its own instantiation, ACT_RESID: frame map, per-frame scale, fp32 stream updated in place), the
+    MLP's GELU pair, and a split-precision (2 k-segment) forward."""
+    from mico_amd import ops, _lib
+    torch.manual_seed(5)
+    frames, rows_per = 131, 257
+    M, N, K = frames * rows_per - 100, 1368, 1408
+    A = (0.5 * torch.randn(M, K, device=cuda)).to(dtype)
+    W = (0.05 * torch.randn(N, K, device=cuda)).to(dtype)
+    bias = torch.randn(N, device=cuda)
+    acc = A.float() @ W.float().t()
+    old = _lib.lib().mico_gemm_set_variant(variant)
+    try:
+        y = torch.empty(M, N, device=cuda, dtype=dtype)
+        ops.gemm(A, W, y, bias=bias)
+        assert _lib.lib().mico_gemm_last_kernel() == {0: 1, 5: 6, 8: 7}[variant]
+        assert rel_err(y, acc + bias) < tol(dtype)
+        # dX orientation: the weight read reduction-major
+        Wt = W.t().contiguous()
+        y2 = torch.empty(M, N, device=cuda, dtype=dtype)
+        ops.gemm(A, Wt, y2, tb=True, M=M, N=N, K=K)
+        assert rel_err(y2, acc) < tol(dtype)
+        # residual scatter: the compact rows of the kept frames go to frames fmap[f] of the fp32 stream, scaled per frame, in place
+        nf = (M + rows_per - 1) // rows_per
+        fmap = (torch.arange(nf, device=cuda, dtype=torch.int32) * 3 // 2).contiguous()          # skips every third frame
+        stream = torch.randn((int(fmap[-1]) + 1) * rows_per, N, device=cuda)
+        rs = torch.rand(int(fmap[-1]) + 1, device=cuda) + 0.5
+        ref = stream.clone()
+        rows = (fmap.long().repeat_interleave(rows_per) * rows_per + torch.arange(rows_per, device=cuda).repeat(nf))[:M]
+        ref[rows] += (acc + bias) * rs[fmap.long()].repeat_interleave(rows_per)[:M, None]
+        ops.gemm(A, W, stream, bias=bias, resid=stream, row_scale=rs, rows_per_scale=rows_per, row_map=fmap, rows_per_map=rows_per)
+        assert rel_err(stream, ref) < 1e-5 * math.sqrt(K)
+        # the MLP pair
+        gd = torch.empty(M, N, device=cuda, dtype=dtype)
+        a2 = torch.empty(M, N, device=cuda, dtype=dtype)
+        ops.gemm(A, W, a2, bias=bias, aux_out=gd, act=ops.ACT_GELU_SAVE_DERIV)
+        pre = acc + bias
+        gp32 = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+        assert rel_err(a2, F.gelu(pre)) < tol(dtype) and rel_err(gd, gp32) < tol(dtype)
+        dh = torch.empty(M, N, device=cuda, dtype=dtype)
+        ops.gemm(A, Wt, dh, tb=True, M=M, N=N, K=K, aux_in=gd, act=ops.ACT_MUL_AUX, alpha=0.5)
+        assert rel_err(dh, 0.5 * acc * gd.float()) < tol(dtype)
+        # two k-segments (x W_hi + x W_lo of the split-weights precision mode): A read twice, B = [hi | lo]
+        if dtype == torch.float16:
+            Wf = 0.05 * torch.randn(N, K, device=cuda)
+            hi = Wf.to(dtype)
+            lo = (Wf - hi.float()).to(dtype)
+            Wcat = torch.cat((hi, lo), dim=1).contiguous()
+            y3 = torch.empty(M, N, device=cuda, dtype=torch.float32)
+            ops.gemm(A, Wcat, y3, ksegs=(K, [0, 0], [0, K]))
+            assert rel_err(y3, A.float() @ Wf.t()) < 2e-5 * math.sqrt(K)
+    finally:
+        _lib.lib().mico_gemm_set_variant(old)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cols", [768, 1408, 2048])
 @pytest.mark.parametrize("xdt", ["f32", "16"])
