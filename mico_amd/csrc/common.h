@@ -73,6 +73,16 @@ template <> struct T16<bf16> {
     }
 };
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 32x32x16: lane l supplies row l & 31 of each operand, k = 8 (l >> 5) .. + 7; D[i][j]: j = l & 31, i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+template <typename T> __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma32<f16>(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma32<bf16>(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 

@@ -82,6 +82,9 @@ constexpr int GROUP_M = MICO_GROUP_M;
 #ifndef MICO_MID_DB   // MID kernel: both k-steps' fragments of a K-tile read up front (48 more registers): layer forward 951 -> 985, dX 989 -> 1040 TFLOP/s
 #define MICO_MID_DB 1
 #endif
+#ifndef MICO_MID_M32   // MID kernel, forward orientation: 32x32x16 MFMAs instead of 16x16x32 (VERDICT r2 lever (a))
+#define MICO_MID_M32 0
+#endif
 #ifndef MICO_MID_PRIO   // MID kernel: 1 = static priority for alternate rounds of workgroups, 2 = s_setprio(1) around the MFMA bursts
 #define MICO_MID_PRIO 0
 #endif
@@ -282,7 +285,9 @@ constexpr int ACT_LEAN = 5;
 // the SHARED lean epilogue: +3-8 % on these launches, but 30-70 spilled registers on every other launch (tools/probes/README.md) - as a
 // separate instantiation the lean kernels keep their 208 registers.
 constexpr int ACT_RESID = 6;
-template <typename T, int MB = 4, int ACT = 0>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
+// M32: the accumulators come from 32x32x16 MFMAs (operands swapped like the 16x16 kernels: lane l holds output row l & 31 and the four
+// 4-column groups 8 rg + 4 (l >> 5) of a 32x32 tile): `acc` then points at the block's [2 row-tiles][2 column-tiles][4 groups] f32x4 values.
+template <typename T, int MB = 4, int ACT = 0, bool M32 = false>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
     // ACT == ACT_LEAN: launches that use none of {aux copy, activation, dropout, positional table, patch->token remap} - the qkv / fc2 /
@@ -300,7 +305,19 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
            g.e.drop_p, g.e.drop_seed, g.e.drop_site};
     const int64_t gM = g.M, gN = g.N, gldc = g.ldc;
     char* const gC = g.C;
-    {
+    if constexpr (M32) {
+        static_assert(MB == 4, "32x32 accumulator blocks are 64 rows");
+        const int r = lane & 31, hh = lane >> 5, kp = epi_key(r);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int row = mi * 32 + r, cc = nj * 8 + 2 * rg + hh;
+                    *(LDS_AS f32x4*)(wbuf + row * 256 + ((cc ^ kp) << 4)) = acc[mi * 2 + nj][rg] * e.alpha;
+                }
+    } else {
         const int p = lane & 15, gq = lane >> 4, kp = epi_key(p);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -960,6 +977,7 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
     __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
 
+    constexpr bool M32 = MICO_MID_M32 && !TB;   // 32x32x16 MFMAs (forward orientation: both operands k-contiguous)
     f32x4 acc[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -968,6 +986,11 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
 
     // fragment addressing inside a unit: a wave reads all 128 rows of ITS A unit (wm picks the unit) and 64 of the B unit's 128 rows / columns
     const FragBase ab = frag_base<false, 128, BK>(0, lane), bb = frag_base<TB, 128, BK>(wn * 64, lane);
+    // 32x32x16 fragments: row l & 31 of a 32-row tile, 16-byte chunk 2 ks + (l >> 5) of the row's 64 k (k-step ks of 16); the swizzle key
+    // (row >> 1) & 7 does not depend on the tile, so one base per k-step serves both operands (+ tile * 4096 bytes)
+    int b32[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b32[ks] = (lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4);
     unsigned voa[UD], vob[UD];
     dma_offsets<false, 128, THREADS, BK, UD>(voa, wave, lane, lda_b, 128);
     dma_offsets<TB, 128, THREADS, BK, UD>(vob, wave, lane, ldb_b, g.N - n0);
@@ -1002,13 +1025,33 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
     auto read_k = [&](int sa, int sb, int kk) {
         LDS_AS const char* ta = lds + sa * UNIT;
         LDS_AS const char* tb = lds + sb * UNIT;
-        const int abase = kk ? ab.b1 : ab.b0, bbase = kk ? bb.b1 : bb.b0;
         const int s = MICO_MID_DB ? kk : 0;
+        if constexpr (M32) {   // half kk of the K-tile = k-steps 2 kk, 2 kk + 1 of 16: fa[s][ks2 * 4 + mi], fb[s][ks2 * 2 + nj]
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const int bs = (kk * 2 + ks2 == 0) ? b32[0] : (kk * 2 + ks2 == 1) ? b32[1] : (kk * 2 + ks2 == 2) ? b32[2] : b32[3];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) fa[s][ks2 * 4 + mi] = *(LDS_AS const s16x8*)(ta + bs + mi * 4096);
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) fb[s][ks2 * 2 + nj] = *(LDS_AS const s16x8*)(tb + bs + (wn * 64 + nj * 32) * 128);
+            }
+            return;
+        }
+        const int abase = kk ? ab.b1 : ab.b0, bbase = kk ? bb.b1 : bb.b0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[s][i] = read_frag_b<false, 128, BK>(ta, abase, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[s][j] = read_frag_b<TB, 128, BK>(tb, bbase, j);
     };
+    f32x16 acc32[4][2];
+    if constexpr (M32) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[mi][nj][r] = 0.f;
+    }
     auto mma_k = [&](int kk) {
         const int s = MICO_MID_DB ? kk : 0;
         if (MICO_GEMM_ABLATE == 3 && g.K > 0) {   // ablation: no MFMA (keep operands live)
@@ -1016,6 +1059,15 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
             for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[s][i]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[s][j]));
+            return;
+        }
+        if constexpr (M32) {
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj) acc32[mi][nj] = mfma32<T>(fb[s][ks2 * 2 + nj], fa[s][ks2 * 4 + mi], acc32[mi][nj]);
             return;
         }
         if (MICO_MID_PRIO == 2) __builtin_amdgcn_s_setprio(1);
@@ -1078,6 +1130,22 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
         if (cs >= 5) cs -= 5;
     }
     __syncthreads();   // every wave is done with the operand units (and the DMA queue is empty) before LDS is reused
+    if constexpr (M32) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 blk[4][4];   // [row-tile mi * 2 + column-tile nj][4-column group rg] of the 64x64 block
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        blk[mi * 2 + nj][rg] = (f32x4){acc32[h * 2 + mi][nj][rg * 4], acc32[h * 2 + mi][nj][rg * 4 + 1], acc32[h * 2 + mi][nj][rg * 4 + 2],
+                                                       acc32[h * 2 + mi][nj][rg * 4 + 3]};
+            gemm_epilogue_block<T, 4, ACT, true>(g, blk, lds + wave * 16384, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
 }

@@ -154,20 +154,20 @@ def _mx8_worthwhile(m, n):
     return ((m + 255) // 256) * ((n + 255) // 256) >= 128
 
 
-def _gemm_fwd(a_buf, a_cols, plist, tag, out, k_pad=None, n_pad=None, **epi):
+def _gemm_fwd(a_buf, a_cols, plist, tag, out, k_pad=None, n_pad=None, ln=True, **epi):
     """Forward GEMM out = a W^T: plain in the bf16 configuration; in the fp16 parity configuration the weight is hi|lo split
     (and the activation too when its producer emitted [hi | lo]) and the products are summed by one k-segmented launch."""
     if runtime.fp8_enabled() and a_cols % 128 == 0 and "pos" not in epi and not k_pad and not n_pad and _mx8_worthwhile(a_buf.shape[0], out.shape[1]):
         # configs[4]: block-scaled fp8 MFMA.  The activation is quantised here in a pass of its own (5 TB/s; fusing it into the producing
         # LayerNorm / GELU epilogue is the next step), the weight's fp8 copy is cached per optimizer step.
         return ops.gemm_mx8(ops.quant_mx8(a_buf[:, :a_cols]), runtime.gemm_weight_mx8(plist, tag), out, dtype=a_buf.dtype, **epi)
-    w, ks = runtime.gemm_weight(plist, tag, k_pad=k_pad, n_pad=n_pad)
+    w, ks = runtime.gemm_weight(plist, tag, k_pad=k_pad, n_pad=n_pad, ln_fed=ln)
     if ks is not None and a_buf.shape[1] == 2 * a_cols and a_cols == ks[0]:
         ks = (ks[0], [0, a_cols, 0], [0, 0, ks[0]])
     return ops.gemm(a_buf[:, :a_cols], w, out, ksegs=ks, **epi)
 
 
-def _gemm_dx(dy16, plist, tag, out, k_pad=None, n_pad=None, **epi):
+def _gemm_dx(dy16, plist, tag, out, k_pad=None, n_pad=None, ln=True, **epi):
     """Input gradient out = epilogue(dy W), W = the rows of `plist` concatenated ([N_out, K_in]): 16-bit MFMA reading W reduction-major
     (no transposed copy), or - configs[4] - the block-scaled fp8 MFMA on dy and a transposed fp8 copy of W, both quantised along N_out."""
     n_out = n_pad or sum(p.shape[0] for p in plist)          # (padded hidden widths: zero rows / columns behind the parameter's own)
@@ -176,7 +176,7 @@ def _gemm_dx(dy16, plist, tag, out, k_pad=None, n_pad=None, **epi):
         return ops.gemm(dy16, runtime.gemm_weight(plist, tag, k_pad=k_pad, n_pad=n_pad)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
     if runtime.fp8_enabled() and n_out % 128 == 0 and _mx8_worthwhile(dy16.shape[0], k_in):
         return ops.gemm_mx8(ops.quant_mx8(dy16), runtime.gemm_weight_mx8(plist, tag, transposed=True), out, dtype=dy16.dtype, **epi)
-    return ops.gemm(dy16, runtime.gemm_weight(plist, tag)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
+    return ops.gemm(dy16, runtime.gemm_weight(plist, tag, ln_fed=ln)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
 
 
 def _qkv_params(P, b, arch):
@@ -305,7 +305,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
             # scatters the kept frames onto the stream in place and the LN's compact copy (xc1) is what is saved
             x_mid = _empty((M, D), torch.float32, dev) if fmap1 is None else x
             _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=sc1,
-                      rows_per_scale=N, row_map=fmap1, rows_per_map=N)
+                      rows_per_scale=N, row_map=fmap1, rows_per_map=N, ln=bool(arch["subln"]))
             a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=None if diet >= 2 else ln1, qkv=qkv, ao=ao, lse=lse)
             x = x_mid
         # --- MLP branch ---
@@ -347,7 +347,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
                 h = _empty((M2, Hd), dt, dev)
                 act = _empty((M2, Hd), dt, dev)
                 _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
-                _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), **epi)
+                _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), ln=False, **epi)
                 if diet == 0:
                     a.update(h=h, act=act)
                 del h, act
@@ -458,7 +458,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                     del ln2b
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                _gemm_dx(g16, [w2], "w", dh, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
+                _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
                 linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
                 _gemm_dx(dh, [w1], "w", dln2)
                 del dh
@@ -476,7 +476,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             proj_in = a["aln"] if arch["subln"] else a["ao"]
             linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s, dbias=G(b + "attn.proj.bias"))
             dao = _empty((M1, D), dt, dev)
-            _gemm_dx(g16, [wp], "w", dao)
+            _gemm_dx(g16, [wp], "w", dao, ln=bool(arch["subln"]))
             if arch["subln"]:
                 dao2 = _empty((M1, D), dt, dev)
                 ops.layernorm_bwd(dao, a["ao"], P(b + "attn.inner_attn_ln.weight"), a["mean_a"], a["rstd_a"], dx16=dao2,

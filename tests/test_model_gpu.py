@@ -82,7 +82,7 @@ def test_vit_tower_head_split(setup, cuda, chunk):
     named = dict(m.vision_encoder.visual.named_parameters())
     worst = max(grad_digest_check(d, named[n].grad, None) for n, d in fx["grads"].items())
     print(f"{tag} head-split fwd rel err {e:.2e} worst grad err {worst:.2e}")
-    assert e < 1.3e-3 and worst < GRAD_TOL[torch.float16]      # depth-2 towers in plain fp16: 0.6-1.2e-3 (B/16 is the noisier one)
+    assert e < FWD_TOL[torch.float16] and worst < GRAD_TOL[torch.float16]      # the gate itself (measured: B/16 6.1e-4, g/14 4.6e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

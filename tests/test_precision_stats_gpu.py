@@ -53,4 +53,9 @@ def test_bench_precision_over_inputs(cuda):
     # feat_v 7.8e-4 / 9.2e-4; plain fp16 everywhere: 8.8e-4 / 1.0e-3 and 9.2e-4 / 1.09e-3 - at the gate, like the reference's own fp16
     # autocast at 8.4e-4)
     assert sum(a for a, _ in e) / len(e) < 9e-4 and sum(b for _, b in e) / len(e) < 9e-4, e
-    assert max(a for a, _ in e) < 1.05e-3 and max(b for _, b in e) < 1.05e-3, e
+    # every image under the gate itself (the bound used to sit at 1.05e-3).  Round 3 looked for a cheap configuration with
+    # more margin (8 images: max tokens / feat_v): first 8 blocks weights-split 8.4e-4 / 8.9e-4, 16 blocks 8.2e-4 / 8.2e-4, LN-fed GEMMs only
+    # (qkv + fc1) in 8 / 12 / 16 / 40 blocks 9.0e-4 / 1.14e-3 ... 8.1e-4 / 1.10e-3 (worse on feat_v), first 8 / 16 blocks in the 3-segment mode
+    # 7.8e-4 / 8.7e-4 and 7.2e-4 / 6.9e-4 - the error follows the MFMA work spent, there is no cheap margin: fp16 operands round the
+    # LayerNorm outputs, qkv, attention probabilities / outputs and the GELU output of every block, the weights are one source of seven.
+    assert max(a for a, _ in e) < 1e-3 and max(b for _, b in e) < 1e-3, e
