@@ -89,26 +89,48 @@ __device__ __forceinline__ void row_frags(s16x8 (&f)[Cfg<HDP>::KS], const T* bas
     }
 }
 
+// chunk-swizzle key of a row of the 256-byte-row tile images.  KM 0: 2 (row & 7) - the tiled kernels and the 16x16-MFMA resident kernels
+// (conflict free for their ds_read_b128 / transposing access patterns, see Cfg).  KM 1: the bit pairs of row & 15 swapped - the 32x32-MFMA
+// kernels: a ds_read_b128 lane group then holds 16 rows with ONE chunk index (16 distinct keys), and the four consecutive rows of a
+// transposing read land in four different 64-byte windows.
+template <int KM> __device__ __forceinline__ int swz_key(int row) {
+    return KM == 0 ? ((row & 7) << 1) : (((row & 3) << 2) | ((row >> 2) & 3));
+}
 // A-operand fragment of a row-major LDS tile: rows r0 + (lane&15), head-dim chunk ks
-template <int HDP>
+template <int HDP, int KM = 0>
 __device__ __forceinline__ s16x8 lds_row_frag(LDS_AS const char* tile, int r0, int ks, int lane) {
     const int row = r0 + (lane & 15), ch = ks * 4 + (lane >> 4);
-    return *(LDS_AS const s16x8*)(tile + row * Cfg<HDP>::RS + ((ch ^ ((row & 7) << 1)) << 4));
+    return *(LDS_AS const s16x8*)(tile + row * Cfg<HDP>::RS + ((ch ^ swz_key<KM>(row)) << 4));
 }
 // A-operand fragment of the TRANSPOSED tile: output rows d = td*16 + (lane&15), reduction slots over tile rows
 // (2*s2 + r2)*16 + (lane>>4)*4 + {0..3}
-template <int HDP>
+template <int HDP, int KM = 0>
 __device__ __forceinline__ s16x8 lds_tr_frag(LDS_AS const char* tile, int td, int s2, int lane) {
     const int g = lane >> 4, p = lane & 15;
     const int ch = td * 2 + ((p >> 1) & 1), half = (p & 1) * 8;
-    const int r_lo = (2 * s2) * 16 + g * 4 + (p >> 2);   // rows r_lo and r_lo + 16 share (row & 7), hence the swizzle key
-    const int col_b = ((ch ^ ((r_lo & 7) << 1)) << 4) + half;
+    const int r_lo = (2 * s2) * 16 + g * 4 + (p >> 2);   // rows r_lo and r_lo + 16 share (row & 15), hence the swizzle key
+    const int col_b = ((ch ^ swz_key<KM>(r_lo)) << 4) + half;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + r_lo * Cfg<HDP>::RS + col_b));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + (r_lo + 16) * Cfg<HDP>::RS + col_b));
     s16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
+}
+
+// one LDS-DMA piece (16 bytes per lane, lane-linear destination starting at the wave-uniform LDS byte address lds_dst) issued by inline assembly
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned voffset) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voffset), "s"(dst), "s"(rsrc) : "memory");
+}
+
+// a pointer the compiler can see is wave-uniform (buffer descriptors must live in SGPRs)
+__device__ __forceinline__ void* uniform_ptr(const void* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
 }
 
 template <typename T>
@@ -1265,7 +1287,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
 // K / V fragments in registers), and nothing synchronises inside the query loop.  Keys 256.. (the 257th token) form one more 16-key block
 // that is split over the QUERIES: wave t takes query tile t, the partial dK / dV rows are summed through LDS.
 // ======================================================================================================================
-template <typename T, int HDP>
+template <typename T, int HDP, int KM = 0>
 __device__ __forceinline__ void dkv_tile(LDS_AS const char* qt, LDS_AS const char* dot, LDS_AS const float* lse_t, LDS_AS const float* del_t,
                                          const int nti, const bool fast, const int i0, const int j, const int Sq, const int Sk, const float sc2,
                                          const float scale, const s16x8 (&kf)[Cfg<HDP>::KS], const s16x8 (&vf)[Cfg<HDP>::KS],
@@ -1280,8 +1302,8 @@ __device__ __forceinline__ void dkv_tile(LDS_AS const char* qt, LDS_AS const cha
         if (ti < nti) {
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
-                s[ti] = T16<T>::mfma(lds_row_frag<HDP>(qt, ti * 16, ks, lane), kf[ks], s[ti]);
-                dp[ti] = T16<T>::mfma(lds_row_frag<HDP>(dot, ti * 16, ks, lane), vf[ks], dp[ti]);
+                s[ti] = T16<T>::mfma(lds_row_frag<HDP, KM>(qt, ti * 16, ks, lane), kf[ks], s[ti]);
+                dp[ti] = T16<T>::mfma(lds_row_frag<HDP, KM>(dot, ti * 16, ks, lane), vf[ks], dp[ti]);
             }
         }
     }
@@ -1305,8 +1327,8 @@ __device__ __forceinline__ void dkv_tile(LDS_AS const char* qt, LDS_AS const cha
         const s16x8 df = pack_pair<T>(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
         for (int td = 0; td < C::TD; ++td) {
-            dvacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(dot, td, s2, lane), pf, dvacc[td]);
-            dkacc[td] = T16<T>::mfma(lds_tr_frag<HDP>(qt, td, s2, lane), df, dkacc[td]);
+            dvacc[td] = T16<T>::mfma(lds_tr_frag<HDP, KM>(dot, td, s2, lane), pf, dvacc[td]);
+            dkacc[td] = T16<T>::mfma(lds_tr_frag<HDP, KM>(qt, td, s2, lane), df, dkacc[td]);
         }
     }
 }
@@ -1457,6 +1479,499 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_res_kernel(const T* __res
     }
 }
 
+// ======================================================================================================================
+// backward dK / dV on 32x32x16 MFMAs (round 3; hd 65..96, i.e. the g/14 towers).  Same residency as attn_bwd_dkv_res_kernel - persistent 8-wave
+// workgroups, Q and dO of one (b, h) in LDS - but a wave owns 32 keys as ONE block: K / V fragments of the 32x32x16 operand layout in
+// registers (2 x 6 k-steps of 16 head dims), query tiles of 32.  Per (32 queries x 32 keys): 6 + 6 MFMAs for S and dP, 6 + 6 for dV^T / dK^T
+// = 24 MFMAs of 32 cycles on 12 ds_read_b128 + 24 transposing reads - half the LDS bytes per MFMA cycle of the 16x16 kernel (where every
+// fragment fed one MFMA), a quarter of the MFMA instructions, and the softmax statistics are ONE value per lane and tile (lane = key column of
+// the score tile would need a value per register; here S is computed as Q K^T with lane = key, registers = queries, so P / dS are already the
+// B operands of dV^T = dO^T P and dK^T = Q^T dS, and lse / delta are read per register row ... see the layout notes below).
+// Layout: S[q][key] = mfma32(A = Q rows (LDS, row = query), B = K fragment (lane l: key l & 31, dims 16 ks + 8 (l >> 5) ..)): lane l holds key
+// l & 31 and queries i(r) = (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15.  Registers 0-7 / 8-15 are the B operands of two MFMAs over queries
+// 0-15 / 16-31 of the tile: slot (h, e) <-> query 16 m + 4 h + (e & 3) + 8 (e >> 2); the A operands dO^T / Q^T follow the same numbering with
+// two transposing reads per fragment (4 consecutive queries each, 8 rows apart).
+// Key 256 (the 257th token) keeps the 16x16 path of the kernel above, split over the query tiles.
+// ======================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkv_res32_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                                    const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                                    const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
+                                                                    const mico_attn_params p) {
+    constexpr int HDP = 96, KM = 1;
+    using C = Cfg<HDP>;
+    constexpr int CPR = HDP / 8, QR = RES_KR, RS = C::RS;
+    constexpr int NLD = (QR * CPR + 511) / 512;
+    constexpr int NKS = HDP / 16;   // k-steps of 16 head dims (6)
+    constexpr int NTD = HDP / 32;   // 32-wide head-dim tiles (3)
+    __shared__ __attribute__((aligned(16))) char smem[2 * QR * RS + 2 * QR * 4 + 8 * 2 * HDP * 4];
+    LDS_AS char* qt = (LDS_AS char*)smem;
+    LDS_AS char* dot = qt + QR * RS;
+    LDS_AS float* lse_t = (LDS_AS float*)(dot + QR * RS);
+    LDS_AS float* del_t = lse_t + QR;
+    LDS_AS float* part = del_t + QR;   // [wave][dK | dV][HDP]: partial rows of key 256
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const int nitems = p.B * p.H;
+#ifndef MICO_DKV_ABL   // ablation builds (tools/probes): 1 = no tile loop (the load / stage / store skeleton), 2 = no global loads (compute only)
+#define MICO_DKV_ABL 0
+#endif
+    const int nt64 = (p.Sq + 63) / 64, nt32 = MICO_DKV_ABL == 1 ? 0 : (p.Sq + 31) / 32;
+    const bool ragged = p.Sk > 256 && MICO_DKV_ABL == 0;
+    // per-lane LDS offsets.  Row fragments: row l & 31 of a 32-query tile, chunk 2 ks + (l >> 5).
+    const int r31 = lane & 31, hh = lane >> 5, key_r = swz_key<KM>(r31);
+    int rfo[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) rfo[ks] = r31 * RS + (((ks * 2 + hh) ^ key_r) << 4);
+    // Transposed fragments: 16-lane group u = l >> 4 reads the block [4 queries][16 head dims]: head dims 32 td + 16 (u & 1) + .., queries
+    // 16 m + 4 (u >> 1) + (p >> 2) (first read) and 8 rows further (second read); lane p points at [row p >> 2][dims 4 (p & 3) ..].
+    int tfo[NTD][2];
+    {
+        const int pp = lane & 15, u = lane >> 4;
+        const int row0 = 4 * (u >> 1) + (pp >> 2);
+#pragma unroll
+        for (int td = 0; td < NTD; ++td) {
+            const int ch = td * 4 + (u & 1) * 2 + ((pp & 3) >> 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row = row0 + 8 * s;
+                tfo[td][s] = row * RS + ((ch ^ swz_key<KM>(row)) << 4) + (pp & 1) * 8;
+            }
+        }
+    }
+    const int nwg = gridDim.x;
+    int item = (int)blockIdx.x, item_step = nwg;
+    if ((nwg & 7) == 0 && nitems % nwg == 0) {   // XCD-contiguous runs of items (see attn_fwd_res_kernel)
+        const int per_wg = nitems / nwg;
+        item = ((int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3)) * per_wg;
+        item_step = 1;
+    }
+    const int item_end = item_step == 1 ? item + nitems / nwg : nitems;
+    for (; item < item_end; item += item_step) {
+        const int b = item / p.H, h = item - b * p.H;
+        const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
+        const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
+        const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+        const T* dob = d_o + (int64_t)b * p.o_bs + h * p.hd;
+        const int64_t stat_base = ((int64_t)b * p.H + h) * p.Sq;
+        // ---- this wave's K / V fragments (keys 32 wave + (l & 31)), requested before the staging so that they travel with it ----
+        const int kb0 = wave * 32;
+        const bool own = kb0 < p.Sk && kb0 < 256;   // wave-uniform
+        const int j = kb0 + r31;
+        s16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 16 + hh * 8;
+            s16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (MICO_DKV_ABL != 2 && own && j < p.Sk && d < p.hd) {
+                a = *(const s16x8*)(kb + (int64_t)j * p.k_rs + d);
+                c = *(const s16x8*)(vb + (int64_t)j * p.v_rs + d);
+            }
+            kf[ks] = a;
+            vf[ks] = c;
+        }
+        // ---- Q, dO of the head -> registers -> LDS (zero beyond Sq / hd); lse * log2(e) and delta * scale next to them ----
+        {
+            s16x8 qr[NLD], dor[NLD];
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int c = it * 512 + tid;
+                const int row = c / CPR, ch = c - row * CPR;
+                s16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, d = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (MICO_DKV_ABL != 2 && row < p.Sq && ch * 8 < p.hd) {
+                    a = *(const s16x8*)(qb + (int64_t)row * p.q_rs + ch * 8);
+                    d = *(const s16x8*)(dob + (int64_t)row * p.o_rs + ch * 8);
+                }
+                qr[it] = a;
+                dor[it] = d;
+            }
+            // rows beyond Sq: lse = +big makes their probabilities (and dS) exactly zero - no masking in the tile loop
+            float sl = 1.0e30f, sd = 0.f;
+            if (tid < QR && tid < p.Sq) { sl = lse[stat_base + tid] * LOG2E; sd = delta[stat_base + tid] * p.scale; }
+            __syncthreads();   // the previous item's readers are done with the LDS images (and its key-256 partials are consumed)
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int c = it * 512 + tid;
+                const int row = c / CPR, ch = c - row * CPR;
+                if (row < QR) {
+                    const int off = row * RS + ((ch ^ swz_key<KM>(row)) << 4);
+                    *(LDS_AS s16x8*)(qt + off) = qr[it];
+                    *(LDS_AS s16x8*)(dot + off) = dor[it];
+                }
+            }
+            if (tid < QR) { lse_t[tid] = sl; del_t[tid] = sd; }
+        }
+        __syncthreads();
+        if (own) {
+            f32x16 dkacc[NTD], dvacc[NTD];
+#pragma unroll
+            for (int td = 0; td < NTD; ++td)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dkacc[td][r] = 0.f; dvacc[td][r] = 0.f; }
+            for (int t = 0; t < nt32; ++t) {
+                LDS_AS const char* qtile = qt + t * 32 * RS;
+                LDS_AS const char* dtile = dot + t * 32 * RS;
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    s = mfma32<T>(*(LDS_AS const s16x8*)(qtile + rfo[ks]), kf[ks], s);
+                    dp = mfma32<T>(*(LDS_AS const s16x8*)(dtile + rfo[ks]), vf[ks], dp);
+                }
+                // statistics of this lane's queries i(r) = (r & 3) + 8 (r >> 2) + 4 hh: two float4 reads each per half m (registers 8 m .. 8 m + 7
+                // = the B operands of the MFMAs over queries 16 m .. 16 m + 15 of the tile)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float pr[8], ds[8];
+#pragma unroll
+                    for (int rq = 0; rq < 2; ++rq) {
+                        const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + t * 32 + 16 * m + 8 * rq + 4 * hh);
+                        const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + t * 32 + 16 * m + 8 * rq + 4 * hh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = m * 8 + rq * 4 + e;
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));
+                            pr[rq * 4 + e] = pv;
+                            ds[rq * 4 + e] = pv * fmaf(dp[r], p.scale, -dv4[e]);
+                        }
+                    }
+                    const s16x8 pf = pack8<T>(pr);
+                    const s16x8 df = pack8<T>(ds);
+#pragma unroll
+                    for (int td = 0; td < NTD; ++td) {
+                        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dtile + m * 16 * RS + tfo[td][0]));
+                        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dtile + m * 16 * RS + tfo[td][1]));
+                        dvacc[td] = mfma32<T>((s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, pf, dvacc[td]);
+                        const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(qtile + m * 16 * RS + tfo[td][0]));
+                        const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(qtile + m * 16 * RS + tfo[td][1]));
+                        dkacc[td] = mfma32<T>((s16x8){c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]}, df, dkacc[td]);
+                    }
+                }
+            }
+            if (j < p.Sk) {   // dK^T / dV^T tile td: this lane's key, head dims 32 td + 8 (r >> 2) + 4 hh + (r & 3)
+                T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * p.hd;
+                T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * p.hd;
+#pragma unroll
+                for (int td = 0; td < NTD; ++td)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int d = td * 32 + 8 * rq + 4 * hh;
+                        if (d < p.hd) {
+                            *(s16x4*)(dkb + d) = pack4<T>(dkacc[td][rq * 4], dkacc[td][rq * 4 + 1], dkacc[td][rq * 4 + 2], dkacc[td][rq * 4 + 3]);
+                            *(s16x4*)(dvb + d) = pack4<T>(dvacc[td][rq * 4], dvacc[td][rq * 4 + 1], dvacc[td][rq * 4 + 2], dvacc[td][rq * 4 + 3]);
+                        }
+                    }
+            }
+        }
+        if (ragged) {
+            // ---- keys 256..: wave t takes query tile t (64 queries, 16x16 MFMAs), partial rows through LDS ----
+            f32x4 dkx[C::TD], dvx[C::TD];
+#pragma unroll
+            for (int t = 0; t < C::TD; ++t) {
+                dkx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dvx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (wave < nt64) {
+                s16x8 kx[C::KS], vx[C::KS];
+                const int jx = 256 + (lane & 15);
+                row_frags<T, HDP>(kx, kb, p.k_rs, jx, p.Sk, p.hd, lane);
+                row_frags<T, HDP>(vx, vb, p.v_rs, jx, p.Sk, p.hd, lane);
+                const int t = wave;
+                const int nti = (t == nt64 - 1 && (p.Sq & 63)) ? ((p.Sq - t * 64 + 15) >> 4) : 4;
+                dkv_tile<T, HDP, KM>(qt + t * C::TILE, dot + t * C::TILE, lse_t + t * 64, del_t + t * 64, nti, false, t * 64, jx, p.Sq, p.Sk, sc2, p.scale, kx,
+                                     vx, dkx, dvx, lane);
+            }
+            LDS_AS float* pw = part + wave * 2 * HDP;
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pw[td * 16 + g * 4 + r] = dkx[td][r];
+                        pw[HDP + td * 16 + g * 4 + r] = dvx[td][r];
+                    }
+            }
+            __syncthreads();
+            if (tid < 2 * HDP / 4) {
+                const int which = tid / (HDP / 4), d = (tid - which * (HDP / 4)) * 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int w = 0; w < 8; ++w) {
+                    LDS_AS const float* prow = part + w * 2 * HDP + which * HDP + d;
+                    acc[0] += prow[0]; acc[1] += prow[1]; acc[2] += prow[2]; acc[3] += prow[3];
+                }
+                if (d < p.hd) {
+                    T* out = (which ? dv + (int64_t)b * p.v_bs + (int64_t)256 * p.v_rs : dk + (int64_t)b * p.k_bs + (int64_t)256 * p.k_rs) + h * p.hd + d;
+                    *(s16x4*)out = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================================================================
+// backward dK / dV, STREAMING variant (round 3; Sk == 257, hd 65..96: the g/14 towers).  Measured on the resident 32x32 kernel above
+// (tools/probes/README.md, "attention: what bounds the resident kernels"): its load / stage / store skeleton alone takes 0.24 ms per launch
+// (the HBM floor of the q, k, v, dO reads), its tile loop alone 0.36 ms, together 0.82 ms - the two add up because an item's operands are
+// fetched, committed to LDS behind two barriers and only then multiplied, one item after the other on a CU whose LDS (147 KB of resident Q / dO)
+// admits a single workgroup.  Here only K / V live per item (register fragments, 32 keys per wave); Q and dO arrive by LDS-DMA (16-byte pieces,
+// lane-linear [rows][16 chunks] images, the chunk swizzle applied to the source address) in two HALVES per item - query tiles 0..3 into buffer A
+// (128 rows), tiles 4..8 into buffer B (160 rows; together with the statistics 156 of the 160 KiB) - and while one half is multiplied the
+// next one (of this item or of the next) is on its way: two barriers per item, none inside a half, so the waves of a SIMD drift apart and
+// overlap their MFMA and VALU / LDS phases as in the resident kernels.  (First version: a 4-slot ring of single tiles with a barrier per tile -
+// the eight waves then run every phase in lockstep and the tile arithmetic alone took 0.65 ms against 0.36 without barriers.)
+// Key 256 (the 257th token) is a rank-one update - s = Q k256, dV256 = sum_q P dO, dK256 = sum_q dS Q - done on the VALU: per tile a wave
+// takes 4 of the 32 queries (16 lanes x 8 head dims each), partial rows are folded through LDS once per item.
+// ======================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkv_stream_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                                     const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                                     const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
+                                                                     const mico_attn_params p) {
+    constexpr int HDP = 96, KM = 1, RS = 256, QR = RES_KR, ROWS_A = 128, ROWS_B = 160;
+    constexpr int NKS = HDP / 16, NTD = HDP / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (ROWS_A + ROWS_B) * RS + 2 * 2 * QR * 4 + 8 * 2 * HDP * 4 + 2 * 2 * 16 * 16];
+    LDS_AS char* qA = (LDS_AS char*)smem;                // Q rows 0..127 | dO rows 0..127 | Q rows 128..287 | dO rows 128..287
+    LDS_AS char* dA = qA + ROWS_A * RS;
+    LDS_AS char* qB = dA + ROWS_A * RS;
+    LDS_AS char* dB = qB + ROWS_B * RS;
+    LDS_AS float* stats = (LDS_AS float*)(dB + ROWS_B * RS);   // [item parity][lse | delta][QR]
+    LDS_AS float* part = stats + 2 * 2 * QR;                      // [wave][dK | dV][HDP]: partial rows of key 256
+    LDS_AS char* kv256 = (LDS_AS char*)(part + 8 * 2 * HDP);      // [item parity][K | V][16 chunks of 16 bytes]: row 256 of K and V
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const int nitems = p.B * p.H;
+    const int nt32 = (p.Sq + 31) / 32;
+    // per-lane LDS offsets (see attn_bwd_dkv_res32_kernel)
+    const int r31 = lane & 31, hh = lane >> 5, key_r = swz_key<KM>(r31);
+    int rfo[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) rfo[ks] = r31 * RS + (((ks * 2 + hh) ^ key_r) << 4);
+    // transposed fragments: first read per 32-dim tile, the second one (8 query rows further: the swizzle key flips chunk bit 1) at + tf2
+    int tfo[NTD], tf2;
+    {
+        const int pp = lane & 15, u = lane >> 4;
+        const int row0 = 4 * (u >> 1) + (pp >> 2);
+        const int cl = (u & 1) * 2 + ((pp & 3) >> 1);
+#pragma unroll
+        for (int td = 0; td < NTD; ++td) tfo[td] = row0 * RS + (((td * 4 + cl) ^ swz_key<KM>(row0)) << 4) + (pp & 1) * 8;
+        tf2 = 8 * RS + ((((cl ^ swz_key<KM>(row0 + 8)) & 3) - ((cl ^ swz_key<KM>(row0)) & 3)) << 4);
+    }
+    // DMA source of this thread's piece of a 32-row slab: row tid >> 4, LDS chunk slot tid & 15 <- source chunk slot ^ key(row) (recomputed at
+    // every issue: two registers less in the tile loop)
+    const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2), obytes = (int)(((int64_t)(p.Sq - 1) * p.o_rs + p.hd) * 2);
+
+    const int nwg = gridDim.x;
+    int item0 = (int)blockIdx.x, item_step = nwg, n_my;
+    if ((nwg & 7) == 0 && nitems % nwg == 0) {   // XCD-contiguous runs of items (see attn_fwd_res_kernel)
+        n_my = nitems / nwg;
+        item0 = ((int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3)) * n_my;
+        item_step = 1;
+    } else {
+        n_my = item0 < nitems ? (nitems - item0 + nwg - 1) / nwg : 0;
+    }
+    // half hf of local item li: rows 128 hf .. of Q and dO -> buffer A / B.  Thread tid moves pieces c = it * 512 + tid: row c >> 4, chunk slot c & 15
+    auto issue_half = [&](int li, int hf) {
+        if (MICO_DKV_ABL == 2 || MICO_DKV_ABL == 4) return;   // ablation: no DMA
+        const int it_ = item0 + li * item_step;
+        const int b_ = it_ / p.H, h_ = it_ - b_ * p.H;
+        // (descriptor inputs through readfirstlane: under SGPR pressure hipcc parks them in VGPRs and then wraps every DMA in a waterfall
+        // loop with a vmcnt(0) inside - cdna_hip_programming.md T20)
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(q + (int64_t)b_ * p.q_bs + h_ * p.hd), 0, __builtin_amdgcn_readfirstlane(qbytes), 0x00020000);
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(d_o + (int64_t)b_ * p.o_bs + h_ * p.hd), 0, __builtin_amdgcn_readfirstlane(obytes), 0x00020000);
+        LDS_AS char* qd = hf ? qB : qA;
+        LDS_AS char* dd = hf ? dB : dA;
+        const int drow = tid >> 4, dch = (tid & 15) ^ swz_key<KM>(drow);
+        const bool dlive = dch * 8 < p.hd;
+        const unsigned qoff0 = dlive ? (unsigned)(drow * p.q_rs * 2 + dch * 16) : 0xFFFFFFF0u;
+        const unsigned ooff0 = dlive ? (unsigned)(drow * p.o_rs * 2 + dch * 16) : 0xFFFFFFF0u;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            if (it == 4 && !hf) break;
+            const int rowg = hf * ROWS_A + it * 32;
+            const unsigned qo = qoff0 == 0xFFFFFFF0u ? 0xFFFFFFF0u : qoff0 + (unsigned)(rowg * p.q_rs * 2);
+            const unsigned oo = ooff0 == 0xFFFFFFF0u ? 0xFFFFFFF0u : ooff0 + (unsigned)(rowg * p.o_rs * 2);
+            // The DMA as inline assembly: with the builtin, hipcc knows an LDS write is pending and waits vmcnt(0) in front of the first transposing
+            // read that follows (it cannot tell that read's address from the DMA destination) - in the first tile of every half, i.e. it would
+            // wait for the NEXT half to land before multiplying this one.  The asm form is invisible to its counters; completion is OUR
+            // vmcnt(0) + barrier at the half boundaries (the compiler's own counted waits can only over-wait: the counter is in order).
+            // M0 (the LDS destination) is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+            lds_dma16(rq, (unsigned)(uintptr_t)(qd + (it * 512 + wave * 64) * 16), qo);
+            lds_dma16(rd, (unsigned)(uintptr_t)(dd + (it * 512 + wave * 64) * 16), oo);
+        }
+    };
+    if (n_my > 0) issue_half(0, 0);
+
+    for (int li = 0; li < n_my; ++li) {
+        const int item = item0 + li * item_step;
+        const int b = item / p.H, h = item - b * p.H;
+        const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
+        const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+        const int64_t stat_base = ((int64_t)b * p.H + h) * p.Sq;
+        LDS_AS float* lse_t = stats + (li & 1) * 2 * QR;
+        LDS_AS float* del_t = lse_t + QR;
+        // ---- this wave's K / V fragments (keys 32 wave + (l & 31)), the item's row statistics, key 256's K / V chunk for the VALU update ----
+        const int j = wave * 32 + r31;
+        s16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 16 + hh * 8;
+            s16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (d < p.hd) {
+                a = *(const s16x8*)(kb + (int64_t)j * p.k_rs + d);
+                c = *(const s16x8*)(vb + (int64_t)j * p.v_rs + d);
+            }
+            kf[ks] = a;
+            vf[ks] = c;
+        }
+        const int xc = lane & 31, xq = lane >> 5;   // ragged-key update: 4 head dims 4 xc .. (24 of the 32 lanes of a query carry data), query slot
+        LDS_AS char* kv_t = kv256 + (li & 1) * 512;
+        if (tid < 32) {   // row 256 of K (threads 0..15) and of V (16..31), chunk tid & 15, parked in LDS for the per-tile VALU update
+            s16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((tid & 15) * 8 < p.hd) a = *(const s16x8*)((tid < 16 ? kb : vb) + (int64_t)256 * p.k_rs + (tid & 15) * 8);
+            *(LDS_AS s16x8*)(kv_t + tid * 16) = a;
+        }
+        if (tid < QR) {
+            // rows beyond Sq: lse = +big makes their probabilities (and dS) exactly zero - no masking in the tile loop
+            float sl = 1.0e30f, sd = 0.f;
+            if (tid < p.Sq) { sl = lse[stat_base + tid] * LOG2E; sd = delta[stat_base + tid] * p.scale; }
+            lse_t[tid] = sl;
+            del_t[tid] = sd;
+        }
+        f32x16 dkacc[NTD], dvacc[NTD];
+#pragma unroll
+        for (int td = 0; td < NTD; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dkacc[td][r] = 0.f; dvacc[td][r] = 0.f; }
+        float dkx[4], dvx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dkx[e] = 0.f; dvx[e] = 0.f; }
+
+        for (int t = 0; t < nt32; ++t) {
+            if (t == 0 || t == 4) {
+                // this half has landed (every thread's pieces; the barrier publishes them) and every wave has left the OTHER buffer: refill it
+                __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0), as a builtin: the compiler then knows its own K / V fragment loads have
+                                                      // landed and does not wait for them again BEHIND the DMA it cannot see (that wait would
+                                                      // cover the whole next half)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0) issue_half(li, 1);
+                else if (li + 1 < n_my) issue_half(li + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MICO_DKV_ABL == 1) continue;   // ablation: no tile arithmetic
+            // (tile offsets kept opaque scalars: hipcc otherwise peels the loop and holds per-lane fragment addresses of several tiles in registers)
+            int qto = t < 4 ? t * 32 * RS : (2 * ROWS_A + (t - 4) * 32) * RS;
+            int dto = t < 4 ? (ROWS_A + t * 32) * RS : (2 * ROWS_A + ROWS_B + (t - 4) * 32) * RS;
+            asm volatile("" : "+s"(qto), "+s"(dto));
+            LDS_AS const char* qtile = qA + qto;
+            LDS_AS const char* dtile = qA + dto;
+            // ---- key 256 on the VALU: queries t * 32 + 4 wave + 2 ps + xq (two passes), head dims 4 xc .. 4 xc + 3 ----
+            if (MICO_DKV_ABL != 3 && MICO_DKV_ABL != 4) {
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int qrow = wave * 4 + ps * 2 + xq;
+                    const int off = qrow * RS + (((xc >> 1) ^ swz_key<KM>(qrow)) << 4) + (xc & 1) * 8;
+                    const f32x4 qv = unpack4<T>(*(LDS_AS const s16x4*)(qtile + off));
+                    const f32x4 dov = unpack4<T>(*(LDS_AS const s16x4*)(dtile + off));
+                    const f32x4 k4 = unpack4<T>(*(LDS_AS const s16x4*)(kv_t + xc * 8));
+                    const f32x4 v4 = unpack4<T>(*(LDS_AS const s16x4*)(kv_t + 256 + xc * 8));
+                    float sx = 0.f, dpx = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sx = fmaf(qv[e], k4[e], sx); dpx = fmaf(dov[e], v4[e], dpx); }
+                    sx = xor16_sum(row16_sum(sx));      // (lanes 24..31 of a query read the zero chunks 12..15 of its row)
+                    dpx = xor16_sum(row16_sum(dpx));
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sx, sc2, -lse_t[t * 32 + qrow]));
+                    const float dsx = pv * fmaf(dpx, p.scale, -del_t[t * 32 + qrow]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { dvx[e] = fmaf(pv, dov[e], dvx[e]); dkx[e] = fmaf(dsx, qv[e], dkx[e]); }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (the VALU update first: its unpacked rows and the score tiles are not live together)
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                s = mfma32<T>(*(LDS_AS const s16x8*)(qtile + rfo[ks]), kf[ks], s);
+                dp = mfma32<T>(*(LDS_AS const s16x8*)(dtile + rfo[ks]), vf[ks], dp);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float pr[8], ds[8];
+#pragma unroll
+                for (int rq = 0; rq < 2; ++rq) {
+                    const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + t * 32 + 16 * m + 8 * rq + 4 * hh);
+                    const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + t * 32 + 16 * m + 8 * rq + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = m * 8 + rq * 4 + e;
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[e]));
+                        pr[rq * 4 + e] = pv;
+                        ds[rq * 4 + e] = pv * fmaf(dp[r], p.scale, -dv4[e]);
+                    }
+                }
+                const s16x8 pf = pack8<T>(pr);
+                const s16x8 df = pack8<T>(ds);
+#pragma unroll
+                for (int td = 0; td < NTD; ++td) {
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dtile + m * 16 * RS + tfo[td]));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dtile + m * 16 * RS + tfo[td] + tf2));
+                    dvacc[td] = mfma32<T>((s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, pf, dvacc[td]);
+                    const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(qtile + m * 16 * RS + tfo[td]));
+                    const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(qtile + m * 16 * RS + tfo[td] + tf2));
+                    dkacc[td] = mfma32<T>((s16x8){c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]}, df, dkacc[td]);
+                }
+            }
+        }
+        // ---- this wave's 32 keys: dK^T / dV^T tile td holds head dims 32 td + 8 (r >> 2) + 4 hh + (r & 3) of key j ----
+        {
+            T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * p.hd;
+            T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * p.hd;
+#pragma unroll
+            for (int td = 0; td < NTD; ++td)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d = td * 32 + 8 * rq + 4 * hh;
+                    if (d < p.hd) {
+                        *(s16x4*)(dkb + d) = pack4<T>(dkacc[td][rq * 4], dkacc[td][rq * 4 + 1], dkacc[td][rq * 4 + 2], dkacc[td][rq * 4 + 3]);
+                        *(s16x4*)(dvb + d) = pack4<T>(dvacc[td][rq * 4], dvacc[td][rq * 4 + 1], dvacc[td][rq * 4 + 2], dvacc[td][rq * 4 + 3]);
+                    }
+                }
+        }
+        // ---- key 256: fold the two query slots of the wave, then the eight waves through LDS ----
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dkx[e] = xor32_sum(dkx[e]);
+            dvx[e] = xor32_sum(dvx[e]);
+        }
+        if (lane < 24) {
+            LDS_AS float* pw = part + wave * 2 * HDP + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pw[e] = dkx[e]; pw[HDP + e] = dvx[e]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * HDP / 4) {
+            const int which = tid / (HDP / 4), d = (tid - which * (HDP / 4)) * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < 8; ++w) {
+                LDS_AS const float* prow = part + w * 2 * HDP + which * HDP + d;
+                acc[0] += prow[0]; acc[1] += prow[1]; acc[2] += prow[2]; acc[3] += prow[3];
+            }
+            if (d < p.hd) {
+                T* out = (which ? dv + (int64_t)b * p.v_bs + (int64_t)256 * p.v_rs : dk + (int64_t)b * p.k_bs + (int64_t)256 * p.k_rs) + h * p.hd + d;
+                *(s16x4*)out = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        // (the partial rows are rewritten at the END of the next item: at least one tile barrier lies in between)
+    }
+}
+
 int check_params(const mico_attn_params* p, const char* who) {
     MICO_CHECK(p, "%s: null params", who);
     MICO_CHECK(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Sk > 0, "%s: empty problem", who);
@@ -1552,8 +2067,18 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
         static const int n_cu2 = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int nitems = p->B * p->H;
         const dim3 grid(nitems < n_cu2 ? nitems : n_cu2);
-        DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
-                                        (T*)dk, (T*)dv, *p));
+        // Round 3 experiments, selectable for A/B runs (tools/attn_bench.py; numbers in tools/probes/README.md): MICO_ATTN_DKV=res32 - the same
+        // residency on 32x32x16 MFMAs; MICO_ATTN_DKV=stream - Q / dO by LDS-DMA in two halves per item, double buffered.  Both pass the kernel
+        // tests; neither beats the 16x16 kernel by more than 2-3 % (1.27-1.29 vs 1.31 ms backward at 320 frames), so it keeps the launch.
+        static const char* dkv_env = getenv("MICO_ATTN_DKV");
+        static const int dkv_mode = !dkv_env ? 0 : (dkv_env[0] == 'r' ? 1 : (dkv_env[0] == 's' ? 2 : 0));
+        if (dkv_mode == 2 && p->Sk == 257 && p->Sq > 128 && p->Sq <= RES_KR)
+            DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_stream_kernel<T>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
+                                            (T*)dk, (T*)dv, *p));
+        else if (dkv_mode == 1) DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res32_kernel<T>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
+                                                                (T*)dk, (T*)dv, *p));
+        else DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
+                                             (T*)dk, (T*)dv, *p));
         MICO_LAUNCH_CHECK();
         return MICO_OK;
     }

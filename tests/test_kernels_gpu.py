@@ -520,3 +520,46 @@ def test_mx8_quantise_and_gemm(cuda, dtype):
     e = ((out - full).norm() / full.norm()).item()
     print("mx8 relative Frobenius error", e)
     assert e < 4e-2
+
+
+@pytest.mark.parametrize("mode", ["res32", "stream"])
+def test_attention_dkv_experiment_kernels(cuda, mode):
+    """The round-3 dK / dV experiment kernels (32x32x16 MFMAs resident / LDS-DMA double-buffered halves; MICO_ATTN_DKV, read once per process):
+    the g/14 tower shape - 257 tokens, head dim 88, fused QKV strides - against the default kernels' dK / dV in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import torch, sys
+sys.path.insert(0, %r)
+from mico_amd import ops
+torch.manual_seed(3)
+B, H, S, hd = 40, 16, 257, 88
+D = H * hd
+dev = torch.device('cuda:0')
+qkv = torch.randn(B, S, 3 * D, device=dev).to(torch.float16)
+q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+o = torch.empty(B, S, D, device=dev, dtype=torch.float16)
+do = torch.randn(B, S, D, device=dev).to(torch.float16)
+lse = torch.empty(B, H, S, device=dev); delta = torch.empty(B, H, S, device=dev)
+st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
+kw = dict(B=B, H=H, Sq=S, Sk=S, hd=hd, scale=hd ** -0.5, **st)
+ops.attn_fwd(q, k, v, o, lse, **kw)
+dqkv = torch.full_like(qkv, float('nan'))
+ops.attn_bwd(q, k, v, o, do, lse, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], delta, **kw)
+torch.save(dqkv.float().cpu(), sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for m in ("", mode):
+            env = dict(os.environ)
+            env.pop("MICO_ATTN_DKV", None)
+            if m:
+                env["MICO_ATTN_DKV"] = m
+            f = os.path.join(td, f"g_{m or 'default'}.pt")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=env)
+            outs[m] = torch.load(f)
+    a, b = outs[""], outs[mode]
+    assert torch.isfinite(b).all()
+    assert ((a - b).abs().max() / a.abs().max()).item() < 2e-3
