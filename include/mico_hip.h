@@ -295,6 +295,15 @@ int mico_embed_scatter_add(const int64_t* ids, const float* dsum, float* dword, 
  * caller (injected for parity, torch.rand otherwise); out[r] = #{j : cdf_r[j] <= u[r] * total_r} (inverse-CDF draw: the first column whose CDF
  * exceeds the target, so a zero-weight column is never drawn), int64. */
 int mico_itm_sample(const float* sim, int64_t ld, int rows, int cols, int diag_offset, const float* u, int64_t* out, void* stream);
+/* Caption-loss token masking (TokenMasker.perform_mask, data/model/general_module.py:64-97 - there two Python loops over b x S on the host behind
+ * a .cpu() copy, i.e. a stream sync per step).  tokens: int64 [rows, S].  A token at position j >= 1 with id != 0 is selected when
+ * u_mask[r][row][j] < mask_prob; round r = 0 stands unless it selects nothing in the row, then round 1 is drawn, ... (the reference's
+ * "while all(indicator == 0)" retry; after `rounds` empty rounds the row stays unmasked).  A selected token becomes mask_token when u_kind < 0.8, the id
+ * range_start + floor(u_tok * (range_end - range_start)) when 0.8 <= u_kind < 0.9, and is kept otherwise; labels = the source id at selected
+ * positions, -100 elsewhere.  u_mask: fp32 [rounds, rows, S]; u_kind, u_tok: fp32 [rows, S] - uniform numbers in [0, 1) supplied by the caller
+ * (injected for parity, torch.rand otherwise). */
+int mico_token_mask(const int64_t* tokens, int rows, int S, float mask_prob, const float* u_mask, int rounds, const float* u_kind,
+                    const float* u_tok, int mask_token, int range_start, int range_end, int64_t* out_tokens, int64_t* labels, void* stream);
 
 int mico_ce_fwd_bwd(const void* logits, int logits_dtype, int64_t ld, int64_t rows, int cols,
                     const int64_t* target, int ignore_index, float label_smoothing, float logits_scale,

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "mico_bert_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp],
     "mico_embed_scatter_add": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_f, c_vp],
     "mico_itm_sample": [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "mico_token_mask": [c_vp, c_int, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "mico_win_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_int, c_vp],
     "mico_win_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f, c_f, c_int, c_vp],
     "mico_patch_merge": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
@@ -103,7 +104,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 104   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 105   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

@@ -109,6 +109,56 @@ __global__ __launch_bounds__(64) void itm_sample_kernel(const float* __restrict_
 
 }  // namespace
 
+// TokenMasker.perform_mask (data/model/general_module.py:64-97) with the random numbers supplied by the caller: one wave per row.
+__global__ __launch_bounds__(64) void token_mask_kernel(const int64_t* __restrict__ tokens, int S, float mask_prob, const float* __restrict__ u_mask,
+                                                        int rounds, int64_t round_stride, const float* __restrict__ u_kind,
+                                                        const float* __restrict__ u_tok, int mask_token, int range_start, int range_end,
+                                                        int64_t* __restrict__ out_tokens, int64_t* __restrict__ labels) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int64_t* t = tokens + (int64_t)row * S;
+    // indicator: position 0 and pads (id 0) are never masked; a row is re-drawn (next round of uniforms) until it has >= 1 masked token
+    unsigned long long any = 0;
+    int r = 0;
+    for (; r < rounds && !any; ++r) {
+        const float* u = u_mask + r * round_stride + (int64_t)row * S;
+        for (int j0 = 0; j0 < S; j0 += 64) {
+            const int j = j0 + lane;
+            const bool hit = j >= 1 && j < S && t[j] != 0 && u[j] < mask_prob;
+            any |= __ballot(hit);
+        }
+    }
+    const int used = r - 1;   // the round whose draw stands (a row without a maskable token, or `rounds` exhausted, keeps nothing masked)
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        if (j >= S) break;
+        const int64_t src = t[j];
+        const bool hit = any && j >= 1 && src != 0 && u_mask[used * round_stride + (int64_t)row * S + j] < mask_prob;
+        int64_t tok = src, lab = -100;
+        if (hit) {
+            lab = src;
+            const float pk = u_kind[(int64_t)row * S + j];
+            if (pk < 0.8f) tok = mask_token;
+            else if (pk < 0.9f) {
+                int c = range_start + (int)(u_tok[(int64_t)row * S + j] * (float)(range_end - range_start));
+                tok = c < range_end ? c : range_end - 1;
+            }
+        }
+        out_tokens[(int64_t)row * S + j] = tok;
+        labels[(int64_t)row * S + j] = lab;
+    }
+}
+
+extern "C" int mico_token_mask(const int64_t* tokens, int rows, int S, float mask_prob, const float* u_mask, int rounds, const float* u_kind,
+                               const float* u_tok, int mask_token, int range_start, int range_end, int64_t* out_tokens, int64_t* labels,
+                               void* stream) {
+    MICO_CHECK(tokens && u_mask && u_kind && u_tok && out_tokens && labels && rows > 0 && S > 0 && rounds > 0, "mico_token_mask: bad args");
+    MICO_CHECK(range_end > range_start && mask_prob >= 0.f && mask_prob <= 1.f, "mico_token_mask: bad range / probability");
+    MICO_LAUNCH(token_mask_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, tokens, S, mask_prob, u_mask, rounds, (int64_t)rows * S, u_kind, u_tok,
+                mask_token, range_start, range_end, out_tokens, labels);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
 extern "C" int mico_itm_sample(const float* sim, int64_t ld, int rows, int cols, int diag_offset, const float* u, int64_t* out,
                                void* stream) {
     MICO_CHECK(sim && u && out && cols > 0 && ld >= cols, "mico_itm_sample: bad args");

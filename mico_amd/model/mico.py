@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fn
+from .. import ops
 from .bert import BertForMaskedLM, build_tokenizer
 from .evaclip import create_model
 
@@ -85,13 +86,26 @@ class _HiddenTrans(nn.Sequential):
 
 
 class TokenMasker:
-    """data/model/general_module.py:52-97 with an injectable RNG; runs on the host like the reference's."""
+    """data/model/general_module.py:52-97.  Device tokens (and no injected host RNG): one kernel (mico_token_mask) fed with torch.rand
+    uniforms - no .cpu() copy, i.e. no stream sync in the middle of the step, and no b x S Python loop.  CPU tokens or an injected
+    `random.Random`: the reference's host loops, draw for draw (what the golden fixtures and the oracle use).  `uniforms=(u_mask, u_kind,
+    u_tok)` injects the device path's random numbers (parity against oracle.token_masker_uniform)."""
+
+    ROUNDS = 4      # redraws of a row whose draw selected nothing (0.4^n for n maskable tokens: 1e-2 for 5 tokens per round)
 
     def __init__(self, mask_token=103, range_start=106, range_end=30522, rng=None):
         self.mask_token, self.range = mask_token, (range_start, range_end)
         self.rng = rng or random
+        self._host_rng_injected = rng is not None
 
-    def __call__(self, tokens, mask_prob):
+    def __call__(self, tokens, mask_prob, uniforms=None):
+        if tokens.is_cuda and (uniforms is not None or not self._host_rng_injected):
+            if uniforms is None:
+                b, S = tokens.shape
+                u = torch.rand((self.ROUNDS + 2, b, S), device=tokens.device)
+                uniforms = (u[:self.ROUNDS], u[self.ROUNDS], u[self.ROUNDS + 1])
+            return ops.token_mask(tokens, mask_prob, uniforms[0].to(tokens.device), uniforms[1].to(tokens.device), uniforms[2].to(tokens.device),
+                                  self.mask_token, self.range[0], self.range[1])
         toks = tokens.detach().cpu().clone().numpy()
         ind = [[0] * toks.shape[1] for _ in range(toks.shape[0])]
         for i in range(toks.shape[0]):

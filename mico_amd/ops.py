@@ -370,6 +370,17 @@ def ce_fwd_bwd(logits, target, *, cols=None, ignore_index=-100, label_smoothing=
           "mico_ce_fwd_bwd")
 
 
+def token_mask(tokens, mask_prob, u_mask, u_kind, u_tok, mask_token, range_start, range_end):
+    """(masked token ids, labels) of the caption loss's TokenMasker on the device; see mico_token_mask.  u_mask [rounds, rows, S]."""
+    rows, S = tokens.shape
+    toks = tokens.contiguous()
+    out, labels = torch.empty_like(toks), torch.empty_like(toks)
+    check(_lib.lib().mico_token_mask(_p(toks), rows, S, float(mask_prob), _p(u_mask.contiguous()), u_mask.shape[0], _p(u_kind.contiguous()),
+                                     _p(u_tok.contiguous()), int(mask_token), int(range_start), int(range_end), _p(out), _p(labels), _st()),
+          "mico_token_mask")
+    return out, labels
+
+
 def itm_sample(sim, diag_offset, u):
     """One hard-negative index per row of the fp32 similarity logits `sim` [rows, cols]; see mico_itm_sample."""
     sim = sim.contiguous()

@@ -614,6 +614,34 @@ def token_masker(tokens, mask_prob, rng, mask_token=103, range_start=106, range_
     return torch.from_numpy(toks).long(), torch.from_numpy(labels).long()
 
 
+def token_masker_uniform(tokens, mask_prob, u_mask, u_kind, u_tok, mask_token=103, range_start=106, range_end=30522):
+    """TokenMasker.perform_mask (data/model/general_module.py:64-97) with the uniform numbers given as tensors instead of drawn from
+    `random` one by one (the rule of include/mico_hip.h: mico_token_mask): u_mask [rounds, b, S] - round r is used for a row only when
+    rounds 0..r-1 selected nothing in it (the reference's retry loop); u_kind / u_tok [b, S] decide 80 % [MASK] / 10 % random id / 10 % keep."""
+    import numpy as np
+    toks = np.array(tokens.cpu().numpy())
+    um, uk, ut = (np.asarray(x.detach().cpu().float().numpy()) for x in (u_mask, u_kind, u_tok))
+    labels = -np.ones(toks.shape, dtype=np.int64) * 100
+    pm = np.float32(mask_prob)
+    for i in range(toks.shape[0]):
+        ind = np.zeros(toks.shape[1], dtype=bool)
+        for r in range(um.shape[0]):
+            for j in range(1, toks.shape[1]):
+                if toks[i][j] != 0 and um[r][i][j] < pm:
+                    ind[j] = True
+            if ind.any():
+                break
+        for j in range(toks.shape[1]):
+            if ind[j]:
+                src = toks[i][j]
+                if uk[i][j] < np.float32(0.8):
+                    toks[i][j] = mask_token
+                elif uk[i][j] < np.float32(0.9):
+                    toks[i][j] = min(range_start + int(np.float32(ut[i][j]) * np.float32(range_end - range_start)), range_end - 1)
+                labels[i][j] = src
+    return torch.from_numpy(toks).long(), torch.from_numpy(labels).long()
+
+
 # --------------------------------------------------------------------------------------------------------------
 # caption decoding (inference_demo.py:161-174).  The search itself is third-party code the reference tree does not
 # hold: transformers==4.31.0 GenerationMixin.generate -> beam_search + BeamSearchScorer (set_env.sh:12 pins the

@@ -563,3 +563,37 @@ torch.save(dqkv.float().cpu(), sys.argv[1])
     a, b = outs[""], outs[mode]
     assert torch.isfinite(b).all()
     assert ((a - b).abs().max() / a.abs().max()).item() < 2e-3
+
+
+def test_token_mask_bit_exact(cuda):
+    """mico_token_mask against the oracle's restatement of TokenMasker.perform_mask with the same uniform numbers: ids and labels bit-exact,
+    including a row whose first draw selects nothing (second round stands), a row of pads only, and the 80 / 10 / 10 split."""
+    from mico_amd import ops
+    from mico_amd.model import TokenMasker
+    from oracle import mico_oracle as O
+    g = torch.Generator().manual_seed(11)
+    b, S, R = 48, 77, 4
+    ids = torch.randint(1000, 30000, (b, S), generator=g)
+    ids[:, 0] = 101
+    lens = torch.randint(2, S + 1, (b,), generator=g)
+    ids = ids * (torch.arange(S)[None] < lens[:, None])
+    ids[5, 1:] = 0                       # nothing maskable: stays unmasked whatever the draws
+    um = torch.rand((R, b, S), generator=g)
+    um[0, 7] = 0.99                      # row 7: the first round selects nothing, the second one stands
+    um[0, 9] = 0.99
+    um[1, 9] = 0.99                      # row 9: third round
+    uk, ut = torch.rand((b, S), generator=g), torch.rand((b, S), generator=g)
+    ref_t, ref_l = O.token_masker_uniform(ids, 0.6, um, uk, ut)
+    got_t, got_l = ops.token_mask(ids.to(cuda), 0.6, um.to(cuda), uk.to(cuda), ut.to(cuda), 103, 106, 30522)
+    assert torch.equal(got_t.cpu(), ref_t) and torch.equal(got_l.cpu(), ref_l)
+    assert (ref_l[5] == -100).all() and (ref_l[7] != -100).any() and (ref_l[9] != -100).any()
+    sel = ref_l != -100
+    assert 0.5 < sel[:, 1:].float().sum() / (ids[:, 1:] != 0).float().sum() < 0.7
+    kinds = [(ref_t[sel] == 103).float().mean().item(), ((ref_t[sel] != 103) & (ref_t[sel] != ref_l[sel])).float().mean().item()]
+    assert 0.7 < kinds[0] < 0.9 and 0.05 < kinds[1] < 0.16
+    # the module: device tokens take the kernel (no host sync), injected uniforms reproduce the oracle
+    tm = TokenMasker()
+    t2, l2 = tm(ids.to(cuda), 0.6, uniforms=(um, uk, ut))
+    assert torch.equal(t2.cpu(), ref_t) and torch.equal(l2.cpu(), ref_l)
+    t3, l3 = tm(ids.to(cuda), 0.6)
+    assert t3.is_cuda and ((l3 != -100).sum(1)[(ids[:, 1:] != 0).any(1)] >= 1).all()
