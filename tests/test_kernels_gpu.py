@@ -551,6 +551,7 @@ torch.save(dqkv.float().cpu(), sys.argv[1])
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     outs = {}
+    torch.cuda.empty_cache()   # the children need device memory of their own: give back what earlier (full-size) tests left cached in this process
     with tempfile.TemporaryDirectory() as td:
         for m in ("", mode):
             env = dict(os.environ)
