@@ -255,6 +255,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner to the C-level stdout when its first
+    # communicator comes up, flushed at exit - i.e. AFTER the JSON line): keep the real stdout aside, point fd 1 at stderr for the whole run
+    # and write the line to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun)")
     if torch.cuda.device_count() <= local_rank:
@@ -434,17 +440,23 @@ def main():
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/*_gemm_hbm_traffic.json, FETCH_SIZE
         # doubled as MI355X_MICROARCH.md prescribes for gfx950).  null when that profile is not present.
         traffic = None
-        for tname in ("r02_gemm_hbm_traffic.json", "r01_gemm_hbm_traffic.json"):
+        traffic_src = None
+        for tname in ("r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json", "r01_gemm_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
                 key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[0][:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8", 5: "big", 6: "mid", 7: "mid"}[dom[0][2]]
                 if key in tj:
                     traffic = tj[key]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/" + tname
                     break
         peak = 5000.0 if dom[0][2] == 4 else MFMA_PEAK_TFLOPS     # dense MX-fp8 peak (MI355X_MICROARCH.md) for the fp8 kernel
         roofline = dict(bound="mfma", kernel=kname(dom[0]), achieved=achieved, peak=peak, unit="TFLOP/s",
-                        frac=achieved / peak, traffic=traffic, traffic_unit="bytes/launch (PMC pass, see profiles/)",
+                        frac=achieved / peak, traffic=traffic,
+                        traffic_unit="bytes/launch", traffic_provenance=(f"{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
+                                                                          "on the builder's box (tools/profile_round.sh; FETCH_SIZE doubled for gfx950) - PMC counters "
+                                                                          "cannot be read from inside this process, so this figure is NOT measured in this run"
+                                                                          if traffic_src else None),
                         launches=dom[1]["launches"], avg_launch_ms=dom[1]["ms"] / dom[1]["launches"],
                         all_gemm=dict(tflops=tot_flops / tot_ms / 1e9, share_of_step_time=tot_ms / 1e3 / elapsed), variants=per_variant)
     workload = wl["key"]
@@ -569,7 +581,8 @@ def main():
             res["secondary"] = {"omni_configs3_rank_share": {"error": repr(e)}}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(sd_cpu, args)
-    print(json.dumps(res))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

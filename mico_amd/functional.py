@@ -584,7 +584,7 @@ def tower_plan(spec, n_frames, device, kept=1.0):
     # over frames x N condition tokens, the gradient arena: measured 23 GB at 320 frames (configs[2]: 162 GB peak, 139 GB of it activations)
     # and 57 GB at 896 (one rank of configs[3]: 228 GB peak at level 2, 267 GB at level 1)
     headroom = (12 << 30) + n_frames * (52 << 20)
-    budget = int(0.95 * max(free - headroom, free // 4))
+    budget = int(0.90 * max(free - headroom, free // 4))   # (0.95 put one rank of configs[3] on level 1 at a 268 of 288 GiB peak: too close)
     kept = min(1.0, max(0.05, kept + 0.02))      # (a little slack: the draw differs from chunk to chunk)
     best = None
     for lv in levels:

@@ -23,6 +23,10 @@ def variant(name):
         kind = "big"
     elif "gemm_mx8_kernel" in name:
         return "NN_mx8"
+    elif "gemm_mid_kernel" in name:   # gemm_mid_kernel<T, TB, ACT>: forward (TB = false) or dX orientation
+        m = re.search(r"gemm_mid_kernelI\w+?Lb([01])E|gemm_mid_kernel<[^,]+,\s*(true|false)", name)
+        tb = bool(m) and (m.group(1) == "1" or m.group(2) == "true")
+        return ("dX" if tb else "NN") + "_mid"
     elif "gemm_kernel" in name:
         kind = "big" if re.search(r"256,\s*256|Li256ELi256", name) else "small"
     else:

@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-rXX}; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/prof_$TAG
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-extras"
+B="python $R/bench.py --no-cpu-baseline --no-extras --no-comm"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 3 --warmup 2 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex gemm --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex gemm --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/write.log 2>&1
