@@ -130,6 +130,27 @@ __device__ __forceinline__ int key_kc(int row) { return (row >> 1) & 7; }       
 __device__ __forceinline__ int key_k32(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }      // [rows][32]: {0,3,2,1}[(row>>2)&3]
 __device__ __forceinline__ int key_tr(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }   // [64][cols] reduction-major
 
+// One LDS-DMA piece: 16 bytes per lane from the buffer `rs` at per-lane byte offset voff into the lane-linear LDS image starting at lds_dst.
+// MICO_ASM_DMA (default on): issued by inline assembly.  With the builtin, hipcc knows an LDS write is pending and puts `s_waitcnt vmcnt(0)` in
+// front of the first __builtin_amdgcn_ds_read_tr16_b64 that follows (the transposing read carries no address information it could tell from
+// the DMA destination; tools/probes/README.md) - in the dX / dW kernels that drained the three K-tiles in flight once per K-tile.  The asm form
+// is invisible to the compiler's counters: completion is the kernels' own counted `s_waitcnt vmcnt(N)` + barrier (they never relied on the
+// compiler for that, except in front of the __syncthreads() of the two-stage loops, which now carry an explicit vmcnt(0)).  M0 (the LDS
+// destination register of the instruction) is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+#ifndef MICO_ASM_DMA
+#define MICO_ASM_DMA 1
+#endif
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, LDS_AS void* lds_dst, unsigned voff) {
+#if MICO_ASM_DMA
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_dst, 16, voff, 0, 0, 0);
+#endif
+}
+
 // generic (masked) staging of one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim.
 template <bool TR, int ROWS, int THREADS, int BK>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, int lane,
@@ -153,7 +174,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS cha
             voff = (unsigned)((int64_t)(k0 + row) * ld_bytes + cg * 16);
             if (cg * 8 >= cdim_rem || (k0 + row) >= kdim) voff = 0xFFFFFFF0u;
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), 16, voff, 0, 0, 0);
+        lds_dma16(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), voff);
     }
 }
 
@@ -261,7 +282,7 @@ __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char
     for (int it = 0; it < NISSUE; ++it) {
         unsigned v = (vo[it] == 0xFFFFFFF0u) ? 0xFFFFFFF0u : vo[it] + koff;
         if (MICO_GEMM_ABLATE == 4) v |= 0xFFFFFFF0u;   // ablation: every DMA out of bounds (issue + LDS zero-fill, no memory traffic)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), 16, v, 0, 0, 0);
+        lds_dma16(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), v);
     }
 }
 
@@ -665,7 +686,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
         int bo = 0;
         if (T_ > 0) stage(kt0, 0);
         for (int t = 0; t < T_; ++t) {
-            __syncthreads();   // stage `bo` landed (vmcnt(0) precedes the barrier); the other stage is no longer being read
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage `bo` landed (explicit: the DMA may be invisible to the compiler) ...
+            __syncthreads();   // ... and is published; the other stage is no longer being read
             if (t + 1 < T_) stage(kt0 + t + 1, bo ^ CFG::STAGE_BYTES);
 #pragma unroll
             for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
@@ -1238,7 +1260,8 @@ __global__ __launch_bounds__(Mx8::THREADS, 2) void gemm_mx8_kernel(const Mx8Args
     int bo = 0;
     stage(0, 0);
     for (int t = 0; t < T_; ++t) {
-        __syncthreads();   // stage `bo` landed (vmcnt(0) precedes the barrier); the other stage is no longer being read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage `bo` landed (explicit: the operand DMA may be invisible to the compiler) ...
+        __syncthreads();   // ... and is published; the other stage is no longer being read
         if (t + 1 < T_) stage(t + 1, bo ^ Mx8::STAGE_BYTES);
         LDS_AS const char* ta = lds + bo;
         LDS_AS const char* tb = ta + Mx8::A_BYTES;
