@@ -140,19 +140,24 @@ __device__ __forceinline__ int key_tr(int row) { return ((row & 3) | (((row >> 3
 #ifndef MICO_ASM_DMA
 #define MICO_ASM_DMA 1
 #endif
+// Where it is used (in situ A/B of the timed step, asm everywhere vs builtin everywhere): the 8-wave kernel's dX orientation 951 -> 996 TFLOP/s and
+// BERT's small-tile weight gradients 364 -> 417, but the producer / consumer dW kernel 1004 -> 865 (its producer waves interleave the DMA with the
+// bias column sums' own inline-asm LDS reads) and the forward orientation (no transposing reads) 975 -> 962: so ASM = the launch reads an
+// operand with transposing reads AND is not the producer / consumer kernel.
+template <bool ASM>
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, LDS_AS void* lds_dst, unsigned voff) {
-#if MICO_ASM_DMA
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
-#else
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_dst, 16, voff, 0, 0, 0);
-#endif
+    if constexpr (ASM && MICO_ASM_DMA) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
+    } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_dst, 16, voff, 0, 0, 0);
+    }
 }
 
 // generic (masked) staging of one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim.
-template <bool TR, int ROWS, int THREADS, int BK>
+template <bool TR, int ROWS, int THREADS, int BK, bool ASM = false>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, int lane,
                                            int64_t ld_bytes, int k0, int64_t kdim, int64_t cdim_rem) {
     constexpr int NDMA = ROWS * BK * 2 / 16 / THREADS;
@@ -174,7 +179,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS cha
             voff = (unsigned)((int64_t)(k0 + row) * ld_bytes + cg * 16);
             if (cg * 8 >= cdim_rem || (k0 + row) >= kdim) voff = 0xFFFFFFF0u;
         }
-        lds_dma16(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), voff);
+        lds_dma16<ASM>(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), voff);
     }
 }
 
@@ -275,14 +280,14 @@ __device__ __forceinline__ void dma_offsets(unsigned (&vo)[NDMA], int wave, int 
     }
 }
 
-template <int THREADS, int NDMA, int NISSUE = NDMA>
+template <int THREADS, int NDMA, int NISSUE = NDMA, bool ASM = false>
 __device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, const unsigned (&vo)[NDMA],
                                           unsigned koff) {
 #pragma unroll
     for (int it = 0; it < NISSUE; ++it) {
         unsigned v = (vo[it] == 0xFFFFFFF0u) ? 0xFFFFFFF0u : vo[it] + koff;
         if (MICO_GEMM_ABLATE == 4) v |= 0xFFFFFFF0u;   // ablation: every DMA out of bounds (issue + LDS zero-fill, no memory traffic)
-        lds_dma16(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), v);
+        lds_dma16<ASM>(rs, (LDS_AS void*)(lds_tile + (it * THREADS + wave * 64) * 16), v);
     }
 }
 
@@ -611,15 +616,16 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_kernel(const GemmArgs g)
             kdb = g.e.b_seg_off[sg] + kseg;
         }
         if (MICO_GEMM_ABLATE == 1 && kt >= kt0 + 3) return;   // ablation: no DMA in the steady state
+        constexpr bool ADMA = TA || TB;   // a transposing-read orientation: DMA by inline assembly (see lds_dma16)
         if (ktail && kt == g.ktiles - 1) {
-            stage_tile<TA, BM, THREADS, BK>(rsa, lds + bo, wave, lane, lda_b, ka, kda, a_crem);
-            stage_tile<TB, BN, THREADS, BK>(rsb, lds + bo + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
+            stage_tile<TA, BM, THREADS, BK, ADMA>(rsa, lds + bo, wave, lane, lda_b, ka, kda, a_crem);
+            stage_tile<TB, BN, THREADS, BK, ADMA>(rsb, lds + bo + CFG::A_BYTES, wave, lane, ldb_b, kb, kdb, b_crem);
             return;
         }
         const unsigned koa = TA ? (unsigned)((int64_t)ka * lda_b) : (unsigned)(ka * 2);
         const unsigned kob = TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2);
-        dma_issue<THREADS, CFG::A_DMA>(rsa, lds + bo, wave, voa, koa);
-        dma_issue<THREADS, CFG::B_DMA>(rsb, lds + bo + CFG::A_BYTES, wave, vob, kob);
+        dma_issue<THREADS, CFG::A_DMA, CFG::A_DMA, ADMA>(rsa, lds + bo, wave, voa, koa);
+        dma_issue<THREADS, CFG::B_DMA, CFG::B_DMA, ADMA>(rsb, lds + bo + CFG::A_BYTES, wave, vob, kob);
     };
 
     s16x8 fa[MT], fb[4];   // fragments of ONE 32-deep k-step
@@ -1032,8 +1038,8 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
         int ka, kb;
         k_of(t, ka, kb);
         LDS_AS char* dst = lds + slot * UNIT;
-        if (w < 2) dma_issue<THREADS, UD>(rsa, dst, wave, voa, (unsigned)(ka * 2) + (w ? a_half : 0u));
-        else dma_issue<THREADS, UD>(rsb, dst, wave, vob, TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2));
+        if (w < 2) dma_issue<THREADS, UD, UD, TB>(rsa, dst, wave, voa, (unsigned)(ka * 2) + (w ? a_half : 0u));
+        else dma_issue<THREADS, UD, UD, TB>(rsb, dst, wave, vob, TB ? (unsigned)((int64_t)kb * ldb_b) : (unsigned)(kb * 2));
     };
     // prologue: A-top / A-bottom / B of tile 0, A-top / A-bottom of tile 1 -> slots 0..4
     if (T_ > 0) { issue(0, 0, 0); issue(0, 1, 1); issue(0, 2, 2); }
