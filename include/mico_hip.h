@@ -212,7 +212,8 @@ typedef struct mico_attn_params {
 
 int mico_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                   const mico_attn_params* p, int dtype, void* stream);
-/* dq/dk/dv use the q/k/v strides; d_o uses the o strides; delta: fp32 workspace [B,H,Sq]. */
+/* dq/dk/dv use the q/k/v strides; d_o uses the o strides; delta: fp32 workspace [B,H,Sq] (scratch: the one-pass kernel for
+ * Sq <= 80 at hd 64 - BERT's text rows - keeps rowsum(O * dO) in LDS and leaves it untouched). */
 int mico_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   void* dq, void* dk, void* dv, float* delta,
                   const mico_attn_params* p, int dtype, void* stream);

@@ -268,11 +268,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
                 const unsigned thr = drop_threshold(p.drop_p);
                 const float ik = 1.f / (1.f - p.drop_p);
                 const unsigned long long rowbase = (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
+                if ((unsigned long long)p.B * p.H * p.Sq * p.Sk <= 0xFFFFFFFFull) {   // (launch-uniform) every index below 2^32: the incremental hash
+                    const unsigned h0 = p.drop_seed ^ ((unsigned)p.drop_site * 0x9E3779B9u);
+                    const unsigned tb = ((unsigned)rowbase + (unsigned)(t * 64 + g * 4)) * 0x85EBCA6Bu;
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
+                    for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s[rb][tn][r] *= drop_mult(p.drop_seed, p.drop_site, rowbase + (t * 64 + tn * 16 + g * 4 + r), thr, ik);
+                        for (int r = 0; r < 4; ++r)
+                            s[rb][tn][r] *= drop_hash_t(h0, tb + (unsigned)(tn * 16 + r) * 0x85EBCA6Bu) >= thr ? ik : 0.f;
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            s[rb][tn][r] *= drop_mult(p.drop_seed, p.drop_site, rowbase + (t * 64 + tn * 16 + g * 4 + r), thr, ik);
+                }
             }
             l_run[rb] = l_run[rb] * alpha + group_sum(lloc);
             m_run[rb] = m_new;
@@ -1972,6 +1982,255 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_stream_kernel(const T* __
     }
 }
 
+// ======================================================================================================================
+// backward for SHORT query sequences (BERT: 77 text tokens against 1285 condition tokens, hd 64): dQ, dK and dV in ONE pass.
+// The two tiled kernels above give every 64-query block and every 64-key block a workgroup of its own: at 77 x 1285 that is 2 + 21
+// workgroups per (b, h), each of which stages the other operand through LDS again, and the scores, the softmax and - in training - the
+// dropout decision of every (query, key) pair are computed twice (1.2 ms for the ITM triplet's 192 x 12 cross-attention heads).  Here ONE
+// 4-wave workgroup owns a (b, h): Q and dO (<= 80 rows) sit in LDS for its whole life and the keys are dealt out in rounds of four 32-key
+// strips, one per wave (K / V rows straight from global into registers, prefetched one round ahead).  Per round:
+//   every wave, for its strip:
+//     S = Q K^T, dP = dO V^T               acc lane = (key l & 15, queries 4 g + r)     [A = Q / dO rows from LDS, B = K / V in registers]
+//     P, dS (softmax from the saved lse, mask, dropout regenerated by drop_hash_t) - branch free, every score produced ONCE
+//     dV^T = dO^T P, dK^T = Q^T dS         complete for the strip (all queries are here) -> stored at once, no accumulators carried
+//     K and dS^T -> the wave's LDS strip images
+//   barrier; then wave w owns QUERY block w (and the d-slice w of the fifth block, queries 64..79):
+//     dQ^T[d][query] += K^T[d][key] dS^T[key][query] over the round's 128 keys, both operands by transposing reads of the strip images
+//   barrier (the strips are rewritten next round).
+// dQ therefore needs 20 accumulator registers per lane instead of 80, no cross-wave reduction and no atomics (bit-reproducible).
+// LDS: 2 x 12 KiB (Q, dO: 96 rows x 128 B, rows >= Sq zero) + 4 x (4 KiB K strip + 8 KiB dS strip) + statistics = 73.5 KiB -> two
+// workgroups per CU.
+// ======================================================================================================================
+struct SqCfg {
+    static constexpr int QMAX = 80, QR = 96;        // rows 80..95: the zero half of the third 32-deep reduction step over the queries
+    static constexpr int RS = 128;                  // compact 64-wide rows; 16-byte chunk index XOR-ed by (row >> 1) & 7
+    static constexpr int QT = QR * RS;
+    static constexpr int KT = 32 * RS, DST = 32 * 256, WAVE = KT + DST;
+    static constexpr int STAT = 2 * QR * 4;
+    static constexpr int LDS = 2 * QT + STAT + 4 * WAVE;
+};
+
+__device__ __forceinline__ int sq_off(int row, int ch) { return row * SqCfg::RS + ((ch ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ s16x8 sq_row_frag(LDS_AS const char* tile, int r0, int ks, int lane) {
+    return *(LDS_AS const s16x8*)(tile + sq_off(r0 + (lane & 15), ks * 4 + (lane >> 4)));
+}
+// the transposed fragment (see lds_tr_frag): output index d = td * 16 + (lane & 15), reduction slots over tile rows (2 s2 + r2) * 16 + 4 g + {0..3}
+__device__ __forceinline__ s16x8 sq_tr_frag(LDS_AS const char* tile, int td, int s2, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int r_lo = (2 * s2) * 16 + g * 4 + (p >> 2);   // rows r_lo and r_lo + 16 have the same swizzle key
+    const int off = sq_off(r_lo, td * 2 + ((p >> 1) & 1)) + (p & 1) * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + off));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(tile + off + 16 * SqCfg::RS));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <typename T, bool DROP, int MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                                 const T* __restrict__ o, const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                                 T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, const mico_attn_params p) {
+    using S = SqCfg;
+    constexpr int HD = 64;
+    __shared__ __attribute__((aligned(16))) char smem[S::LDS];
+    LDS_AS char* qt = (LDS_AS char*)smem;
+    LDS_AS char* dot = qt + S::QT;
+    LDS_AS float* lse_t = (LDS_AS float*)(dot + S::QT);   // lse * log2(e)
+    LDS_AS float* del_t = lse_t + S::QR;                    // delta * scale
+    LDS_AS char* strips = (LDS_AS char*)smem + 2 * S::QT + S::STAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+    const int b = blockIdx.y, h = blockIdx.x;
+    LDS_AS char* kt = strips + wave * S::WAVE;
+    LDS_AS char* dst = kt + S::KT;
+    const T* qb = q + (int64_t)b * p.q_bs + h * HD;
+    const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;
+    const T* kb = k + (int64_t)kvb * p.k_bs + h * HD;
+    const T* vb = v + (int64_t)kvb * p.v_bs + h * HD;
+    const T* ob = o + (int64_t)b * p.o_bs + h * HD;
+    const T* dob = d_o + (int64_t)b * p.o_bs + h * HD;
+    const int64_t stat_base = ((int64_t)b * p.H + h) * p.Sq;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const int nstrips = (p.Sk + 31) >> 5, nrounds = (nstrips + 3) >> 2;
+
+    // the first round's K / V rows (zero beyond Sk, also for a wave without a strip)
+    s16x8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+        row_frags<T, HD>(kf[kbk], kb, p.k_rs, wave * 32 + kbk * 16 + (lane & 15), p.Sk, HD, lane);
+        row_frags<T, HD>(vf[kbk], vb, p.v_rs, wave * 32 + kbk * 16 + (lane & 15), p.Sk, HD, lane);
+    }
+    // ---- Q, dO -> LDS (rows >= Sq zero); delta = rowsum(O * dO) from the dO chunk in hand ----
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int c = it * 256 + tid, row = c >> 3, ch = c & 7;   // 96 rows x 8 chunks = 768 = 3 x 256
+        s16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, dv8 = qv, ov = qv;
+        if (row < p.Sq) {
+            qv = *(const s16x8*)(qb + (int64_t)row * p.q_rs + ch * 8);
+            dv8 = *(const s16x8*)(dob + (int64_t)row * p.o_rs + ch * 8);
+            ov = *(const s16x8*)(ob + (int64_t)row * p.o_rs + ch * 8);
+        }
+        *(LDS_AS s16x8*)(qt + sq_off(row, ch)) = qv;
+        *(LDS_AS s16x8*)(dot + sq_off(row, ch)) = dv8;
+        float a[8], c8[8], dl = 0.f;
+        unpack8<T>(ov, a);
+        unpack8<T>(dv8, c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += a[e] * c8[e];
+        dl += __shfl_xor(dl, 1);
+        dl += __shfl_xor(dl, 2);
+        dl += __shfl_xor(dl, 4);
+        if (ch == 0) {
+            del_t[row] = dl * p.scale;
+            lse_t[row] = row < p.Sq ? lse[stat_base + row] * LOG2E : 0.f;
+        }
+    }
+    __syncthreads();
+
+    f32x4 dqw[4], dq4 = {0.f, 0.f, 0.f, 0.f};     // dQ^T of query block `wave` (4 d-blocks) and of queries 64..79, d-block `wave`
+#pragma unroll
+    for (int td = 0; td < 4; ++td) dqw[td] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nti = (p.Sq + 15) >> 4;                  // 16-query blocks holding real queries (<= 5)
+    // dropout: idx = ((b H + h) Sq + i) Sk + j, below 2^32 for every launch routed here (mico_attn_bwd) -> the incremental form of the hash
+    const unsigned ibase = (unsigned)((((unsigned long long)b * p.H + h) * p.Sq) * (unsigned long long)p.Sk);
+    const unsigned h0 = p.drop_seed ^ ((unsigned)p.drop_site * 0x9E3779B9u), tstep = (unsigned)p.Sk * 0x85EBCA6Bu;
+    const unsigned thr = drop_threshold(p.drop_p);
+    const float inv_keep = 1.f / (1.f - p.drop_p);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int rd = 0; rd < nrounds; ++rd) {
+        const int k0 = (rd * 4 + wave) * 32;
+        s16x8 nkf[2][2], nvf[2][2];
+        if (rd + 1 < nrounds) {        // next round's rows fly under this round's work
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk) {
+                row_frags<T, HD>(nkf[kbk], kb, p.k_rs, k0 + 128 + kbk * 16 + (lane & 15), p.Sk, HD, lane);
+                row_frags<T, HD>(nvf[kbk], vb, p.v_rs, k0 + 128 + kbk * 16 + (lane & 15), p.Sk, HD, lane);
+            }
+        }
+        if (k0 < p.Sk) {
+            // K strip -> LDS image (the A operand of dQ^T = K^T dS^T is read from it transposed)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) *(LDS_AS s16x8*)(kt + sq_off(kbk * 16 + (lane & 15), ks * 4 + g)) = kf[kbk][ks];
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk) {
+                __builtin_amdgcn_sched_barrier(0);              // one key block at a time: interleaving the two doubles the live score registers
+                const int j = k0 + kbk * 16 + (lane & 15);      // this lane's key
+                const bool jv = j < p.Sk;
+                const int jc = jv ? j : p.Sk - 1;
+                float mk1 = 0.f;
+                if (MASK == 1) mk1 = p.mask[(int64_t)b * p.Sk + jc] * LOG2E;
+                f32x4 s[5], dp[5];
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) {
+                    s[ti] = zero4;
+                    dp[ti] = zero4;
+                    if (ti < nti) {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            s[ti] = T16<T>::mfma(sq_row_frag(qt, ti * 16, ks, lane), kf[kbk][ks], s[ti]);
+                            dp[ti] = T16<T>::mfma(sq_row_frag(dot, ti * 16, ks, lane), vf[kbk][ks], dp[ti]);
+                        }
+                    }
+                }
+                const unsigned tq = (ibase + (unsigned)j + (unsigned)(4 * g) * (unsigned)p.Sk) * 0x85EBCA6Bu;
+                f32x4 pr[5];
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) {
+                    const f32x4 lv = *(LDS_AS const f32x4*)(lse_t + ti * 16 + g * 4);
+                    const f32x4 dv4 = *(LDS_AS const f32x4*)(del_t + ti * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = ti * 16 + g * 4 + r;
+                        const bool ok = jv && i < p.Sq;
+                        float x = s[ti][r] * sc2;
+                        if (MASK == 1) x += mk1;
+                        if (MASK == 2) x += p.mask[((int64_t)b * p.Sq + (i < p.Sq ? i : p.Sq - 1)) * p.Sk + jc] * LOG2E;
+                        float pv = __builtin_amdgcn_exp2f(x - lv[r]);
+                        float dm = 1.f;
+                        if (DROP) dm = drop_hash_t(h0, tq + (unsigned)(ti * 16 + r) * tstep) >= thr ? inv_keep : 0.f;
+                        const float ds = pv * fmaf(dp[ti][r] * dm, p.scale, -dv4[r]);
+                        pv *= dm;      // dV sees the dropped probabilities
+                        pr[ti][r] = ok ? pv : 0.f;
+                        s[ti][r] = ok ? ds : 0.f;
+                    }
+                    // dS^T of this key block -> the wave's strip image [key][query] (256-byte rows, the tiles' swizzle)
+                    const int row = kbk * 16 + (lane & 15), ch = ti * 2 + (g >> 1);
+                    *(LDS_AS s16x4*)(dst + row * 256 + ((ch ^ swz_key<0>(row)) << 4) + (g & 1) * 8) = pack4<T>(s[ti][0], s[ti][1], s[ti][2], s[ti][3]);
+                }
+                // dV^T = dO^T P, dK^T = Q^T dS over all queries: complete for these 16 keys
+                f32x4 dva[4], dka[4];
+#pragma unroll
+                for (int td = 0; td < 4; ++td) {
+                    dva[td] = zero4;
+                    dka[td] = zero4;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    if (2 * s2 >= nti) continue;
+                    const s16x8 pf = pack_pair<T>(pr[2 * s2], s2 < 2 ? pr[2 * s2 + 1] : zero4);
+                    const s16x8 df = pack_pair<T>(s[2 * s2], s2 < 2 ? s[2 * s2 + 1] : zero4);
+#pragma unroll
+                    for (int td = 0; td < 4; ++td) {
+                        dva[td] = T16<T>::mfma(sq_tr_frag(dot, td, s2, lane), pf, dva[td]);
+                        dka[td] = T16<T>::mfma(sq_tr_frag(qt, td, s2, lane), df, dka[td]);
+                    }
+                }
+                if (jv) {
+                    T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * HD;
+                    T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * HD;
+#pragma unroll
+                    for (int td = 0; td < 4; ++td) {
+                        const int d = td * 16 + g * 4;
+                        *(s16x4*)(dkb + d) = pack4<T>(dka[td][0], dka[td][1], dka[td][2], dka[td][3]);
+                        *(s16x4*)(dvb + d) = pack4<T>(dva[td][0], dva[td][1], dva[td][2], dva[td][3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // dQ^T[d][query] += K^T[d][key] dS^T[key][query]: this wave's query block over the round's strips
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if ((rd * 4 + st) * 32 >= p.Sk) continue;
+            LDS_AS const char* skt = strips + st * S::WAVE;
+            LDS_AS const char* sdst = skt + S::KT;
+            if (wave < nti) {
+                const s16x8 dsf = lds_tr_frag<64, 0>(sdst, wave, 0, lane);
+#pragma unroll
+                for (int td = 0; td < 4; ++td) dqw[td] = T16<T>::mfma(sq_tr_frag(skt, td, 0, lane), dsf, dqw[td]);
+            }
+            if (nti == 5) dq4 = T16<T>::mfma(sq_tr_frag(skt, wave, 0, lane), lds_tr_frag<64, 0>(sdst, 4, 0, lane), dq4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[kbk][ks] = nkf[kbk][ks];
+                vf[kbk][ks] = nvf[kbk][ks];
+            }
+    }
+
+    // ---- dQ: lane = (query l & 15 of the block, d = 16 td + 4 g + r) ----
+    {
+        const int i = wave * 16 + (lane & 15);
+        if (i < p.Sq) {
+            T* dqb = dq + (int64_t)b * p.q_bs + (int64_t)i * p.q_rs + h * HD;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) *(s16x4*)(dqb + td * 16 + g * 4) = pack4<T>(dqw[td][0], dqw[td][1], dqw[td][2], dqw[td][3]);
+        }
+        const int i4 = 64 + (lane & 15);
+        if (i4 < p.Sq)
+            *(s16x4*)(dq + (int64_t)b * p.q_bs + (int64_t)i4 * p.q_rs + h * HD + wave * 16 + g * 4) = pack4<T>(dq4[0], dq4[1], dq4[2], dq4[3]);
+    }
+}
+
 int check_params(const mico_attn_params* p, const char* who) {
     MICO_CHECK(p, "%s: null params", who);
     MICO_CHECK(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Sk > 0, "%s: empty problem", who);
@@ -2047,6 +2306,19 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 block(256);
+    // short query sequences at hd 64 (BERT's self- and cross-attention): the fused one-pass kernel
+    static const bool no_smallq = getenv("MICO_ATTN_NOSMALLQ") != nullptr;   // A/B switch (tools/probes/drop_cost.py)
+    if (!no_smallq && p->hd == 64 && p->Sq <= SqCfg::QMAX && (p->drop_p <= 0.f || (unsigned long long)p->B * p->H * p->Sq * p->Sk <= 0xFFFFFFFFull)) {
+        const dim3 grid(p->H, p->B);
+#define SQ_LAUNCH(DROP, MASK) MICO_LAUNCH((attn_bwd_smallq_kernel<T, DROP, MASK>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, *p)
+        DISPATCH_T16(dtype, {
+            if (p->drop_p > 0.f) { if (p->mask_mode == 0) SQ_LAUNCH(true, 0); else if (p->mask_mode == 1) SQ_LAUNCH(true, 1); else SQ_LAUNCH(true, 2); }
+            else { if (p->mask_mode == 0) SQ_LAUNCH(false, 0); else if (p->mask_mode == 1) SQ_LAUNCH(false, 1); else SQ_LAUNCH(false, 2); }
+        });
+#undef SQ_LAUNCH
+        MICO_LAUNCH_CHECK();
+        return MICO_OK;
+    }
     const dim3 gq((p->Sq + 63) / 64, p->H, p->B), gk((p->Sk + 63) / 64, p->H, p->B);
     static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;
     const bool res = !no_res && p->kv_batch_mod == 0 && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 &&

@@ -145,6 +145,16 @@ __device__ __forceinline__ unsigned drop_hash(unsigned seed, int site, unsigned 
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h >> 8;
 }
+// drop_hash() of an index below 2^32 (its high-word term vanishes) whose low-word product t = (unsigned)idx * 0x85EBCA6B the caller
+// carries incrementally (idx + n -> t + n * 0x85EBCA6B): the attention kernels' per-score decision without the 64-bit index
+// arithmetic and one of the three 32-bit multiplies.  h0 = seed ^ site * 0x9E3779B9.
+__device__ __forceinline__ unsigned drop_hash_t(unsigned h0, unsigned t) {
+    unsigned h = h0 ^ t;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h >> 8;
+}
 // multiplier of element idx: 0 or 1/(1-p).  thr = (unsigned)(p * 2^24), inv_keep = 1/(1-p)
 __device__ __forceinline__ float drop_mult(unsigned seed, int site, unsigned long long idx, unsigned thr, float inv_keep) {
     return drop_hash(seed, site, idx) >= thr ? inv_keep : 0.f;

@@ -337,6 +337,57 @@ def test_attention(cuda, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Sq,Sk,mask_kind,drop", [(77, 1285, None, (0.1, 99, 5)), (77, 77, "2d", (0.1, 7, 3)), (40, 100, "3d", (0.25, 1, 0)),
+                                                  (80, 33, None, None), (1, 65, "2d", (0.1, 5, 1)), (13, 32, None, (0.1, 5, 2))])
+def test_attention_short_queries(cuda, dtype, Sq, Sk, mask_kind, drop):
+    """The one-pass backward for Sq <= 80 at hd 64 (attn_bwd_smallq_kernel: BERT's self- and cross-attention) against autograd through
+    the same attention with the dropout multipliers of the restated hash (oracle.drop_mask over [B, H, Sq, Sk]) - every strip class:
+    whole 32-key strips, a ragged last strip, fewer strips than waves, one query, masks of both ranks; dQ / dK / dV ROW-wise."""
+    from mico_amd import ops
+    from oracle import mico_oracle as O
+    torch.manual_seed(Sq * 1000 + Sk)
+    B, H, hd = 3, 12, 64
+    D = H * hd
+    scale = hd ** -0.5
+    mask = None
+    if mask_kind == "2d":
+        keep = (torch.arange(Sk, device=cuda)[None] < torch.tensor([Sk, max(1, Sk // 3), 1], device=cuda)[:, None]).float()
+        mask = (1 - keep) * -10000.0
+    elif mask_kind == "3d":
+        keep = (torch.arange(Sk, device=cuda)[None, None] <= (torch.arange(Sq, device=cuda)[None, :, None] + Sk - Sq)).float().expand(B, Sq, Sk)
+        mask = ((1 - keep) * -10000.0).contiguous()
+    q = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    k = torch.randn(B, Sk, D, device=cuda).to(dtype)
+    v = torch.randn(B, Sk, D, device=cuda).to(dtype)
+    do = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    qf = q.float().reshape(B, Sq, H, hd).detach().requires_grad_(True)
+    kf = k.float().reshape(B, Sk, H, hd).detach().requires_grad_(True)
+    vf = v.float().reshape(B, Sk, H, hd).detach().requires_grad_(True)
+    sc = torch.einsum("bihd,bjhd->bhij", qf, kf) * scale
+    if mask is not None:
+        sc = sc + (mask[:, None, None, :] if mask.dim() == 2 else mask[:, None])
+    pr = sc.softmax(-1)
+    if drop is not None:
+        pr = pr * O.drop_mask(drop[1], drop[2], (B, H, Sq, Sk), drop[0]).to(cuda)
+    ref = torch.einsum("bhij,bjhd->bihd", pr, vf)
+    ref.backward(do.float().reshape(B, Sq, H, hd))
+    o = torch.empty(B, Sq, D, device=cuda, dtype=dtype)
+    lse = torch.empty(B, H, Sq, device=cuda)
+    kw = dict(B=B, H=H, Sq=Sq, Sk=Sk, hd=hd, scale=scale, mask=mask, drop=drop, q_strides=(Sq * D, D), k_strides=(Sk * D, D), v_strides=(Sk * D, D),
+              o_strides=(Sq * D, D))
+    ops.attn_fwd(q, k, v, o, lse, **kw)
+    dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+    delta = torch.empty(B, H, Sq, device=cuda)
+    ops.attn_bwd(q, k, v, o, do, lse, dq, dk, dv, delta, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(o, ref.reshape(B, Sq, D)) < tol(dtype, 1.5)
+    for name, got, want in (("dq", dq, qf.grad.reshape(B, Sq, D)), ("dk", dk, kf.grad.reshape(B, Sk, D)), ("dv", dv, vf.grad.reshape(B, Sk, D))):
+        assert torch.isfinite(got.float()).all(), name
+        err = (got.float() - want).norm(dim=-1) / want.norm(dim=-1).max().clamp_min(1e-20)     # per row, against the largest row
+        assert err.max().item() < tol(dtype, 4), (name, err.max().item(), err.argmax().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_elementwise(cuda, dtype):
     from mico_amd import ops
     torch.manual_seed(5)
