@@ -1,13 +1,16 @@
-import torch, sys
+"""Weight-gradient GEMM (dW = dy^T x, producer/consumer kernel, split-K slabs) against a uniform K split (--split-k semantics of ops.gemm;
+0 = the library's choice).  Each configuration is warmed up: the first timing in a process otherwise reads ~10 % low (clock ramp).
+DW_TOKENS=<rows> changes the reduction length (the kept-token count varies per block in situ)."""
+import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from mico_amd import ops
 dev = torch.device("cuda:0")
-M = 82240
+M = int(os.environ.get("DW_TOKENS", "82240"))
 def run(kin, nout, sk, iters=20):
     x = torch.randn(M, kin, device=dev).half(); dy = torch.randn(M, nout, device=dev).half()
     dw = torch.zeros(nout, kin, device=dev)
     fn = lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=nout, N=kin, K=M, accumulate=True, split_k=sk)
-    for _ in range(3): fn()
+    for _ in range(8): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
