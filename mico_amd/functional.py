@@ -35,14 +35,21 @@ def _empty(shape, dtype, dev):
 
 class GradArena:
     """fp32 parameter-gradient storage of one backward pass: ONE zero-filled flat buffer with a view per parameter (a ViT-g
-    backward otherwise issues ~1600 tiny fill launches per step).  Parameters nobody asked a view for report None."""
+    backward otherwise issues ~1600 tiny fill launches per step).  Parameters nobody asked a view for report None.
+    groups: lists of parameter positions whose views must be ADJACENT in the given order (BERT's query | key | value weights: the
+    fused [3 D, D] weight-gradient GEMM then accumulates straight into them, fused())."""
 
-    def __init__(self, params):
+    def __init__(self, params, groups=None):
         self.shapes = [tuple(p.shape) for p in params]
-        self.offsets, n = [], 0
-        for p in params:
-            self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.offsets, n = [None] * len(params), 0
+        lead = {g[0]: g for g in (groups or [])}
+        for i, p in enumerate(params):
+            if self.offsets[i] is not None:
+                continue
+            for j in lead.get(i, [i]):
+                assert self.offsets[j] is None and (j == i or j > i), "a group follows its first member"
+                self.offsets[j] = n
+                n += (params[j].numel() + 3) // 4 * 4          # keep every view 16-byte aligned
         self.flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
         self.views = [None] * len(params)
 
@@ -54,6 +61,15 @@ class GradArena:
                 numel *= d
             self.views[i] = self.flat[o:o + numel].view(self.shapes[i])
         return self.views[i]
+
+    def fused(self, idxs, shape):
+        """one view over the adjacent parameters idxs (a group of the constructor), shaped `shape`"""
+        n = 0
+        for a, b in zip(idxs, idxs[1:]):
+            assert self.offsets[b] == self.offsets[a] + self.get(a).numel(), "not adjacent (numel % 4 != 0 or not a group)"
+        for i in idxs:
+            n += self.get(i).numel()
+        return self.flat[self.offsets[idxs[0]]:self.offsets[idxs[0]] + n].view(shape)
 
     def span(self, i0, i1):
         """flat slice covering parameters i0 .. i1-1 (every one of them gets a view)."""
@@ -901,6 +917,14 @@ class BertSpec:
         self.names = names
         self.idx = {n: i for i, n in enumerate(names)}
         self.L, self.H, self.D, self.I, self.eps = n_layers, heads, hidden, inter, eps
+        # gradient views that the fused projections' weight-gradient GEMMs write as one matrix (GradArena groups)
+        self.grad_groups = []
+        for li in range(n_layers):
+            for att, parts in (("attention", ("query", "key", "value")), ("crossattention", ("key", "value"))):
+                for kind in ("weight", "bias"):
+                    ns = [f"encoder.layer.{li}.{att}.self.{q}.{kind}" for q in parts]
+                    if all(n in self.idx for n in ns):
+                        self.grad_groups.append([self.idx[n] for n in ns])
 
 
 def _fused_w(key, plist, dt_unused=None):
@@ -1111,10 +1135,13 @@ class BertFn(torch.autograd.Function):
         Sg = runtime.grad_scale()
         inv_s = 1.0 / Sg
         scale = 1.0 / math.sqrt(hd)
-        grads = GradArena(params)
+        grads = GradArena(params, spec.grad_groups)
 
         def G(name):
             return grads.get(spec.idx[name])
+
+        def GF(names, shape):   # the adjacent gradient views of a fused projection as one matrix / vector
+            return grads.fused([spec.idx[n] for n in names], shape)
 
         g = dseq.contiguous().view(rows, D).float().clone()
         dcond = torch.zeros((b * E, D), dtype=torch.float32, device=dev) if cond16 is not None else None
@@ -1133,13 +1160,6 @@ class BertFn(torch.autograd.Function):
             if ph > 0:
                 ops.dropout_(d16, (ph, dseed, site))
             return d16
-
-        def split_rows(dwf, names):
-            o = 0
-            for n in names:
-                k = params[spec.idx[n]].shape[0]
-                G(n).add_(dwf[o:o + k])
-                o += k
 
         for li in reversed(range(spec.L)):
             p = f"encoder.layer.{li}."
@@ -1176,12 +1196,8 @@ class BertFn(torch.autograd.Function):
                         torch.add(dkv[:ne], dkv[2 * ne:], out=dkv_own[li])
                         dkv_neg[li].copy_(dkv[ne:2 * ne])
                 else:
-                    dwkv = torch.zeros((2 * D, D), dtype=torch.float32, device=dev)
-                    linear_wgrad(dkv, cond16, dwkv, inv_s)
-                    split_rows(dwkv, [ca + "key.weight", ca + "value.weight"])
-                    dbkv = torch.zeros(2 * D, dtype=torch.float32, device=dev)
-                    ops.colsum(dkv, dbkv, scale=inv_s)
-                    split_rows(dbkv, [ca + "key.bias", ca + "value.bias"])
+                    linear_wgrad(dkv, cond16, GF([ca + "key.weight", ca + "value.weight"], (2 * D, D)), inv_s)
+                    ops.colsum(dkv, GF([ca + "key.bias", ca + "value.bias"], (2 * D,)), scale=inv_s, accumulate=True)
                 if ctx.cond_needs_grad:
                     wkv = _fused_w("bkv", [P(ca + "key.weight"), P(ca + "value.weight")])
                     ops.gemm(dkv, wkv, dcond, tb=True, M=b * E, N=D, K=2 * D, alpha=inv_s, accumulate=True)
@@ -1200,12 +1216,8 @@ class BertFn(torch.autograd.Function):
             st = dict(q_strides=(S * 3 * D, 3 * D), k_strides=(S * 3 * D, 3 * D), v_strides=(S * 3 * D, 3 * D), o_strides=(S * D, D))
             ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["co"], dco, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
                          B=b, H=H, Sq=S, Sk=S, hd=hd, scale=scale, mask=mask, drop=at_drop(li * 8 + SITE_SELF_P), **st)
-            dwf = torch.zeros((3 * D, D), dtype=torch.float32, device=dev)
-            linear_wgrad(dqkv, a["x16"], dwf, inv_s)
-            split_rows(dwf, [sa + "query.weight", sa + "key.weight", sa + "value.weight"])
-            dbf = torch.zeros(3 * D, dtype=torch.float32, device=dev)
-            ops.colsum(dqkv, dbf, scale=inv_s)
-            split_rows(dbf, [sa + "query.bias", sa + "key.bias", sa + "value.bias"])
+            linear_wgrad(dqkv, a["x16"], GF([sa + "query.weight", sa + "key.weight", sa + "value.weight"], (3 * D, D)), inv_s)
+            ops.colsum(dqkv, GF([sa + "query.bias", sa + "key.bias", sa + "value.bias"], (3 * D,)), scale=inv_s, accumulate=True)
             wqkv = _fused_w("bqkv", [P(sa + "query.weight"), P(sa + "key.weight"), P(sa + "value.weight")])
             ops.gemm(dqkv, wqkv, g, tb=True, M=rows, N=D, K=3 * D, alpha=inv_s, resid=g)
             del a, dqkv, dco, d16
