@@ -174,13 +174,19 @@ int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
  * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced
  * and ACCUMULATED (+=) into dgamma/dbeta (fp32 [cols]) scaled by grad_scale.
  * frame_map (optional): dx_add and dx32 are indexed with the scattered row
- * frame_map[r / rows_per_frame] * rows_per_frame + r % rows_per_frame (dy, x, mean, rstd, dx16 stay compact). */
+ * frame_map[r / rows_per_frame] * rows_per_frame + r % rows_per_frame (dy, x, mean, rstd, dx16 stay compact).
+ * dx16_dst (optional, int32 per compact frame; needs rows_per_frame): dx16 is the 16-bit operand of the NEXT consumer, which keeps another
+ * frame set - compact frame j goes to frame slot dx16_dst[j] of dx16 (< 0: not kept there, not written) and is multiplied by
+ * scale16 * dx16_frame_scale[scattered frame] (dx16_frame_scale optional, fp32 per frame of the full stream).  Replaces the
+ * mico_gather_rows_cast pass over the frames both sets share (the stochastic-depth backward: the residual-stream gradient a branch's
+ * LayerNorm backward just produced is what the next branch's GEMMs read). */
 int mico_layernorm_bwd_nblk(int64_t rows);
 int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        const float* dx_add, float* dx32, void* dx16, float scale16,
                        float* dgamma, float* dbeta, float grad_scale, float* ws,
-                       int64_t rows, int cols, const int* frame_map, int rows_per_frame, int valid_cols, int dtype, void* stream);
+                       int64_t rows, int cols, const int* frame_map, int rows_per_frame, int valid_cols,
+                       const int* dx16_dst, const float* dx16_frame_scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (flash style: scores never materialised), forward and backward.
@@ -241,11 +247,13 @@ int mico_cast_16_to_f32(const void* src, int64_t ld_src, float* dst, int64_t ld_
 /* dst16[m', :] = T(scale * row_scale[m'/rows_per_scale] * src32[m, :]) with the same row remap as the GEMM epilogue
  * (gathers token rows out of the residual-gradient stream, skipping CLS rows).  rows = number of output rows.
  * frame_map (optional, int32): source row = frame_map[m' / rows_per_frame] * rows_per_frame + m' % rows_per_frame
- * (compacting gather of whole frames); row_scale is indexed with the SOURCE row in both remap modes. */
+ * (compacting gather of whole frames); row_scale is indexed with the SOURCE row in both remap modes.
+ * dst_map (optional, with frame_map): frame j of the list is written to frame slot dst_map[j] of dst instead of slot j (rows then counts the
+ * listed frames' rows) - the frames a fused producer (mico_layernorm_bwd's dx16_dst) did not cover. */
 int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
                           int remap_group, int remap_skip, int remap_offset,
                           const float* row_scale, int rows_per_scale, float scale,
-                          const int* frame_map, int rows_per_frame, int dtype, void* stream);
+                          const int* frame_map, int rows_per_frame, const int* dst_map, int dtype, void* stream);
 /* In-place dropout x[r, c] *= keep(r * cols + c) / (1 - p) on an fp32 or 16-bit [rows, cols] tensor (leading dim ld): the
  * backward of every hidden-state dropout (the same mask multiplies the gradient).  keep() is a stateless counter hash of
  * (seed, site, index) - no mask tensor exists anywhere:

@@ -48,19 +48,23 @@ template <typename T>
 __global__ void gather_rows_cast_kernel(const float* __restrict__ src, int64_t ld_src, T* __restrict__ dst, int64_t ld_dst,
                                         int64_t rows, int cols, int remap_group, int remap_skip, int remap_offset,
                                         const float* __restrict__ row_scale, int rows_per_scale, float scale,
-                                        const int* __restrict__ frame_map, int rpf) {
+                                        const int* __restrict__ frame_map, int rpf, const int* __restrict__ dst_map) {
     const int vpr = cols >> 2;
     const int64_t total = rows * vpr;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
         const int64_t r = i / vpr;
         const int c = (int)(i - r * vpr) * 4;
-        int64_t rs = r;
+        int64_t rs = r, rd = r;
         if (remap_group) rs = r + (r / remap_group) * remap_skip + remap_offset;
-        else if (frame_map) { const int64_t f = r / rpf; rs = (int64_t)frame_map[f] * rpf + (r - f * rpf); }
+        else if (frame_map) {
+            const int64_t f = r / rpf;
+            rs = (int64_t)frame_map[f] * rpf + (r - f * rpf);
+            if (dst_map) rd = (int64_t)dst_map[f] * rpf + (r - f * rpf);   // frame f of the list lands in frame slot dst_map[f]
+        }
         float sc = scale;
         if (row_scale) sc *= row_scale[rs / rows_per_scale];
         f32x4 v = *(const f32x4*)(src + rs * ld_src + c) * sc;
-        *(s16x4*)(dst + r * ld_dst + c) = pack4<T>(v[0], v[1], v[2], v[3]);
+        *(s16x4*)(dst + rd * ld_dst + c) = pack4<T>(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -427,14 +431,15 @@ extern "C" int mico_cast_16_to_f32(const void* src, int64_t ld_src, float* dst, 
 
 extern "C" int mico_gather_rows_cast(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols,
                                      int remap_group, int remap_skip, int remap_offset, const float* row_scale,
-                                     int rows_per_scale, float scale, const int* frame_map, int rows_per_frame, int dtype,
-                                     void* stream) {
+                                     int rows_per_scale, float scale, const int* frame_map, int rows_per_frame, const int* dst_map,
+                                     int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype) && src && dst, "mico_gather_rows_cast: bad args");
+    if (dst_map) MICO_CHECK(frame_map != nullptr, "mico_gather_rows_cast: dst_map goes with frame_map");
     MICO_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "mico_gather_rows_cast: cols/ld must be multiples of 4");
     if (row_scale) MICO_CHECK(rows_per_scale > 0, "mico_gather_rows_cast: rows_per_scale");
     if (frame_map) MICO_CHECK(rows_per_frame > 0 && !remap_group, "mico_gather_rows_cast: frame_map needs rows_per_frame > 0 and no remap_group");
     if (rows <= 0) return MICO_OK;
-    DISPATCH_T16(dtype, MICO_LAUNCH(gather_rows_cast_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, remap_group, remap_skip, remap_offset, row_scale, rows_per_scale, scale, frame_map, rows_per_frame));
+    DISPATCH_T16(dtype, MICO_LAUNCH(gather_rows_cast_kernel<T>, dim3(egrid(rows * (cols / 4))), dim3(EB), 0, ST, src, ld_src, (T*)dst, ld_dst, rows, cols, remap_group, remap_skip, remap_offset, row_scale, rows_per_scale, scale, frame_map, rows_per_frame, dst_map));
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

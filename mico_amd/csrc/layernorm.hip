@@ -126,7 +126,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            const float* __restrict__ rstd, const float* __restrict__ dx_add,
                                                            float* __restrict__ dx32, T* __restrict__ dx16, float scale16,
                                                            float* __restrict__ ws, int64_t rows, int cols, float dy_scale,
-                                                           const int* __restrict__ frame_map, int rpf, int valid_cols) {
+                                                           const int* __restrict__ frame_map, int rpf, int valid_cols,
+                                                           const int* __restrict__ dx16_dst, const float* __restrict__ dx16_fscale) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -158,7 +159,20 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
         }
         const float c1 = wave_sum(s1) * inv, c2 = wave_sum(s2) * inv;
         int64_t orow = row;   // scattered row of the residual-gradient stream (dx_add / dx32)
-        if (frame_map) { const int64_t f = row / rpf; orow = (int64_t)frame_map[f] * rpf + (row - f * rpf); }
+        int64_t fidx = 0, fpos = 0;
+        if (frame_map || dx16_dst) { fpos = row / rpf; fidx = frame_map ? frame_map[fpos] : fpos; }
+        if (frame_map) orow = fidx * rpf + (row - fpos * rpf);
+        // dx16 for the NEXT consumer's frame set (dx16_dst): frame slot dx16_dst[compact frame] of a compact 16-bit buffer, or none (< 0);
+        // its per-frame multiplier dx16_fscale[scattered frame] rides along
+        int64_t drow = row;
+        float s16 = scale16;
+        bool w16 = dx16 != nullptr;
+        if (dx16_dst) {
+            const int d = dx16_dst[fpos];
+            w16 = d >= 0;
+            drow = (int64_t)d * rpf + (row - fpos * rpf);
+            if (dx16_fscale) s16 *= dx16_fscale[fidx];
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
@@ -166,9 +180,9 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                 f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
                 if (dx_add) o += *(const f32x4*)(dx_add + orow * cols + c * 4);
                 if (dx32) *(f32x4*)(dx32 + orow * cols + c * 4) = o;
-                if (dx16) {
-                    o *= scale16;
-                    *(s16x4*)(dx16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+                if (w16) {
+                    o *= s16;
+                    *(s16x4*)(dx16 + drow * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
                 }
             }
         }
@@ -254,8 +268,8 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
 template <typename T, typename DT, typename XT>
 void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                    const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
-                   int cols, float dy_scale, const int* fmap, int rpf, int valid) {
-#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf, valid)
+                   int cols, float dy_scale, const int* fmap, int rpf, int valid, const int* d16dst, const float* d16scale) {
+#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf, valid, d16dst, d16scale)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else if (cols <= 2048) LNB(8);
@@ -296,8 +310,10 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
 extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype, const float* gamma,
                                   const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
                                   float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
-                                  int cols, const int* frame_map, int rows_per_frame, int valid_cols, int dtype, void* stream) {
+                                  int cols, const int* frame_map, int rows_per_frame, int valid_cols,
+                                  const int* dx16_dst, const float* dx16_frame_scale, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
+    if (dx16_dst) MICO_CHECK(dx16 && rows_per_frame > 0, "mico_layernorm_bwd: dx16_dst needs dx16 and rows_per_frame > 0");
     if (valid_cols <= 0) valid_cols = cols;
     MICO_CHECK(valid_cols <= cols, "mico_layernorm_bwd: valid_cols > cols");
     if (rows <= 0) return MICO_OK;
@@ -312,10 +328,10 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     const dim3 grid(nblk);
     float* wsp = (dgamma || dbeta) ? ws : nullptr;
     DISPATCH_T16(dtype, {
-        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
-        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
-        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
-        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols);
+        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
+        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
+        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
+        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {

@@ -227,6 +227,31 @@ class DropPlan:
         for c in self.counts:
             self.starts.append(self.starts[-1] + c)
         self.n_frames = n_frames
+        # Backward hand-over between consecutive branches (j = 2 block + which is processed in DEScending order): the LayerNorm backward of
+        # branch j produces the residual-stream gradient that branch j - 1's GEMMs read as a compact 16-bit operand over ITS kept frames.
+        # For every j >= 1: where each kept frame of j sits in j - 1's compact list (-1: not kept there), and the frames only j - 1 keeps.
+        pos = keep.long().cumsum(1) - 1
+        dsts, dfr, ddst, self.tr_dst_starts, self.tr_diff_starts = [], [], [], [0], [0]
+        for j in range(1, keep.shape[0]):
+            fx = keep[j].nonzero()[:, 0]
+            dsts.append(torch.where(keep[j - 1, fx], pos[j - 1, fx], torch.full_like(fx, -1)))
+            only = (keep[j - 1] & ~keep[j]).nonzero()[:, 0]
+            dfr.append(only)
+            ddst.append(pos[j - 1, only])
+            self.tr_dst_starts.append(self.tr_dst_starts[-1] + fx.numel())
+            self.tr_diff_starts.append(self.tr_diff_starts[-1] + only.numel())
+        cat = lambda xs: (torch.cat(xs) if xs else torch.zeros(0, dtype=torch.long)).to(torch.int32).to(dev)
+        self.tr_dst, self.tr_diff_frames, self.tr_diff_dst = cat(dsts), cat(dfr), cat(ddst)
+
+    def transition(self, block, which):
+        """Hand-over from branch j = 2 block + which to branch j - 1 in the backward: (slot of each of j's kept frames in j - 1's compact
+        list or -1, the frames only j - 1 keeps, their slots) as int32 device tensors; None for j = 0."""
+        j = block * 2 + which
+        if j == 0:
+            return None
+        a0, a1 = self.tr_dst_starts[j - 1], self.tr_dst_starts[j]
+        d0, d1 = self.tr_diff_starts[j - 1], self.tr_diff_starts[j]
+        return self.tr_dst[a0:a1], self.tr_diff_frames[d0:d1], self.tr_diff_dst[d0:d1]
 
     def branch(self, block, which):
         """-> (kept frame count, int32 device frame list or None when every frame is kept, [Bf] scale vector)"""
@@ -296,7 +321,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
             runtime.CFG.split_mode = _TAIL_EXP[1]
         # --- attention branch: x <- x + s1 * proj(attn(LN1 x)) on the kept frames ---
         B1, fmap1, sc1 = branch_io(i, 0)
-        a.update(B1=B1, fmap1=fmap1, sc1=sc1)
+        a.update(B1=B1, fmap1=fmap1, sc1=sc1, tr1=plan.transition(i, 0) if plan is not None else None)
         if B1 > 0:
             M1 = B1 * N
             xc1 = _empty((M1, D), torch.float32, dev) if fmap1 is not None else None
@@ -326,7 +351,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
             x = x_mid
         # --- MLP branch ---
         B2, fmap2, sc2 = branch_io(i, 1)
-        a.update(B2=B2, fmap2=fmap2, sc2=sc2)
+        a.update(B2=B2, fmap2=fmap2, sc2=sc2, tr2=plan.transition(i, 1) if plan is not None else None)
         if B2 > 0:
             M2 = B2 * N
             xc2 = _empty((M2, D), torch.float32, dev) if fmap2 is not None else None
@@ -414,6 +439,31 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
     del x_last
     Hd = spec.hidden
     pstate = runtime.snapshot()
+    fuse = runtime.CFG.fuse_grad_handover
+
+    def take_g16(pre, rows, fmap, sc):
+        """The branch's 16-bit gradient operand [rows, D] = S * sc[frame] * g over its kept frames: handed over by the previous LayerNorm
+        backward (only the frames that branch did not keep are still gathered), or gathered whole."""
+        if pre is not None:
+            g16, dframes, ddst = pre
+            if dframes is not None and dframes.numel() > 0:
+                ops.gather_rows_cast(g, g16, row_scale=sc, rows_per_scale=N, scale=S, frame_map=dframes, rows_per_frame=N, dst_map=ddst)
+            return g16
+        g16 = _empty((rows, D), dt, dev)
+        ops.gather_rows_cast(g, g16, row_scale=sc, rows_per_scale=N, scale=S, frame_map=fmap, rows_per_frame=N)
+        return g16
+
+    def handover(tr, nb, nsc, had_plan):
+        """LayerNorm-backward arguments that make it write the next branch's operand (nb kept frames, per-frame scale nsc), and the `pre`
+        tuple for take_g16().  tr: DropPlan.transition of the current branch (None without a plan: both branches keep every frame)."""
+        if not fuse or nb <= 0 or (had_plan and tr is None):
+            return {}, None
+        g16n = _empty((nb * N, D), dt, dev)
+        if tr is None:
+            return dict(dx16=g16n, scale16=S), (g16n, None, None)
+        return dict(dx16=g16n, scale16=S, dx16_dst=tr[0], dx16_frame_scale=nsc), (g16n, tr[1], tr[2])
+
+    pre = None
     for i in reversed(range(arch["depth_built"])):
         b = f"blocks.{i}."
         a = saved["acts"].pop()
@@ -421,8 +471,8 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
         # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
         if a["B2"] > 0:
             M2, fmap2 = a["B2"] * N, a["fmap2"]
-            g16 = _empty((M2, D), dt, dev)
-            ops.gather_rows_cast(g, g16, row_scale=a["sc2"], rows_per_scale=N, scale=S, frame_map=fmap2, rows_per_frame=N)
+            g16 = take_g16(pre, M2, fmap2, a["sc2"])
+            pre = None
             # gradient at the LayerNorm output: 16-bit like every other gradient operand (dqkv, dH, g16 carry the same scale) - the input-gradient
             # GEMM writes half the bytes and the LayerNorm backward reads half; the SwiGLU path accumulates two GEMMs into it and stays fp32
             dln2 = _empty((M2, D), torch.float32 if (arch["swiglu"] or not runtime.CFG.ln_grad_16bit) else dt, dev)
@@ -478,16 +528,19 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
                 _gemm_dx(dh, [w1], "w", dln2)
                 del dh
+            ho, pre = handover(a["tr2"], a["B1"], a["sc1"], a["sc2"] is not None)
             ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt, frame_map=fmap2,
-                              rows_per_frame=N)
+                              rows_per_frame=N, **ho)
             del dln2, g16
+        else:
+            pre = None
         # ---------------- attention branch ----------------
         if a["B1"] > 0:
             B1, fmap1 = a["B1"], a["fmap1"]
             M1 = B1 * N
-            g16 = _empty((M1, D), dt, dev)
-            ops.gather_rows_cast(g, g16, row_scale=a["sc1"], rows_per_scale=N, scale=S, frame_map=fmap1, rows_per_frame=N)
+            g16 = take_g16(pre, M1, fmap1, a["sc1"])
+            pre = None
             wp = P(b + "attn.proj.weight")
             proj_in = a["aln"] if arch["subln"] else a["ao"]
             linear_wgrad(g16, proj_in, G(b + "attn.proj.weight"), inv_s, dbias=G(b + "attn.proj.bias"))
@@ -522,10 +575,14 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             G(b + "attn.v_bias").add_(dbias[2 * D:])
             dln1 = _empty((M1, D), dt if runtime.CFG.ln_grad_16bit else torch.float32, dev)
             _gemm_dx(dqkv, _qkv_params(P, b, arch), "qkv", dln1)
+            nxt = saved["acts"][-1] if saved["acts"] else None     # block i - 1: its MLP branch is next
+            ho, pre = handover(a["tr1"], nxt["B2"], nxt["sc2"], a["sc1"] is not None) if nxt is not None else ({}, None)
             ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,
-                              rows_per_frame=N)
+                              rows_per_frame=N, **ho)
             del dqkv, dao, dln1, g16
+        else:
+            pre = None
         del a
         if hook is not None:      # every gradient of block i is final: its arena slice can be reduced now
             i0, i1 = block_range[i]

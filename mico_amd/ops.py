@@ -219,8 +219,9 @@ def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rst
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
-                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0):
-    """frame_map: dx_add / dx32 are the full stream, addressed through the frame scatter; dy / x / mean / rstd are compact."""
+                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0, dx16_dst=None, dx16_frame_scale=None):
+    """frame_map: dx_add / dx32 are the full stream, addressed through the frame scatter; dy / x / mean / rstd are compact.
+    dx16_dst / dx16_frame_scale: dx16 is laid out for the next consumer's frame set (mico_layernorm_bwd in include/mico_hip.h)."""
     rows, cols = x.shape[0], x.shape[1]
     ws = None
     if dgamma is not None or dbeta is not None:
@@ -228,7 +229,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=N
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=x.device)
     rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), dy_scale, _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
                                        _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
-                                       _p(ws), rows, cols, _p(frame_map), rows_per_frame, int(valid_cols), dt_code(dtype), _st())
+                                       _p(ws), rows, cols, _p(frame_map), rows_per_frame, int(valid_cols), _p(dx16_dst), _p(dx16_frame_scale),
+                                       dt_code(dtype), _st())
     check(rc, "mico_layernorm_bwd")
 
 
@@ -306,11 +308,14 @@ def cast_16_to_f32(src, dst, *, scale=1.0, accumulate=False):
 
 
 def gather_rows_cast(src, dst, *, remap=(0, 0, 0), row_scale=None, rows_per_scale=0, scale=1.0, frame_map=None,
-                     rows_per_frame=0):
+                     rows_per_frame=0, dst_map=None):
+    """dst_map: the frames listed in frame_map land in the frame slots dst_map[j] of dst (only those rows are written)."""
     rows, cols = dst.shape
+    if dst_map is not None:
+        rows = frame_map.numel() * rows_per_frame
     check(_lib.lib().mico_gather_rows_cast(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, remap[0], remap[1],
                                            remap[2], _p(row_scale), rows_per_scale, scale, _p(frame_map), rows_per_frame,
-                                           dt_code(dst.dtype), _st()),
+                                           _p(dst_map), dt_code(dst.dtype), _st()),
           "mico_gather_rows_cast")
     return dst
 

@@ -25,6 +25,9 @@ class _Cfg:
     # what is split when split_fp16 is on: "full" = weights AND LayerNorm outputs (3 k-segments, x_hi W_hi + x_lo W_hi + x_hi W_lo),
     # "weights" = weights only (2 k-segments, x W_hi + x W_lo: removes the weight-rounding half of the error at 2x the MFMA work)
     split_mode = "full"
+    # the tower backward's LayerNorm backward writes the NEXT branch's 16-bit gradient operand itself (functional._tower_backward: handover);
+    # MICO_NO_GRAD_HANDOVER: A/B switch, every branch gathers its operand with mico_gather_rows_cast
+    fuse_grad_handover = os.environ.get("MICO_NO_GRAD_HANDOVER") is None
     ln_grad_16bit = os.environ.get("MICO_LN_GRAD_FP32") is None   # gradient at the LayerNorm outputs stored 16-bit (functional._tower_backward)
     head_split_blocks = 0     # plain fp16 only: the first n tower blocks in a split mode (see enter_block)
     head_split_mode = "weights"

@@ -196,6 +196,49 @@ def test_layernorm(cuda, dtype, cols, xdt):
     assert rel_err(y2, ref.detach() + table[idx]) < 2e-6
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("x_all", [False, True])
+def test_layernorm_bwd_handover(cuda, dtype, x_all):
+    """mico_layernorm_bwd's dx16_dst / dx16_frame_scale + mico_gather_rows_cast's dst_map: the LayerNorm backward of a branch that kept
+    frames X writes the 16-bit operand of the next branch (frames Y, per-frame scale) for the frames both keep, a gather over Y \ X fills
+    the rest - bit-identical to "update the stream, then gather all of Y" (the stochastic-depth backward, functional._tower_backward).
+    x_all: the producing branch kept every frame (no frame_map)."""
+    from mico_amd import ops
+    torch.manual_seed(17)
+    N, Bf, D, S = 5, 9, 256, 64.0
+    keep_x = [True] * Bf if x_all else [True, False, True, True, False, False, True, True, False]
+    keep_y = [False, True, True, False, False, True, True, True, True]
+    fx = torch.tensor([f for f in range(Bf) if keep_x[f]], device=cuda, dtype=torch.int32)
+    fy = torch.tensor([f for f in range(Bf) if keep_y[f]], device=cuda, dtype=torch.int32)
+    sc = torch.rand(Bf, device=cuda) + 0.5
+    rows = fx.numel() * N
+    x = torch.randn(rows, D, device=cuda)
+    dy = torch.randn(rows, D, device=cuda).to(dtype)
+    gmm = 1 + 0.1 * torch.randn(D, device=cuda)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-6).rsqrt()
+    g0 = torch.randn(Bf * N, D, device=cuda)
+    fmap = None if x_all else fx
+    # reference schedule: update the stream in place, then gather the next branch's frames
+    g_ref = g0.clone()
+    ops.layernorm_bwd(dy, x, gmm, mean, rstd, dy_scale=0.25, dx_add=g_ref, dx32=g_ref, dtype=dtype, frame_map=fmap, rows_per_frame=N)
+    want = torch.empty(fy.numel() * N, D, device=cuda, dtype=dtype)
+    ops.gather_rows_cast(g_ref, want, row_scale=sc, rows_per_scale=N, scale=S, frame_map=fy, rows_per_frame=N)
+    # hand-over
+    pos_y = {int(f): j for j, f in enumerate(fy.tolist())}
+    dst = torch.tensor([pos_y.get(int(f), -1) for f in fx.tolist()], device=cuda, dtype=torch.int32)
+    only = [f for f in fy.tolist() if not keep_x[f]]
+    g = g0.clone()
+    got = torch.full((fy.numel() * N, D), float("nan"), device=cuda, dtype=dtype)
+    ops.layernorm_bwd(dy, x, gmm, mean, rstd, dy_scale=0.25, dx_add=g, dx32=g, dx16=got, scale16=S, dtype=dtype, frame_map=fmap, rows_per_frame=N,
+                      dx16_dst=dst, dx16_frame_scale=sc)
+    if only:
+        ops.gather_rows_cast(g, got, row_scale=sc, rows_per_scale=N, scale=S, frame_map=torch.tensor(only, device=cuda, dtype=torch.int32),
+                             rows_per_frame=N, dst_map=torch.tensor([pos_y[f] for f in only], device=cuda, dtype=torch.int32))
+    torch.cuda.synchronize()
+    assert torch.equal(g, g_ref)
+    assert torch.equal(got, want)
+
+
 def _attn_ref(q, k, v, scale, mask):
     s = torch.einsum("bihd,bjhd->bhij", q, k) * scale
     if mask is not None:
