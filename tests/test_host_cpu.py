@@ -184,3 +184,39 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])
+
+
+def test_drop_plan_transitions_and_grad_arena_groups():
+    """Host logic behind two fused backward paths: DropPlan.transition (where each kept frame of a branch sits in the PREVIOUS branch's
+    compact list - the LayerNorm backward's dx16_dst - and which frames only that branch keeps) against a brute-force restatement; GradArena
+    groups (BERT's q | k | v gradient views adjacent, so the fused projection's weight-gradient GEMM accumulates into one matrix view)."""
+    from mico_amd.functional import DropPlan, GradArena
+    torch.manual_seed(0)
+    depth, Bf = 4, 11
+    sc = (torch.rand(depth, 2, Bf) > 0.35).float() * 1.25
+    sc[1, 0] = 1.25            # a branch that keeps everything
+    sc[2, 1] = 0.0             # and one that keeps nothing
+    stats = list(DropPlan.stats)
+    plan = DropPlan(sc, Bf, torch.device("cpu"))
+    DropPlan.stats[:] = stats
+    keep = (sc != 0).reshape(-1, Bf)
+    assert plan.transition(0, 0) is None
+    for j in range(1, 2 * depth):
+        dst, only, only_dst = plan.transition(j // 2, j % 2)
+        fx = keep[j].nonzero()[:, 0].tolist()
+        fy = keep[j - 1].nonzero()[:, 0].tolist()
+        assert dst.tolist() == [fy.index(f) if f in fy else -1 for f in fx]
+        assert only.tolist() == [f for f in fy if f not in fx]
+        assert only_dst.tolist() == [fy.index(f) for f in only.tolist()]
+        # together they cover the previous branch's compact list exactly once
+        assert sorted([d for d in dst.tolist() if d >= 0] + only_dst.tolist()) == list(range(len(fy)))
+    ps = [torch.zeros(8, 4), torch.zeros(8), torch.zeros(8, 4), torch.zeros(8), torch.zeros(8, 4), torch.zeros(8), torch.zeros(5)]
+    ar = GradArena(ps, [[0, 2, 4], [1, 3, 5]])
+    ar.fused([0, 2, 4], (24, 4)).copy_(torch.arange(96.0).view(24, 4))
+    ar.fused([1, 3, 5], (24,)).fill_(7.0)
+    assert torch.equal(ar.get(2), torch.arange(32.0, 64.0).view(8, 4)) and torch.equal(ar.get(5), torch.full((8,), 7.0))
+    assert ar.get(6).abs().sum() == 0 and ar.views[6].shape == (5,)
+    plain = GradArena(ps)
+    assert plain.offsets == [0, 32, 40, 72, 80, 112, 120]        # registration order (the towers' block spans rely on it)
+    with pytest.raises(AssertionError):
+        plain.fused([0, 2], (12, 4))
