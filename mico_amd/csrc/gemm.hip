@@ -1500,7 +1500,12 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
         constexpr int AHEAD = CFG::STAGES - 1;   // K-tiles in flight
         for (int i = 0; i < AHEAD && i < T_; ++i) stage(kt0 + i, i * CFG::STAGE_BYTES);
         // bias gradient riding along (tile column 0 only): this lane's column of the A image, its 8 swizzled chunk offsets
-        const bool do_colsum = TA && TB && g.e.colsum_out != nullptr && tile_n == 0;
+        // (round 3: EVERY tile column takes a share - the workgroups of one tile row stage the same A panel over the same K range, so column
+        // n sums the K-tiles with index % ntn == n.  With tile column 0 alone carrying it those workgroups ran ~2x longer than the rest and
+        // the launch waited for them: +8 / 26 / 11 / 9 % on the qkv / proj / fc1 / fc2 weight gradients, tools/probes/dw_colsum_cost.py.)
+        const bool do_colsum = TA && TB && g.e.colsum_out != nullptr;
+        const int cs_ntn = g.ntn;
+        int cs_phase = do_colsum ? (tile_n + cs_ntn - kt0 % cs_ntn) % cs_ntn : 0;   // iterations until this column's next K-tile
         const int pid = pw * 64 + lane, lc = pid & 31, rg = pid >> 5;
         // row r = rg + 8 j of the image: byte r * 512 + ((lc ^ key_tr(r)) << 4); key_tr(r) = ((r & 3) | (bit 3 of r) << 2) << 1
         const unsigned cbase = (unsigned)(uintptr_t)lds + (unsigned)rg * 512u;
@@ -1526,8 +1531,12 @@ __global__ __launch_bounds__(Wide<BKW>::THREADS) void gemm_pc_kernel(const GemmA
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (TA && TB) {
                 if (do_colsum) {   // tile t is published and stays until the next iteration's barrier
-                    tile_colsum32<T>(cs, cx_even + (unsigned)bo, cx_odd + (unsigned)bo, rg);
-                    if constexpr (BK == 64) tile_colsum32<T>(cs, cx_even + (unsigned)bo + 32u * 512u, cx_odd + (unsigned)bo + 32u * 512u, rg);   // rows 32..63: same keys
+                    if (cs_phase == 0) {
+                        tile_colsum32<T>(cs, cx_even + (unsigned)bo, cx_odd + (unsigned)bo, rg);
+                        if constexpr (BK == 64) tile_colsum32<T>(cs, cx_even + (unsigned)bo + 32u * 512u, cx_odd + (unsigned)bo + 32u * 512u, rg);   // rows 32..63: same keys
+                        cs_phase = cs_ntn;
+                    }
+                    --cs_phase;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
