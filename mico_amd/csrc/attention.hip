@@ -2003,14 +2003,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_stream_kernel(const T* __
 // ======================================================================================================================
 struct SqCfg {
     static constexpr int QMAX = 80, QR = 96;        // rows 80..95: the zero half of the third 32-deep reduction step over the queries
-    static constexpr int RS = 128;                  // compact 64-wide rows; 16-byte chunk index XOR-ed by (row >> 1) & 7
+    static constexpr int RS = 128;                  // compact 64-wide rows; 16-byte chunk index XOR-ed by the key of sq_off()
     static constexpr int QT = QR * RS;
     static constexpr int KT = 32 * RS, DST = 32 * 256, WAVE = KT + DST;
     static constexpr int STAT = 2 * QR * 4;
     static constexpr int LDS = 2 * QT + STAT + 4 * WAVE;
 };
 
-__device__ __forceinline__ int sq_off(int row, int ch) { return row * SqCfg::RS + ((ch ^ ((row >> 1) & 7)) << 4); }
+// swizzle key of the compact rows: 2 ((row >> 1) & 3) + ((row >> 3) & 1).  Two rows share 256 bytes (all 64 banks); a ds_read_b128 is
+// served 16 lanes at a time - eight consecutive rows x two adjacent chunks (lane groups g, g + 1), or sixteen rows x one chunk - and either
+// set must spread over all 16 four-bank groups: rows of equal parity get keys whose upper two bits differ within 8 rows and whose low bit
+// tells rows r and r + 8 apart (measured with (row >> 1) & 7: 0.4 conflict cycles per LDS cycle, SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int sq_off(int row, int ch) { return row * SqCfg::RS + ((ch ^ ((((row >> 1) & 3) << 1) | ((row >> 3) & 1))) << 4); }
 __device__ __forceinline__ s16x8 sq_row_frag(LDS_AS const char* tile, int r0, int ks, int lane) {
     return *(LDS_AS const s16x8*)(tile + sq_off(r0 + (lane & 15), ks * 4 + (lane >> 4)));
 }
