@@ -47,6 +47,13 @@ def main():
     print(f"ln bwd (tower form) : {ms * 1e3:7.1f} us  {M * D * 16 / ms / 1e6:7.1f} GB/s (16 B/elem)")
     ms = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dx_add=gr, dx32=gr, dgamma=dg, dbeta=db, dtype=dt, frame_map=fmap, rows_per_frame=N))
     print(f"ln bwd scatter      : {ms * 1e3:7.1f} us  {M * D * 16 / ms / 1e6:7.1f} GB/s (16 B/elem)")
+    # the in-situ form of round 3: 16-bit dy, frame scatter, and the next branch's 16-bit operand written along (gradient hand-over)
+    dy16 = dy.to(dt)
+    g16n = torch.empty(M, D, device=dev, dtype=dt)
+    fsc = torch.ones(F, device=dev)
+    ms = timeit(lambda: ops.layernorm_bwd(dy16, x, g, mean, rstd, dx_add=gr, dx32=gr, dgamma=dg, dbeta=db, dtype=dt, frame_map=fmap, rows_per_frame=N,
+                                          dx16=g16n, scale16=1.0, dx16_dst=fmap, dx16_frame_scale=fsc))
+    print(f"ln bwd in situ      : {ms * 1e3:7.1f} us  {M * D * 16 / ms / 1e6:7.1f} GB/s (16 B/elem: dy 2, x 4, g 4 + 4, next operand 2)")
     ms = timeit(lambda: xc.copy_(x))
     print(f"device copy fp32    : {ms * 1e3:7.1f} us  {M * D * 8 / ms / 1e6:7.1f} GB/s (8 B/elem)")
     ms = timeit(lambda: y16.copy_(x))
