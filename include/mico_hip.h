@@ -179,14 +179,18 @@ int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
  * frame set - compact frame j goes to frame slot dx16_dst[j] of dx16 (< 0: not kept there, not written) and is multiplied by
  * scale16 * dx16_frame_scale[scattered frame] (dx16_frame_scale optional, fp32 per frame of the full stream).  Replaces the
  * mico_gather_rows_cast pass over the frames both sets share (the stochastic-depth backward: the residual-stream gradient a branch's
- * LayerNorm backward just produced is what the next branch's GEMMs read). */
+ * LayerNorm backward just produced is what the next branch's GEMMs read).
+ * dx16_drop_p > 0: dx16 is additionally multiplied by mico_dropout's keep / (1 - p) mask of (dx16_drop_seed, dx16_drop_site, element index
+ * in the [rows, cols] dx16) - the gradient side of a hidden-state dropout that sat between this LayerNorm's input and the dense layer
+ * (bert.py:295,373), without the separate mico_dropout pass. */
 int mico_layernorm_bwd_nblk(int64_t rows);
 int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        const float* dx_add, float* dx32, void* dx16, float scale16,
                        float* dgamma, float* dbeta, float grad_scale, float* ws,
                        int64_t rows, int cols, const int* frame_map, int rows_per_frame, int valid_cols,
-                       const int* dx16_dst, const float* dx16_frame_scale, int dtype, void* stream);
+                       const int* dx16_dst, const float* dx16_frame_scale,
+                       float dx16_drop_p, unsigned dx16_drop_seed, int dx16_drop_site, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (flash style: scores never materialised), forward and backward.

@@ -56,7 +56,7 @@ PROTOTYPES = {
                            c_int, c_vp, c_int, c_vp, c_f, C.c_uint, c_int, c_int, c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
     "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
-                           c_i64, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp],
+                           c_i64, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_f, C.c_uint, c_int, c_int, c_vp],
     "mico_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_rope": [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
@@ -104,7 +104,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 106   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 107   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            float* __restrict__ dx32, T* __restrict__ dx16, float scale16,
                                                            float* __restrict__ ws, int64_t rows, int cols, float dy_scale,
                                                            const int* __restrict__ frame_map, int rpf, int valid_cols,
-                                                           const int* __restrict__ dx16_dst, const float* __restrict__ dx16_fscale) {
+                                                           const int* __restrict__ dx16_dst, const float* __restrict__ dx16_fscale,
+                                                           float d16_drop_p, unsigned d16_drop_seed, int d16_drop_site) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -182,6 +183,13 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                 if (dx32) *(f32x4*)(dx32 + orow * cols + c * 4) = o;
                 if (w16) {
                     o *= s16;
+                    if (d16_drop_p > 0.f) {   // the dense branch sat behind a dropout in the forward: the same mask multiplies its gradient
+                        const unsigned thr = drop_threshold(d16_drop_p);
+                        const float ik = 1.f / (1.f - d16_drop_p);
+                        const unsigned long long i0 = (unsigned long long)drow * cols + c * 4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] *= drop_mult(d16_drop_seed, d16_drop_site, i0 + k, thr, ik);
+                    }
                     *(s16x4*)(dx16 + drow * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
                 }
             }
@@ -268,8 +276,9 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
 template <typename T, typename DT, typename XT>
 void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
                    const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
-                   int cols, float dy_scale, const int* fmap, int rpf, int valid, const int* d16dst, const float* d16scale) {
-#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf, valid, d16dst, d16scale)
+                   int cols, float dy_scale, const int* fmap, int rpf, int valid, const int* d16dst, const float* d16scale, float d16p,
+                   unsigned d16seed, int d16site) {
+#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf, valid, d16dst, d16scale, d16p, d16seed, d16site)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else if (cols <= 2048) LNB(8);
@@ -311,8 +320,10 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
                                   const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
                                   float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
                                   int cols, const int* frame_map, int rows_per_frame, int valid_cols,
-                                  const int* dx16_dst, const float* dx16_frame_scale, int dtype, void* stream) {
+                                  const int* dx16_dst, const float* dx16_frame_scale, float dx16_drop_p, unsigned dx16_drop_seed,
+                                  int dx16_drop_site, int dtype, void* stream) {
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
+    MICO_CHECK(dx16_drop_p >= 0.f && dx16_drop_p < 1.f && (dx16_drop_p == 0.f || dx16), "mico_layernorm_bwd: dx16_drop_p must be in [0, 1) and needs dx16");
     if (dx16_dst) MICO_CHECK(dx16 && rows_per_frame > 0, "mico_layernorm_bwd: dx16_dst needs dx16 and rows_per_frame > 0");
     if (valid_cols <= 0) valid_cols = cols;
     MICO_CHECK(valid_cols <= cols, "mico_layernorm_bwd: valid_cols > cols");
@@ -328,10 +339,10 @@ extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, 
     const dim3 grid(nblk);
     float* wsp = (dgamma || dbeta) ? ws : nullptr;
     DISPATCH_T16(dtype, {
-        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
-        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
-        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
-        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale);
+        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
+        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
+        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
+        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {

@@ -1213,9 +1213,8 @@ class BertFn(torch.autograd.Function):
             branch, which sat behind a dropout in training: the same mask multiplies its gradient."""
             d16 = _empty((rows, D), dt, dev)
             ops.layernorm_bwd(gin, u, P(pre + "LayerNorm.weight"), m_, r_, dx32=gin, dx16=d16, scale16=Sg,
-                              dgamma=G(pre + "LayerNorm.weight"), dbeta=G(pre + "LayerNorm.bias"), dtype=dt)
-            if ph > 0:
-                ops.dropout_(d16, (ph, dseed, site))
+                              dgamma=G(pre + "LayerNorm.weight"), dbeta=G(pre + "LayerNorm.bias"), dtype=dt,
+                              dx16_drop=(ph, dseed, site) if ph > 0 else None)
             return d16
 
         for li in reversed(range(spec.L)):

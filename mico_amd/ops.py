@@ -219,9 +219,12 @@ def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rst
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
-                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0, dx16_dst=None, dx16_frame_scale=None):
+                  grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0, dx16_dst=None, dx16_frame_scale=None,
+                  dx16_drop=None):
     """frame_map: dx_add / dx32 are the full stream, addressed through the frame scatter; dy / x / mean / rstd are compact.
-    dx16_dst / dx16_frame_scale: dx16 is laid out for the next consumer's frame set (mico_layernorm_bwd in include/mico_hip.h)."""
+    dx16_dst / dx16_frame_scale: dx16 is laid out for the next consumer's frame set (mico_layernorm_bwd in include/mico_hip.h).
+    dx16_drop: (p, seed, site) - dx16 also carries that dropout's mask (the gradient side of a hidden-state dropout)."""
+    dp, dseed, dsite = (float(dx16_drop[0]), int(dx16_drop[1]) & 0xFFFFFFFF, int(dx16_drop[2])) if dx16_drop is not None else (0.0, 0, 0)
     rows, cols = x.shape[0], x.shape[1]
     ws = None
     if dgamma is not None or dbeta is not None:
@@ -230,7 +233,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=N
     rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), dy_scale, _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
                                        _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
                                        _p(ws), rows, cols, _p(frame_map), rows_per_frame, int(valid_cols), _p(dx16_dst), _p(dx16_frame_scale),
-                                       dt_code(dtype), _st())
+                                       dp, dseed, dsite, dt_code(dtype), _st())
     check(rc, "mico_layernorm_bwd")
 
 

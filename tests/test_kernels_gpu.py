@@ -188,6 +188,15 @@ def test_layernorm(cuda, dtype, cols, xdt):
     assert rel_err(dx16, 2.0 * (0.5 * xr.grad + add)) < tol(dtype)
     assert rel_err(dg, 1 + 0.25 * gr.grad) < 2e-5
     assert rel_err(db, 1 + 0.25 * br.grad) < 2e-5
+    # dx16 with a hidden-state dropout's mask riding along (dx16_drop): the restated hash over the [rows, cols] index
+    from oracle import mico_oracle as O
+    dx16d = torch.empty(rows, cols, device=cuda, dtype=dtype)
+    dxd = torch.empty(rows, cols, device=cuda)
+    ops.layernorm_bwd(dy, x, gmm, mean, rstd, dy_scale=0.5, dx_add=add, dx32=dxd, dx16=dx16d, scale16=2.0, dtype=dtype, dx16_drop=(0.1, 77, 5))
+    keep = O.drop_mask(77, 5, (rows, cols), 0.1).to(cuda)
+    assert torch.equal(dxd, dx)                                       # the fp32 output does not see the mask
+    assert torch.equal(dx16d == 0, (keep == 0) | (dx16d == 0)) and ((dx16d == 0) | (keep != 0)).all()
+    assert rel_err(dx16d, 2.0 * (0.5 * xr.grad + add) * keep) < tol(dtype)
     # post-add table (frame + type embeddings)
     table = torch.randn(4, cols, device=cuda)
     y2 = torch.empty(rows, cols, device=cuda)
