@@ -311,7 +311,8 @@ int mico_itm_sample(const float* sim, int64_t ld, int rows, int cols, int diag_o
 /* Caption-loss token masking (TokenMasker.perform_mask, data/model/general_module.py:64-97 - there two Python loops over b x S on the host behind
  * a .cpu() copy, i.e. a stream sync per step).  tokens: int64 [rows, S].  A token at position j >= 1 with id != 0 is selected when
  * u_mask[r][row][j] < mask_prob; round r = 0 stands unless it selects nothing in the row, then round 1 is drawn, ... (the reference's
- * "while all(indicator == 0)" retry; after `rounds` empty rounds the row stays unmasked).  A selected token becomes mask_token when u_kind < 0.8, the id
+ * "while all(indicator == 0)" retry, which guarantees >= 1 masked token per row; after `rounds` empty rounds ONE position is forced instead:
+ * the floor(u_tok[row][0] * n)-th of the row's n maskable positions - u_tok of position 0 is otherwise unused; a row with n = 0 stays unmasked).  A selected token becomes mask_token when u_kind < 0.8, the id
  * range_start + floor(u_tok * (range_end - range_start)) when 0.8 <= u_kind < 0.9, and is kept otherwise; labels = the source id at selected
  * positions, -100 elsewhere.  u_mask: fp32 [rounds, rows, S]; u_kind, u_tok: fp32 [rows, S] - uniform numbers in [0, 1) supplied by the caller
  * (injected for parity, torch.rand otherwise). */

@@ -127,12 +127,36 @@ __global__ __launch_bounds__(64) void token_mask_kernel(const int64_t* __restric
             any |= __ballot(hit);
         }
     }
-    const int used = r - 1;   // the round whose draw stands (a row without a maskable token, or `rounds` exhausted, keeps nothing masked)
+    const int used = r - 1;   // the round whose draw stands
+    // `rounds` exhausted with nothing selected: the reference would keep drawing (general_module.py:71 guarantees >= 1 masked token per
+    // row), so ONE maskable position is forced - the floor(u_tok[row][0] * n)-th of the row's n maskable positions (u_tok of position 0 is
+    // otherwise unused: position 0 is never masked).  A row without any maskable token keeps nothing masked.
+    int forced = -1;
+    if (!any) {
+        int n = 0;
+        for (int j0 = 0; j0 < S; j0 += 64) {
+            const int j = j0 + lane;
+            n += __popcll(__ballot(j >= 1 && j < S && t[j] != 0));
+        }
+        if (n > 0) {
+            int k = (int)(u_tok[(int64_t)row * S] * (float)n);
+            k = k < n ? k : n - 1;
+            for (int j0 = 0; j0 < S && forced < 0; j0 += 64) {
+                const int j = j0 + lane;
+                unsigned long long m = __ballot(j >= 1 && j < S && t[j] != 0);
+                const int c = __popcll(m);
+                if (k < c) {
+                    for (int q = 0; q < k; ++q) m &= m - 1;     // drop the k lowest set bits
+                    forced = j0 + __ffsll((long long)m) - 1;
+                } else k -= c;
+            }
+        }
+    }
     for (int j0 = 0; j0 < S; j0 += 64) {
         const int j = j0 + lane;
         if (j >= S) break;
         const int64_t src = t[j];
-        const bool hit = any && j >= 1 && src != 0 && u_mask[used * round_stride + (int64_t)row * S + j] < mask_prob;
+        const bool hit = any ? (j >= 1 && src != 0 && u_mask[used * round_stride + (int64_t)row * S + j] < mask_prob) : j == forced;
         int64_t tok = src, lab = -100;
         if (hit) {
             lab = src;

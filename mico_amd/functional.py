@@ -718,10 +718,12 @@ class EvaTowerFn(torch.autograd.Function):
     @runtime.saved_precision
     def backward(ctx, dout):
         spec, params = ctx.spec, ctx.params
+        runtime.mem_trace("tower backward start")
         grads = GradArena(params)
         if ctx.chunked is None:
             _tower_backward(spec, params, ctx.saved, dout, grads)
             ctx.saved = None
+            runtime.mem_trace("tower backward end")
         else:
             groups, dp_scale, chunk, Bf = ctx.chunked
             starts = list(range(0, Bf, chunk))

@@ -91,7 +91,9 @@ class TokenMasker:
     `random.Random`: the reference's host loops, draw for draw (what the golden fixtures and the oracle use).  `uniforms=(u_mask, u_kind,
     u_tok)` injects the device path's random numbers (parity against oracle.token_masker_uniform)."""
 
-    ROUNDS = 4      # redraws of a row whose draw selected nothing (0.4^n for n maskable tokens: 1e-2 for 5 tokens per round)
+    # redraws of a row whose draw selected nothing (0.4^n per round for n maskable tokens).  When they run out the kernel forces one
+    # maskable position (mico_token_mask), so every row with a maskable token leaves with >= 1 label, as general_module.py:71 guarantees.
+    ROUNDS = 8
 
     def __init__(self, mask_token=103, range_start=106, range_end=30522, rng=None):
         self.mask_token, self.range = mask_token, (range_start, range_end)

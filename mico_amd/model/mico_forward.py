@@ -180,7 +180,9 @@ def _forward_cap(self, batch, enc, subtasks):
 def forward(self, batch, task, compute_loss=True):
     """Returns {"loss_itc", "loss_itm", "loss_cap"} for task strings like "ret%tva%tv_cap%tva" (vast.py:317-348)."""
     batch = dict(batch) if not isinstance(batch, dict) else batch
+    runtime.mem_trace("step start")
     enc = encode_batch(self, batch)
+    runtime.mem_trace("after encode_batch")
     out = {}
     for t in task.split("_"):
         subtasks = t.split("%")[1:]
@@ -189,6 +191,7 @@ def forward(self, batch, task, compute_loss=True):
         if t.startswith("ret"):
             if compute_loss:
                 out.update(_forward_ret(self, batch, enc, subtasks))
+                runtime.mem_trace("after forward_ret")
             else:   # evaluation dict of vast.py:466-483
                 ids, am = _tokens(self, batch)
                 out.update(feat_t=enc["feat_t"], input_ids=ids, attention_mask=am)
@@ -198,6 +201,7 @@ def forward(self, batch, task, compute_loss=True):
         elif t.startswith("cap"):
             if compute_loss:
                 out.update(_forward_cap(self, batch, enc, subtasks))
+                runtime.mem_trace("after forward_cap")
             else:   # evaluation dict of vast.py:513-547: beam-search captions per sub-task (captioner_mode sampling is not provided)
                 tk = self.multimodal_encoder.tokenizer
                 for st in subtasks:

@@ -314,7 +314,7 @@ def set_tower_chunk(frames):
 
 
 _activation_diet = None
-last_tower_plan = None      # (frames per pass, diet level, kept fraction, bytes per frame) of the most recent training-mode tower forward
+last_tower_plan = None      # dict(frames, frames_per_pass, diet, kept_fraction, ...) of the most recent training-mode tower forward
 
 
 def activation_diet_override():
@@ -343,3 +343,15 @@ def set_grad_slice_hook(fn):
 
 def grad_slice_hook():
     return _grad_slice_hook
+
+
+_MEM_TRACE = os.environ.get("MICO_MEM_TRACE") is not None
+
+
+def mem_trace(tag):
+    """MICO_MEM_TRACE=1: print the device memory in use at a stage boundary of the step (syncs: a debugging aid, never on in a timed run)."""
+    if _MEM_TRACE and torch.cuda.is_available():
+        import sys
+        torch.cuda.synchronize()
+        print(f"[mem] {tag:28s} allocated {torch.cuda.memory_allocated() / 2**30:7.1f} GB   peak {torch.cuda.max_memory_allocated() / 2**30:7.1f} GB   "
+              f"reserved {torch.cuda.memory_reserved() / 2**30:7.1f} GB", file=sys.stderr, flush=True)

@@ -494,6 +494,51 @@ def swin_fixture():
     print("wrote swin_tiny.pt", tuple(out.shape), float(out.abs().max()), len(fx["grads"]), "gradient digests")
 
 
+def masker_fixture():
+    """The reference's TokenMasker itself (data/model/general_module.py:52-97, constructed as data/model/vast.py does:
+    mask_token 103, random ids from [106, 30522)) run under random.seed(s) on ragged token batches: masked ids and labels draw for
+    draw.  The class ends with `.cuda()` on two index tensors; there is no GPU in the build container, so Tensor.cuda is the identity
+    for the duration of the call (no arithmetic involved).  `easydict` / `utils.logger` are import-time names of that file only."""
+    import importlib.util
+    import types
+    ref_import._install_shims()
+    if "utils" not in sys.modules or not hasattr(sys.modules.get("utils.logger", None), "LOGGER"):
+        u = sys.modules.setdefault("utils", types.ModuleType("utils"))
+        lg = types.ModuleType("utils.logger")
+        lg.LOGGER = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None)
+        sys.modules["utils.logger"] = lg
+        u.logger = lg
+    spec = importlib.util.spec_from_file_location("ref_general_module", ref_import.REF_ROOT + "/data/model/general_module.py")
+    gm = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(gm)
+    masker = gm.TokenMasker(mask_token=103, range_start=106, range_end=30522)
+    cases = []
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for seed, (b, S, p) in enumerate([(4, 12, 0.6), (8, 77, 0.6), (3, 30, 0.15), (5, 9, 0.05), (64, 77, 0.6), (2, 40, 1.0)]):
+            g = torch.Generator().manual_seed(500 + seed)
+            ids = torch.randint(1000, 30000, (b, S), generator=g)
+            lens = torch.randint(2, S + 1, (b,), generator=g)
+            lens[0] = S
+            if b > 1:
+                lens[1] = 2          # one maskable token: the retry loop of general_module.py:71 runs (many times at p = 0.05)
+            ids[:, 0] = 101
+            ids = ids * (torch.arange(S)[None] < lens[:, None])
+            ids[torch.arange(b), lens - 1] = 102
+            random.seed(9000 + seed)
+            toks, labels = masker(ids, p)
+            after = random.random()      # the generator's position afterwards: pins the NUMBER of draws as well
+            cases.append(dict(seed=9000 + seed, p=p, ids=ids, masked=toks.clone(), labels=labels.clone(), next_draw=after))
+    finally:
+        torch.Tensor.cuda = real_cuda
+    torch.save(dict(cases=cases, meta=dict(mask_token=103, range_start=106, range_end=30522,
+                                           source="data/model/general_module.py:52-97 TokenMasker under random.seed")),
+               os.path.join(OUT, "token_masker.pt"))
+    print("wrote token_masker.pt", [(c["ids"].shape, (c["labels"] != -100).sum().item()) for c in cases])
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -537,6 +582,8 @@ def main(which):
         processor_fixture()
     if want("sub"):
         subtitle_fixture()
+    if want("masker"):
+        masker_fixture()
 
 
 if __name__ == "__main__":

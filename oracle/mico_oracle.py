@@ -631,6 +631,12 @@ def token_masker_uniform(tokens, mask_prob, u_mask, u_kind, u_tok, mask_token=10
                     ind[j] = True
             if ind.any():
                 break
+        if not ind.any():
+            # rounds exhausted: the reference keeps drawing until a token is masked (general_module.py:71); the uniform-number form forces
+            # the floor(u_tok[i][0] * n)-th of the row's n maskable positions instead (include/mico_hip.h: mico_token_mask)
+            cand = [j for j in range(1, toks.shape[1]) if toks[i][j] != 0]
+            if cand:
+                ind[cand[min(int(np.float32(ut[i][0]) * np.float32(len(cand))), len(cand) - 1)]] = True
         for j in range(toks.shape[1]):
             if ind[j]:
                 src = toks[i][j]

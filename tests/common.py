@@ -1,3 +1,4 @@
+import contextlib
 import os
 
 import torch
@@ -33,3 +34,44 @@ def grad_digest_check(digest, grad, tol):
     e1 = ((f[:256] - digest["head"]).abs().max() / scale).item()
     e2 = abs(f.norm().item() - digest["norm"].item()) / max(digest["norm"].item(), 1e-20)
     return max(e1, e2)
+
+
+PRECISION_CONFIGS = ("parity", "timed")
+
+
+@contextlib.contextmanager
+def precision_config(name):
+    """The two fp16 configurations every golden test runs under:
+    "parity" - forward GEMMs as x_hi W_hi + x_lo W_hi + x_hi W_lo (runtime default, 3 k-segments);
+    "timed"  - EXACTLY what bench.py times (bench.set_precision("fp16")): plain fp16 MFMA operands everywhere, the forward GEMMs of the
+               first bench.HEAD_SPLIT_BLOCKS tower blocks with hi/lo-split weights.  BERT, the heads and the losses are plain fp16."""
+    import bench
+    from mico_amd import runtime
+    old = runtime.snapshot()
+    try:
+        if name == "parity":
+            runtime.restore((torch.float16, True, "full", False, 0, "weights"))
+        elif name == "timed":
+            dt, split, mode, _ = bench.PRECISIONS["fp16"]
+            runtime.restore((getattr(torch, dt), split, mode, False, bench.HEAD_SPLIT_BLOCKS, "weights"))
+        else:
+            raise KeyError(name)
+        yield
+    finally:
+        runtime.restore(old)
+
+
+class Errs:
+    """Collects (name, error, tolerance) so that a failing run still prints every measured error before it asserts."""
+
+    def __init__(self, tag):
+        self.tag, self.rows = tag, []
+
+    def add(self, name, err, tol):
+        self.rows.append((name, float(err), tol))
+
+    def check(self):
+        for n, e, t in self.rows:
+            print(f"[{self.tag}] {n:28s} {e:.3e}  (tol {t:g}){'   <-- OVER' if not e < t else ''}")
+        bad = [(n, e, t) for n, e, t in self.rows if not e < t]
+        assert not bad, (self.tag, bad)

@@ -145,3 +145,37 @@ def test_alignment_step_full_gradients(setup, cuda):
     for n, gr in ref_grads.items():
         if n not in nz and named[n].grad is not None:
             assert named[n].grad.abs().max().item() == 0.0, n
+
+
+@pytest.mark.parametrize("pc", ["parity", "timed"])
+def test_vit_g_depth40_full_gradients(cuda, pc):
+    """The full 40-block EVA01-g/14 tower, one image: every parameter gradient element-wise against the CPU oracle, in the parity
+    configuration and in the precision bench.py times (16-bit stored gradients compound over depth; the depth-2
+    checks above cannot see that).  The oracle's forward is re-pinned to the reference's own full-depth output inside the test."""
+    from common import precision_config, rel_err
+    torch.set_num_threads(min(32, torch.get_num_threads() or 32))
+    fx = golden("vit_g14_full.pt")
+    m, sd = build_model("evaclip01_giant", None, device=cuda)
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((1, 3, 224, 224), generator=g)
+    pre = "vision_encoder.visual."
+    sdo = {k: (v.clone().requires_grad_(True) if k.startswith(pre) and v.is_floating_point() else v) for k, v in sd.items()}
+    ref = O.eva_vit_forward(sdo, x, O.ARCHS["evaclip01_giant"])
+    assert ((ref[0, [0, 1, 128, 256]].detach() - fx["rows"]).abs().max() / fx["amax"]).item() < 1e-5      # oracle == reference at depth 40
+    w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(77)) / ref.numel() ** 0.5
+    (ref * w).sum().backward()
+    ref_grads = {k[len(pre):]: v.grad for k, v in sdo.items() if k.startswith(pre) and torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    assert len(ref_grads) > 400
+    m.zero_grad(set_to_none=True)
+    with precision_config(pc):
+        out = m.vision_encoder.visual(x.to(cuda), return_all_features=True)
+        e_fwd = rel_err(out, ref)
+        (out * w.to(cuda)).sum().backward()
+    print(f"depth-40 g/14 [{pc}] forward {e_fwd:.2e}")
+    assert e_fwd < 1e-3
+    errs = compare_all(dict(m.vision_encoder.visual.named_parameters()), ref_grads, TOL, f"vit g/14 depth 40 [{pc}]")
+    by_block = {}
+    for n, e in errs.items():
+        if n.startswith("blocks."):
+            by_block.setdefault(int(n.split(".")[1]), []).append(e)
+    print("worst per block:", " ".join(f"{b}:{max(v):.1e}" for b, v in sorted(by_block.items())))

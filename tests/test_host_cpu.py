@@ -138,6 +138,20 @@ def test_token_masker_rules():
     assert (labels[:, 0] == -100).all() and (labels[ids == 0] == -100).all() and ((labels != -100).sum(1) >= 1).all()
 
 
+def test_token_masker_host_path_equals_reference_class():
+    """The product's host TokenMasker (CPU tokens / injected random.Random) against the reference class's own output under the same seed
+    (tests/golden/token_masker.pt, oracle/make_golden.py `masker`): ids, labels and the generator position afterwards."""
+    import random
+    from common import golden
+    from mico_amd.model import TokenMasker
+    fx = golden("token_masker.pt")
+    for c in fx["cases"]:
+        rng = random.Random(c["seed"])
+        toks, labels = TokenMasker(rng=rng)(c["ids"], c["p"])
+        assert torch.equal(toks, c["masked"]) and torch.equal(labels, c["labels"]), c["seed"]
+        assert rng.random() == c["next_draw"]
+
+
 def test_modify_checkpoint_remap_and_interpolation():
     import torch.nn.functional as F
     from mico_amd.model import MiCo, default_cfg

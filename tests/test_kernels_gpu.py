@@ -686,11 +686,17 @@ def test_token_mask_bit_exact(cuda):
     um[0, 7] = 0.99                      # row 7: the first round selects nothing, the second one stands
     um[0, 9] = 0.99
     um[1, 9] = 0.99                      # row 9: third round
+    um[:, 11] = 0.99                     # rows 11, 12: every round empty -> one position is forced (the reference never returns a row
+    um[:, 12] = 0.99                     # with maskable tokens and no label, general_module.py:71)
     uk, ut = torch.rand((b, S), generator=g), torch.rand((b, S), generator=g)
+    ut[11, 0], ut[12, 0] = 0.0, 0.999
     ref_t, ref_l = O.token_masker_uniform(ids, 0.6, um, uk, ut)
     got_t, got_l = ops.token_mask(ids.to(cuda), 0.6, um.to(cuda), uk.to(cuda), ut.to(cuda), 103, 106, 30522)
     assert torch.equal(got_t.cpu(), ref_t) and torch.equal(got_l.cpu(), ref_l)
     assert (ref_l[5] == -100).all() and (ref_l[7] != -100).any() and (ref_l[9] != -100).any()
+    assert (ref_l[11] != -100).sum() == 1 and ref_l[11, 1] != -100                  # first maskable position
+    assert (ref_l[12] != -100).sum() == 1 and ref_l[12, int(lens[12]) - 1] != -100   # last maskable position
+    assert ((ref_l != -100).sum(1)[(ids[:, 1:] != 0).any(1)] >= 1).all()
     sel = ref_l != -100
     assert 0.5 < sel[:, 1:].float().sum() / (ids[:, 1:] != 0).float().sum() < 0.7
     kinds = [(ref_t[sel] == 103).float().mean().item(), ((ref_t[sel] != 103) & (ref_t[sel] != ref_l[sel])).float().mean().item()]

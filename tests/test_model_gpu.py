@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from common import golden, rel_err, build_model, grad_digest_check
+from common import golden, rel_err, build_model, grad_digest_check, precision_config, Errs, PRECISION_CONFIGS
 from mico_amd import runtime
 from mico_amd.weights import synth_inputs
 from oracle import mico_oracle as O
@@ -112,7 +112,11 @@ def test_vit_tower_large(cuda, dtype):
     print(f"l14_d2 {dtype} worst grad err {worst:.2e}")
 
 
-def test_bert(setup, cuda):
+@pytest.mark.parametrize("pc", PRECISION_CONFIGS)
+def test_bert(setup, cuda, pc):
+    """BERT (self-only, cross-attention with a 2-D mask, causal cross-attention + LM head + CE) against the reference's own outputs, in
+    the parity configuration AND in the precision bench.py times (plain fp16: common.precision_config): sequence outputs and the loss at
+    the 1e-3 gate of SURVEY section 8d, argmax ids bit-exact where the reference decides, gradients at the 2e-2 gradient gate."""
     vtype, tag, m, sd = setup
     if tag != "b16_d2":
         pytest.skip("tower independent")
@@ -126,7 +130,8 @@ def test_bert(setup, cuda):
     cond = torch.randn((b, E, 768), generator=g)
     ids, mask, cond = ids.to(cuda), mask.to(cuda), cond.to(cuda)
     me = m.multimodal_encoder
-    with runtime.precision(torch.float16):
+    er = Errs(f"bert/{pc}")
+    with precision_config(pc):
         def ids_exact(tag, logits):
             """argmax token ids bit-exact wherever the reference itself decides: its gap between the two largest
             logits of the position exceeds 2e-3 of max|logit|, twice the 1e-3 gate on the logits.  The other positions (6 + 1 + 1 of
@@ -139,32 +144,36 @@ def test_bert(setup, cuda):
             assert (got[..., None] == fx[tag + "_top2_ids"]).any(-1).all(), tag
 
         o = me(input_ids=ids, attention_mask=mask)
-        assert rel_err(o.sequence_output, fx["self_seq"]) < 1e-3
+        er.add("self_seq", rel_err(o.sequence_output, fx["self_seq"]), 1e-3)
         ids_exact("self", o.logits)
         o = me(input_ids=ids, attention_mask=mask, encoder_hidden_states=cond)
-        assert rel_err(o.sequence_output, fx["cross_seq"]) < 1e-3
+        er.add("cross_seq", rel_err(o.sequence_output, fx["cross_seq"]), 1e-3)
         ids_exact("cross", o.logits)
         m3 = torch.tril(mask.unsqueeze(1).expand(-1, S, -1)).contiguous()
         m.zero_grad(set_to_none=True)
         cr = cond.clone().requires_grad_(True)
         o = me(input_ids=ids, attention_mask=m3, encoder_hidden_states=cr, labels=fx["labels"].to(cuda))
-        assert rel_err(o.sequence_output, fx["causal_seq"]) < 1e-3
-        assert abs(o.loss.item() - fx["causal_loss"].item()) < 1e-3 * fx["causal_loss"].item()
+        er.add("causal_seq", rel_err(o.sequence_output, fx["causal_seq"]), 1e-3)
+        er.add("causal_loss", abs(o.loss.item() - fx["causal_loss"].item()) / fx["causal_loss"].item(), 1e-3)
         o.loss.backward()
-    assert rel_err(cr.grad, fx["causal_dcond"]) < GRAD_TOL[torch.float16]
+    er.add("causal_dcond", rel_err(cr.grad, fx["causal_dcond"]), GRAD_TOL[torch.float16])
     named = dict(me.named_parameters())
-    for n, d in fx["causal_grads"].items():
-        ge = grad_digest_check(d, named[n].grad, None)
-        assert ge < GRAD_TOL[torch.float16], (n, ge)
+    worst = max(grad_digest_check(d, named[n].grad, None) for n, d in fx["causal_grads"].items())
+    er.add("causal_param_grads(worst)", worst, GRAD_TOL[torch.float16])
+    er.check()
 
 
-def test_facade(setup, cuda):
+@pytest.mark.parametrize("pc", PRECISION_CONFIGS)
+def test_facade(setup, cuda, pc):
+    """The MiCo facade against the reference's own outputs, in the parity configuration and in bench.py's timed precision: every tensor
+    SURVEY section 8d names at 1e-3 (max|out - ref| / max|ref|)."""
     vtype, tag, m, sd = setup
     fx = golden(f"facade_{tag}.pt")
     cfgs = {"n1": dict(b=2, vision=1, audio=1, depth=1, S=20), "n4": dict(b=2, vision=4, audio=4, depth=1, S=20),
             "n3": dict(b=2, vision=3, audio=2, depth=1, S=20)}
     tol = 1e-3
-    with runtime.precision(torch.float16), torch.no_grad():
+    er = Errs(f"facade/{tag}/{pc}")
+    with precision_config(pc), torch.no_grad():
         for name, c in cfgs.items():
             r = fx[name]
             inp = to_dev(synth_inputs(c, seed=100), cuda)
@@ -173,39 +182,43 @@ def test_facade(setup, cuda):
             do = m.forward_depth_encoder(inp["depth_pixels"])
             # metric of SURVEY.md section 8d: max|out - ref| / max|ref| over the feature tensor (the fixture keeps 3 token
             # rows per frame; the tensor-wide max is taken from the product output)
-            assert err_vs(vo[:, :, [0, 1, 50]], r["vision_out_rows"], vo.abs().max()) < tol
-            assert err_vs(ao[:, :, [0, 1, 50]], r["audio_out_rows"], ao.abs().max()) < tol
+            er.add(f"{name} vision rows", err_vs(vo[:, :, [0, 1, 50]], r["vision_out_rows"], vo.abs().max()), tol)
+            er.add(f"{name} audio rows", err_vs(ao[:, :, [0, 1, 50]], r["audio_out_rows"], ao.abs().max()), tol)
             from mico_amd.functional import l2_normalize
             pv_, pa_, pd_ = m.pool_vision_for_contra(vo), m.pool_audio_for_contra(ao), m.pool_depth_for_contra(do)
             fv = l2_normalize(m.contra_head_v(pv_))
-            assert rel_err(fv, r["feat_v"]) < tol
-            assert rel_err(l2_normalize(m.contra_head_a(pa_)), r["feat_a"]) < tol
-            assert rel_err(l2_normalize(m.contra_head_d(pd_)), r["feat_d"]) < tol
-            assert rel_err(l2_normalize(m.contra_head_va(torch.cat((pv_, pa_), 1))), r["feat_va"]) < tol
-            assert rel_err(l2_normalize(m.contra_head_id(torch.cat((pv_, pd_), 1))), r["feat_vd"]) < tol
+            er.add(f"{name} feat_v", rel_err(fv, r["feat_v"]), tol)
+            er.add(f"{name} feat_a", rel_err(l2_normalize(m.contra_head_a(pa_)), r["feat_a"]), tol)
+            er.add(f"{name} feat_d", rel_err(l2_normalize(m.contra_head_d(pd_)), r["feat_d"]), tol)
+            er.add(f"{name} feat_va", rel_err(l2_normalize(m.contra_head_va(torch.cat((pv_, pa_), 1))), r["feat_va"]), tol)
+            er.add(f"{name} feat_vd", rel_err(l2_normalize(m.contra_head_id(torch.cat((pv_, pd_), 1))), r["feat_vd"]), tol)
             to = m.forward_multimodal_encoder(inp["input_ids"], inp["attention_mask"]).sequence_output
             ft = l2_normalize(m.contra_head_t(m.pool_text_for_contra(to)))
-            assert rel_err(ft, r["feat_t"]) < tol
+            er.add(f"{name} feat_t", rel_err(ft, r["feat_t"]), tol)
             # cosine-similarity logits live in [-1, 1]: error measured against that range (random features are near
             # orthogonal, so max|sim| itself is ~0.02 here)
-            assert (ft @ fv.t() - r["sim_t2v"].to(cuda)).abs().max().item() < 1e-3
+            er.add(f"{name} sim_t2v", (ft @ fv.t() - r["sim_t2v"].to(cuda)).abs().max().item(), tol)
             for pv, k in ((False, "full"), (True, "pv")):
                 m.config.pool_video = pv
                 cv = m.get_multimodal_forward_input_vision(vo)
                 ca = m.get_multimodal_forward_input_audio(ao)
                 cd = m.get_multimodal_forward_input_depth(do)
-                assert err_vs(cv[:, [0, 1, cv.shape[1] - 1]], r[f"cond_v_{k}_rows"], cv.abs().max()) < tol
-                assert rel_err(cv.sum((1, 2)), r[f"cond_v_{k}_sum"]) < 5e-3
-                assert err_vs(ca[:, [0, 1, ca.shape[1] - 1]], r[f"cond_a_{k}_rows"], ca.abs().max()) < tol
-                assert err_vs(cd[:, [0, 1, cd.shape[1] - 1]], r[f"cond_d_{k}_rows"], cd.abs().max()) < tol
+                er.add(f"{name} cond_v_{k} rows", err_vs(cv[:, [0, 1, cv.shape[1] - 1]], r[f"cond_v_{k}_rows"], cv.abs().max()), tol)
+                er.add(f"{name} cond_v_{k} sum", rel_err(cv.sum((1, 2)), r[f"cond_v_{k}_sum"]), tol)
+                er.add(f"{name} cond_a_{k} rows", err_vs(ca[:, [0, 1, ca.shape[1] - 1]], r[f"cond_a_{k}_rows"], ca.abs().max()), tol)
+                er.add(f"{name} cond_d_{k} rows", err_vs(cd[:, [0, 1, cd.shape[1] - 1]], r[f"cond_d_{k}_rows"], cd.abs().max()), tol)
                 out = m.forward_multimodal_encoder(inp["input_ids"], inp["attention_mask"], cv).sequence_output
                 score = F.softmax(m.itm_head(out[:, 0]), dim=1)[:, 1]
-                assert rel_err(score, r[f"itm_score_{k}"]) < 2e-3
+                er.add(f"{name} itm_score_{k}", rel_err(score, r[f"itm_score_{k}"]), tol)
             m.config.pool_video = False
+    er.check()
 
 
+@pytest.mark.parametrize("pc", PRECISION_CONFIGS)
 @pytest.mark.parametrize("W", [1, 2, 4])
-def test_alignment_loss(setup, cuda, W):
+def test_alignment_loss(setup, cuda, W, pc):
+    """ITC + ITM + CAP of vast.py against the reference's own losses and gradient digests (W = 1 and simulated 2 / 4 ranks), in the parity
+    configuration and in bench.py's timed precision: scalar losses at 1e-3 relative."""
     vtype, tag, m, sd = setup
     fx = golden(f"loss_{tag}.pt")
     r = fx[f"W{W}"]
@@ -214,7 +227,8 @@ def test_alignment_loss(setup, cuda, W):
     batch = dict(inputs[0])
     batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
     batch["_injected"]["cap"] = r["inj"]["cap"]
-    with runtime.precision(torch.float16):
+    er = Errs(f"loss/{tag}/W{W}/{pc}")
+    with precision_config(pc):
         if W >= 2:
             with torch.no_grad():
                 encs = [m.encode_batch(dict(i)) for i in inputs[1:]]
@@ -228,17 +242,16 @@ def test_alignment_loss(setup, cuda, W):
         m.zero_grad(set_to_none=True)
         out = m(batch, fx["meta"]["task"], compute_loss=True)
         for k, v in r["losses"].items():
-            e = abs(out[k].item() - v.item()) / max(abs(v.item()), 1e-6)
-            print(tag, W, k, out[k].item(), v.item(), f"{e:.2e}")
-            assert e < 2e-3, k
+            er.add(k, abs(out[k].item() - v.item()) / max(abs(v.item()), 1e-6), 1e-3)
         sum(out.values()).backward()
     named = dict(m.named_parameters())
-    worst = 0.0
+    worst = ("", 0.0)
     for n, d in r["grads"].items():
         ge = grad_digest_check(d, named[n].grad, None)
-        worst = max(worst, ge)
-        assert ge < 5e-2, (n, ge)
-    print(tag, W, f"worst grad err {worst:.2e}")
+        if ge > worst[1]:
+            worst = (n, ge)
+    er.add(f"worst grad digest ({worst[0]})", worst[1], 5e-2)
+    er.check()
 
 
 def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
@@ -289,20 +302,23 @@ def test_no_cpu_fallback():
 
 
 def test_full_depth_vit_g(cuda):
-    """Full 40-block EVA01-g/14 on one image against the reference's own output (tests/golden/vit_g14_full.pt)."""
+    """Full 40-block EVA01-g/14 on one image against the reference's own output (tests/golden/vit_g14_full.pt): the parity configuration,
+    bench.py's timed precision (both at the 1e-3 gate, token rows AND feat_v) and bf16 (reported bound)."""
     fx = golden("vit_g14_full.pt")
     m, sd = build_model("evaclip01_giant", None, device=cuda)
     g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
     x = torch.randn((1, 1, 3, 224, 224), generator=g).to(cuda)
     from mico_amd.functional import l2_normalize
-    for dtype, tol in ((torch.float16, 1e-3), (torch.bfloat16, 2e-2)):
-        with runtime.precision(dtype), torch.no_grad():
+    import contextlib
+    er = Errs("full g/14")
+    for name, ctx, tol in (("parity", precision_config("parity"), 1e-3), ("timed", precision_config("timed"), 1e-3),
+                           ("bf16", runtime.precision(torch.bfloat16), 2e-2)):
+        with ctx, torch.no_grad():
             out = m.forward_vision_encoder(x)
             feat = l2_normalize(m.contra_head_v(m.pool_vision_for_contra(out)))
-        e_rows = err_vs(out[0, 0, [0, 1, 128, 256]], fx["rows"], fx["amax"])
-        e_feat = rel_err(feat, fx["feat_v"])
-        print(f"full g/14 {dtype}: token rows {e_rows:.2e}  feat_v {e_feat:.2e}  amax {out.abs().max().item():.3f}/{fx['amax'].item():.3f}")
-        assert e_rows < tol and e_feat < 2 * tol
+        er.add(f"{name} token rows", err_vs(out[0, 0, [0, 1, 128, 256]], fx["rows"], fx["amax"]), tol)
+        er.add(f"{name} feat_v", rel_err(feat, fx["feat_v"]), tol)
+    er.check()
 
 
 def test_subtitle_branch_and_heads(cuda):
@@ -348,7 +364,7 @@ def test_subtitle_subtasks(cuda):
         out = m(batch, task)
     for k, v in ref.items():
         e = abs(out[k].item() - v.item()) / max(abs(v.item()), 1e-6)
-        assert e < 2e-3, (k, out[k].item(), v.item())
+        assert e < 1e-3, (k, out[k].item(), v.item())
     # raw subtitles are tokenised to max_subtitle_len
     raw = dict(to_dev(synth_inputs(dict(b=2, vision=1, S=10), seed=5), cuda), raw_subtitles=["a dog barks", "people talking loudly"])
     with runtime.precision(torch.float16), torch.no_grad():

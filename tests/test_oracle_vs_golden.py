@@ -214,3 +214,59 @@ def test_token_masker_matches_reference_rule():
     assert ((labels != -100).sum(1) >= 1).all()
     changed = toks != ids
     assert (labels[changed] == ids[changed]).all()
+
+
+def test_token_masker_draw_for_draw_against_reference_class():
+    """tests/golden/token_masker.pt: the reference's own TokenMasker (data/model/general_module.py:52-97) run under random.seed(s) by
+    oracle/make_golden.py (`masker`).  O.token_masker with random.Random(s) - the same Mersenne-Twister stream - must produce the same
+    masked ids and labels AND leave the generator at the same position (same number of draws in the same order: the retry loop of
+    :71, one draw per non-pad position from column 1 on, then one kind draw per selected token and random.choice for the 10 % branch)."""
+    import random
+    fx = golden("token_masker.pt")
+    assert len(fx["cases"]) >= 6
+    for c in fx["cases"]:
+        rng = random.Random(c["seed"])
+        toks, labels = O.token_masker(c["ids"], c["p"], rng, mask_token=fx["meta"]["mask_token"],
+                                      range_start=fx["meta"]["range_start"], range_end=fx["meta"]["range_end"])
+        assert torch.equal(toks, c["masked"]) and torch.equal(labels, c["labels"]), c["seed"]
+        assert rng.random() == c["next_draw"], c["seed"]
+    # the uniform-number form the device kernel implements (mico_token_mask) is the same rule with the draws supplied as tensors:
+    # feed it the reference's own draws, in the reference's order, and it must give the reference's result
+    for c in fx["cases"][:4]:
+        ids = c["ids"]
+        b, S = ids.shape
+        rng = random.Random(c["seed"])
+        # replay general_module.py:69-74: row by row, rounds until something is selected
+        per_row = []
+        for i in range(b):
+            rr = []
+            while True:
+                u = torch.ones(S)
+                hit = False
+                for j in range(1, S):
+                    if ids[i, j] != 0:
+                        u[j] = rng.random()
+                        hit = hit or u[j] < c["p"]
+                rr.append(u)
+                if hit:
+                    break
+            per_row.append(rr)
+        R = max(len(r) for r in per_row)
+        u_mask = torch.ones(R, b, S)
+        for i, rr in enumerate(per_row):
+            for r, u in enumerate(rr):
+                u_mask[r, i] = u
+        u_kind, u_tok = torch.ones(b, S), torch.zeros(b, S)
+        lo, hi = fx["meta"]["range_start"], fx["meta"]["range_end"]
+        sel = c["labels"] != -100
+        for i in range(b):
+            for j in range(S):
+                if sel[i, j]:
+                    k = rng.random()
+                    u_kind[i, j] = k
+                    if 0.8 <= k < 0.9:
+                        tok = rng.choice(list(range(lo, hi)))
+                        u_tok[i, j] = (tok - lo + 0.5) / (hi - lo)
+        toks, labels = O.token_masker_uniform(ids, c["p"], u_mask, u_kind, u_tok, mask_token=103, range_start=lo, range_end=hi)
+        assert torch.equal(labels, c["labels"]), c["seed"]
+        assert torch.equal(toks, c["masked"]), c["seed"]
