@@ -6,6 +6,7 @@ autograd only routes gradients between them and into the fp32 nn.Parameters; eve
 operands are 16-bit (runtime.compute_dtype()).
 """
 import math
+import os
 
 import torch
 
@@ -315,7 +316,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
     for i in range(depth):
         b = f"blocks.{i}."
         a = {}
-        runtime.enter_block(i, pstate)
+        runtime.enter_block(i, pstate, bool(arch["swiglu"]))
         if _TAIL_EXP is not None:
             runtime.CFG.split_fp16 = (i >= depth - _TAIL_EXP[0]) if _TAIL_EXP[0] >= 0 else (i < -_TAIL_EXP[0])
             runtime.CFG.split_mode = _TAIL_EXP[1]
@@ -467,7 +468,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
     for i in reversed(range(arch["depth_built"])):
         b = f"blocks.{i}."
         a = saved["acts"].pop()
-        runtime.enter_block(i, pstate)   # the block's weights in the layout its forward used
+        runtime.enter_block(i, pstate, bool(arch["swiglu"]))   # the block's weights in the layout its forward used
         # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
         if a["B2"] > 0:
             M2, fmap2 = a["B2"] * N, a["fmap2"]
@@ -626,6 +627,9 @@ def _slice_groups(groups, c0, c1):
     return out
 
 
+_SOFT_FRAC = float(os.environ.get("MICO_HBM_SOFT_FRAC", "0.82"))
+
+
 def tower_plan(spec, n_frames, device, kept=1.0):
     """-> (frames per tower pass, activation diet level).  Saved activations cost depth * N * (20 D + 4 hidden) bytes per kept frame (542 MB
     for ViT-g/14: two fp32 stream copies, LN outputs, qkv, attention output, the two MLP intermediates).  When the step's frames do not fit
@@ -654,19 +658,33 @@ def tower_plan(spec, n_frames, device, kept=1.0):
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)    # cached blocks are reusable
     # what the rest of the step needs next to the tower's saved activations - the backward's temporaries, BERT with its cross-attention K/V
-    # over frames x N condition tokens, the gradient arena: measured 23 GB at 320 frames (configs[2]: 162 GB peak, 139 GB of it activations)
-    # and 57 GB at 896 (one rank of configs[3]: 228 GB peak at level 2, 267 GB at level 1)
+    # over frames x N condition tokens, the gradient arena: measured 23 GiB at 320 frames (configs[2]: 162 GiB peak, 139 of it activations)
+    # and 57 GiB at 896 (one rank of configs[3]: 231 GiB peak at level 2, 266 GiB at level 1)
     headroom = (12 << 30) + n_frames * (52 << 20)
-    budget = int(0.90 * max(free - headroom, free // 4))   # (0.95 put one rank of configs[3] on level 1 at a 268 of 288 GiB peak: too close)
+    # Two budgets for the saved activations.  HARD: what fits at all - 0.90 of the free memory beyond the headroom (0.95 put one rank of
+    # configs[3] on level 1 at a 268 of 288 GiB peak).  SOFT: what keeps the step's projected peak (allocated now + headroom + activations)
+    # under MICO_HBM_SOFT_FRAC (0.82) of the device memory, i.e. ~236 of 288 GiB - the margin a data-parallel job needs for RCCL's buffers, a
+    # second reducer and allocator fragmentation (level 1 "fitted" one rank of configs[3] at 266-268 GiB; level 2 costs
+    # 0.02 of a tower forward more and peaks at 231).  The soft budget decides unless staying under it would need chunked recomputation
+    # that the hard budget avoids (> 0.05 of a tower forward dearer): memory margin is worth a LayerNorm recompute, not half a forward.
+    total = torch.cuda.get_device_properties(device).total_memory
+    hard = int(0.90 * max(free - headroom, free // 4))
+    soft = min(hard, int(_SOFT_FRAC * total) - torch.cuda.memory_allocated(device) - headroom)
     kept = min(1.0, max(0.05, kept + 0.02))      # (a little slack: the draw differs from chunk to chunk)
-    best = None
-    for lv in levels:
-        pf = per_frame[lv] * kept
-        most = max(1, int(budget // pf))
-        n_chunks = -(-n_frames // most)
-        cost = extra[lv] + (n_chunks - 1) / n_chunks
-        if best is None or cost < best[0] - 1e-9:
-            best = (cost, -(-n_frames // n_chunks), lv)      # equal chunks: the one whose activations are kept is then as large as the others
+
+    def cheapest(budget):
+        best = None
+        for lv in levels:
+            pf = per_frame[lv] * kept
+            most = max(1, int(max(budget, 0) // pf))
+            n_chunks = -(-n_frames // most)
+            cost = extra[lv] + (n_chunks - 1) / n_chunks
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, -(-n_frames // n_chunks), lv)      # equal chunks: the one whose activations are kept is then as large as the others
+        return best
+
+    bs, bh = cheapest(soft), cheapest(hard)
+    best = bs if bs[0] <= bh[0] + 0.05 else bh
     return best[1], best[2]
 
 

@@ -87,15 +87,17 @@ def using(state):
         restore(old)
 
 
-def enter_block(i, base):
+def enter_block(i, base, subln_swiglu=False):
     """Precision state of tower block i under the pass-wide state `base` (a snapshot()): with CFG.head_split_blocks = n the first n
-    blocks of a plain-fp16 tower run their forward GEMMs as x W_hi + x W_lo (the weights-split mode).  Rounding errors made in the
+    blocks of a plain-fp16 tower run their forward GEMMs as x W_hi + x W_lo (the weights-split mode; EVA02-style towers - RoPE + sub-LN
+    + SwiGLU, subln_swiglu=True - take the 3-segment mode with the fp32 gate there: measured on the reference goldens of the depth-2
+    B/16 tower, weights-split alone leaves the fused feat_vd at 1.39e-3, the 3-segment mode at 7.8e-4).  Rounding errors made in the
     first blocks pass through every later block; on the 40-block g/14 golden four such blocks take plain fp16 from 7.1e-4 / 1.0e-3
     (token rows / feat_v) to 7.4e-4 / 7.5e-4 for +2 % step time, where the same four blocks at the END of the tower change nothing
     (tools/precision_probe.py --tail).  The tower loops call this at the top of every block and restore(base) when they leave."""
     dt, split, mode, fp8, n, hmode = base
     if n and i < n and dt == torch.float16 and not split and not fp8:
-        restore((dt, True, hmode, False, n, hmode))
+        restore((dt, True, "full" if subln_swiglu else hmode, False, n, hmode))
     else:
         restore(base)
 
