@@ -308,7 +308,8 @@ KERNELS = {0: "gemm_kernel<T,{ta},{tb},TileCfg<128,128,2,2,64,2>>", 1: "gemm_ker
            2: "gemm_pc_kernel<T,{ta},{tb},32>", 3: "gemm_w4_kernel<T,{ta},{tb}>", 4: "gemm_mx8_kernel<T> (fp8 e4m3 x E8M0/32, v_mfma_scale_f32_16x16x128)",
            5: "gemm_persist_kernel<T,{ta},{tb}> (256x256 8-wave ping-pong, persistent)",
            6: "gemm_kernel<T,{ta},{tb},TileCfg<256,128,2,2,32,3>> (two workgroups per CU)",
-           7: "gemm_mid_kernel<T,{tb}> (256x128x64 unit ring, two workgroups per CU)"}
+           7: "gemm_mid_kernel<T,{tb}> (256x128x64 unit ring, two workgroups per CU)",
+           8: "gemm_p8_kernel<T,{tb}> (256x256x64, 8 phases per K-tile, half-tile DMA stream)"}
 ROLE = {(0, 0): "y = x W^T (forward)", (0, 1): "dx = dy W", (1, 1): "dW = dy^T x", (1, 0): "x^T W"}
 WORKLOAD_TEXT = {
     "img_aud_txt": "BASELINE.json configs[2]: ViT-g/14 image(1)+audio(4x224^2 mel windows)+text(77) fwd+bwd, b={b}/GPU, task {task} (ITC+ITM+CAP)",
@@ -578,7 +579,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
-                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8", 5: "big", 6: "mid", 7: "mid"}[dom[2]]
+                key = {(0, 0): "NN", (0, 1): "dX", (1, 1): "dW", (1, 0): "TN"}[dom[:2]] + "_" + {0: "small", 1: "big", 2: "pc", 3: "w4", 4: "mx8", 5: "big", 6: "mid", 7: "mid", 8: "p8"}[dom[2]]
                 if key in tj:
                     roofline["traffic"] = tj[key]["hbm_bytes_per_launch"]
                     roofline["traffic_unit"] = "bytes/launch"

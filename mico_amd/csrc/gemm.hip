@@ -156,6 +156,15 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, LDS_AS void
     }
 }
 
+// The same with a scalar byte offset in the instruction's SOFFSET operand (address = base + voff + soff; the descriptor's bounds check
+// looks at voff alone - callers keep everything that can leave the buffer, i.e. the row part, in voff): no VALU add per DMA.
+__device__ __forceinline__ void lds_dma16_soff(__amdgpu_buffer_rsrc_t rs, LDS_AS void* lds_dst, unsigned voff, unsigned soff) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs), "s"(soff) : "memory");
+}
+
 // generic (masked) staging of one operand tile HBM -> LDS.  ROWS = tile extent along the non-reduction dim.
 template <bool TR, int ROWS, int THREADS, int BK, bool ASM = false>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, LDS_AS char* lds_tile, int wave, int lane,
@@ -313,7 +322,10 @@ constexpr int ACT_LEAN = 5;
 constexpr int ACT_RESID = 6;
 // M32: the accumulators come from 32x32x16 MFMAs (operands swapped like the 16x16 kernels: lane l holds output row l & 31 and the four
 // 4-column groups 8 rg + 4 (l >> 5) of a 32x32 tile): `acc` then points at the block's [2 row-tiles][2 column-tiles][4 groups] f32x4 values.
-template <typename T, int MB = 4, int ACT = 0, bool M32 = false>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
+// SHIFT: the block's 64 columns are TWO strips of 32 - local columns 0-31 at ncol0, 32-63 at ncol0 + 32 + SHIFT (the 8-phase kernel's
+// waves own columns [32 wn, +32) and [128 + 32 wn, +32) of a 256-wide tile: SHIFT = 96); 0 = one contiguous strip.  Every 4- / 8-column
+// group a lane owns lies inside one strip.
+template <typename T, int MB = 4, int ACT = 0, bool M32 = false, int SHIFT = 0>   // MB = 16-row MFMA tiles per block (4: 64 rows, 16 KiB of LDS; 2: 32 rows, 8 KiB)
 __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32x4 (*acc)[4], LDS_AS char* wbuf, int64_t mrow0,
                                                     int64_t ncol0, int lane) {
     // ACT == ACT_LEAN: launches that use none of {aux copy, activation, dropout, positional table, patch->token remap} - the qkv / fc2 /
@@ -361,17 +373,19 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
     //   16-bit      : groups (2u, 2u+1) = columns u*32 + q*8 .. +7 (store u: 16 B per lane)
     const int q = lane & 3;
     const bool wide = g.c_dtype == MICO_F32;
-    int col[4];
+    int col[4];    // column inside the block's LDS image
+    int gcol[4];   // the same group's column relative to ncol0 in the output (== col[] unless the block is two strips)
     bool ok[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         col[v] = wide ? (v * 16 + q * 4) : ((v >> 1) * 32 + q * 8 + (v & 1) * 4);
-        ok[v] = ncol0 + col[v] < gN;    // N % 4 == 0: a 4-column group is either fully inside or fully outside
+        gcol[v] = col[v] + (col[v] >= 32 ? SHIFT : 0);
+        ok[v] = ncol0 + gcol[v] < gN;    // N % 4 == 0: a 4-column group is either fully inside or fully outside
     }
     if (!ok[0]) return;   // group 0 is the lane's leftmost
     f32x4 bias4[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && ok[v]) ? *(const f32x4*)(e.bias + ncol0 + col[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < 4; ++v) bias4[v] = (e.bias && ok[v]) ? *(const f32x4*)(e.bias + ncol0 + gcol[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (ACT == ACT_RESID) {
         // (launch contract, checked on the host: fp32 C, resid, no aux / activation / dropout / pos / remap / accumulate)
         int64_t mo_[MB];
@@ -391,7 +405,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         auto load_resid = [&](int pass, f32x4 (&r)[4]) {
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                r[v] = (live_[pass] && ok[v]) ? *(const f32x4*)(e.resid + mo_[pass] * gldc + ncol0 + col[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                r[v] = (live_[pass] && ok[v]) ? *(const f32x4*)(e.resid + mo_[pass] * gldc + ncol0 + gcol[v]) : (f32x4){0.f, 0.f, 0.f, 0.f};
         };
         load_resid(0, rcur);
 #pragma unroll
@@ -404,7 +418,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
                 for (int v = 0; v < 4; ++v) {
                     if (!ok[v]) continue;
                     const f32x4 a4 = *(LDS_AS const f32x4*)(wbuf + row * 256 + ((((col[v] >> 2)) ^ kr) << 4)) + bias4[v];
-                    *(f32x4*)((float*)gC + mo_[pass] * gldc + ncol0 + col[v]) = a4 * rs_[pass] + rcur[v];
+                    *(f32x4*)((float*)gC + mo_[pass] * gldc + ncol0 + gcol[v]) = a4 * rs_[pass] + rcur[v];
                 }
             }
 #pragma unroll
@@ -450,10 +464,10 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
                 }
                 const s16x4 lo = pack4<T>(a0[0], a0[1], a0[2], a0[3]);
                 const s16x4 hi = pack4<T>(a1[0], a1[1], a1[2], a1[3]);
-                if (!wide && ok[2 * u + 1]) *(s16x8*)(ap + col[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (!wide && ok[2 * u + 1]) *(s16x8*)(ap + gcol[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 else {
-                    if (ok[2 * u]) *(s16x4*)(ap + col[2 * u]) = lo;
-                    if (ok[2 * u + 1]) *(s16x4*)(ap + col[2 * u + 1]) = hi;
+                    if (ok[2 * u]) *(s16x4*)(ap + gcol[2 * u]) = lo;
+                    if (ok[2 * u + 1]) *(s16x4*)(ap + gcol[2 * u + 1]) = hi;
                 }
             }
         }
@@ -461,7 +475,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
             const T* hp = (const T*)e.aux_in + m * e.ldaux + ncol0;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (ok[v]) v4[v] *= unpack4<T>(*(const s16x4*)(hp + col[v]));
+                if (ok[v]) v4[v] *= unpack4<T>(*(const s16x4*)(hp + gcol[v]));
         } else if constexpr (ACT == 0) {
             if (e.act == MICO_ACT_GELU) {
 #pragma unroll
@@ -471,7 +485,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
                     if (ok[v]) {
-                        const f32x4 h = unpack4<T>(*(const s16x4*)(hp + col[v]));
+                        const f32x4 h = unpack4<T>(*(const s16x4*)(hp + gcol[v]));
                         v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
                     }
             }
@@ -483,20 +497,20 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v4[v][k] *= drop_mult(e.drop_seed, e.drop_site, i0 + col[v] + k, thr, ik);
+                for (int k = 0; k < 4; ++k) v4[v][k] *= drop_mult(e.drop_seed, e.drop_site, i0 + gcol[v] + k, thr, ik);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             v4[v] *= rscale;
             if (!ok[v]) continue;
-            if (!LEAN && e.pos) v4[v] += *(const f32x4*)(e.pos + (mo % e.pos_rows) * gN + ncol0 + col[v]);
-            if (e.resid) v4[v] += *(const f32x4*)(e.resid + mo * gldc + ncol0 + col[v]);
+            if (!LEAN && e.pos) v4[v] += *(const f32x4*)(e.pos + (mo % e.pos_rows) * gN + ncol0 + gcol[v]);
+            if (e.resid) v4[v] += *(const f32x4*)(e.resid + mo * gldc + ncol0 + gcol[v]);
         }
         if (wide) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 if (!ok[v]) continue;
-                float* cp = (float*)gC + mo * gldc + ncol0 + col[v];
+                float* cp = (float*)gC + mo * gldc + ncol0 + gcol[v];
                 if (e.accumulate) *(f32x4*)cp += v4[v];
                 else *(f32x4*)cp = v4[v];
             }
@@ -506,8 +520,8 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
             for (int u = 0; u < 2; ++u) {
                 const s16x4 lo = pack4<T>(v4[2 * u][0], v4[2 * u][1], v4[2 * u][2], v4[2 * u][3]);
                 const s16x4 hi = pack4<T>(v4[2 * u + 1][0], v4[2 * u + 1][1], v4[2 * u + 1][2], v4[2 * u + 1][3]);
-                if (ok[2 * u + 1]) *(s16x8*)(cp + col[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                else if (ok[2 * u]) *(s16x4*)(cp + col[2 * u]) = lo;
+                if (ok[2 * u + 1]) *(s16x8*)(cp + gcol[2 * u]) = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                else if (ok[2 * u]) *(s16x4*)(cp + gcol[2 * u]) = lo;
             }
         }
     }
@@ -1176,6 +1190,281 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wm * 128 + h * 64, n0 + wn * 64, lane);
+}
+
+// ======================================================================================================================
+// "P8" kernel (round 4): 256x256 output tile, 64-deep K-tiles, 8 waves, EIGHT barrier-separated intervals per K-tile.
+// What it changes against the 4-stage BK = 32 ping-pong kernel above:
+//   * 128-byte DMA rows (a 64-deep row of a k-contiguous operand is one cache line; the fill path moves 128 GB/s per CU in 128-byte
+//     segments against 77 in the 64-byte segments of 32-deep stages, tools/probes/dma_fill.hip) in 16 KiB HALF-TILES of 128 rows;
+//   * every half-tile is READ EXACTLY ONCE, one phase after the counted wait that retires it, and its LDS slot is refilled four phases
+//     later: the DMA stream, the fragment reads and the MFMAs each advance by one quarter tile per phase, so three half-tiles (6 DMA
+//     instructions per wave) are always in flight across the barriers - `s_waitcnt vmcnt(6)` in every phase, never 0;
+//   * phases of 16 MFMAs with 8 / 4 / 4 / 8 fragment reads and 2 DMA instructions per wave: the two waves of a SIMD (w, w + 4: the two
+//     row groups) run the same program half a phase apart - one multiplies while the other reads and issues - and no load section holds
+//     more than 8 ds_read_b128 + 2 LDS-DMA against the partner's 256 MFMA cycles (the 32-deep kernel: 12 + 4 against 512).
+// Tile decomposition (chosen so that every half-tile is a contiguous 128-row block of its operand):
+//   wave (wm = w / 4, wn = w % 4) owns rows   [64 wm, +64) (quadrant row block 0)  and [128 + 64 wm, +64) (block 1)
+//                                  and columns [32 wn, +32) (quadrant col block 0) and [128 + 32 wn, +32) (block 1)
+//   half-tiles of K-tile t:  A-lo = A rows 0-127 (row block 0 of both wm), A-hi = rows 128-255, B-lo / B-hi likewise in columns.
+// Phase p of tile t (cur = tile t's 64 KiB buffer, nxt = the other one); every fragment set is loaded once per tile:
+//   p0: read a0 <- A-lo(cur)   | DMA A-lo(t+1) | wait | bar | MFMA a0 x b0 | bar       (b0, a1 were read in p2, p3 of tile t-1)
+//   p1: read b1 <- B-hi(cur)   | DMA B-hi(t+1) | wait | bar | MFMA a1 x b0 | bar
+//   p2: read b0 <- B-lo(nxt)   | DMA B-lo(t+2) | wait | bar | MFMA a1 x b1 | bar
+//   p3: read a1 <- A-hi(nxt)   | DMA A-hi(t+2) | wait | bar | MFMA a0 x b1 | bar
+// Stream order of the half-tiles: h = 4 t + {0: B-lo, 1: A-hi, 2: A-lo, 3: B-hi}; h is read in phase h - 2, waited for in phase h - 3
+// (before that phase's first barrier: the reading phase is two barriers later for the group that waited, one for the staggered
+// group - the DMA of every wave has landed by then), and issued in phase h - 6 into the slot half-tile h - 8 left in phase h - 10.
+// Row group 1 executes one extra barrier before the loop (the stagger) and row group 0 one after it.
+// Forward (B k-contiguous) and dX (B reduction-major, transposing reads, two [64][128] images) orientations; K % 64 == 0; no split-K.
+// ======================================================================================================================
+#ifndef MICO_P8_PRIO
+#define MICO_P8_PRIO 0     // s_setprio(1) around the 16-MFMA bursts
+#endif
+#ifndef MICO_P8_DEFAULT
+#define MICO_P8_DEFAULT 1  // 1: default routing (variant 0) sends the eligible forward / dX problems here
+#endif
+#ifndef MICO_P8_WALK
+#define MICO_P8_WALK 1     // quadrant walk: 0 = (a0,b0) (a1,b0) (a1,b1) (a0,b1) - a0's 8 reads are the ones needed in the phase that issues them;
+#endif                     //                1 = (a0,b0) (a0,b1) (a1,b1) (a1,b0) - b0's 4 reads are
+#ifndef MICO_P8_L
+#define MICO_P8_L 4        // phases between the issue of a half-tile and the wait that retires it, + 1 (3 / 4 / 5: 2 / 3 / 4 half-tiles in flight)
+#endif
+#ifndef MICO_P8_LGKM0
+#define MICO_P8_LGKM0 0    // 1: s_waitcnt lgkmcnt(0) right after each phase's first barrier (all reads issued in the load section land first)
+#endif
+struct P8C {
+    static constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512, HALF = 16384, TILE = 65536, LDS_BYTES = 2 * TILE;
+};
+
+template <typename T, bool TB, int ACT>
+__global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs g) {
+    constexpr int BM = P8C::BM, BN = P8C::BN, BK = P8C::BK, HALF = P8C::HALF, TILE = P8C::TILE;
+    __shared__ __attribute__((aligned(16))) char smem[P8C::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PHASE_STAMP(0);
+    // workgroup -> tile: XCD-contiguous remap (bijective), then grouped row-panel order (as gemm_kernel)
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    int tile_m, tile_n;
+    {
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        tile_m = first + in % gm;
+        tile_n = in / gm;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int T_ = g.ktiles;
+
+    const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+    const char* a_base = g.A + m0 * lda_b;
+    const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
+    int64_t a_bytes = (g.M - m0) * lda_b;
+    int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+    if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+    if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+
+    f32x4 acc[8][4];   // [row tile: 0-3 row block 0, 4-7 row block 1][column tile: 0-1 column block 0, 2-3 column block 1]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane DMA source offsets of a half-tile (two instructions per wave: it = 0, 1), relative to (half, K-tile) ----
+    // k-contiguous operand: half-tile = 128 rows x 128 B; instruction `it` of wave w covers rows it * 64 + 8 w .. + 7 (8 lanes per row)
+    // reduction-major B   : half-tile = 64 k-rows x 256 B (128 columns); instruction `it` covers k-rows it * 32 + 4 w .. + 3 (16 lanes per row)
+    // The row part lives in 4 + 4 loop-invariant VGPRs (it can leave the buffer: rows / columns past the matrix edge must zero-fill),
+    // the K-tile part in the instruction's scalar offset.
+    const int rl = wave * 8 + (lane >> 3);
+    unsigned vra[2][2], vrb[2][2];   // [half][it]
+    {
+        const unsigned va = (unsigned)(rl * lda_b) + (unsigned)(((lane & 7) ^ key_kc(rl)) << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) vra[h][it] = va + (unsigned)((h * 128 + it * 64) * lda_b);
+        if constexpr (!TB) {
+            const unsigned vb = (unsigned)(rl * ldb_b) + (unsigned)(((lane & 7) ^ key_kc(rl)) << 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) vrb[h][it] = vb + (unsigned)((h * 128 + it * 64) * ldb_b);
+        } else {
+            const int kr = wave * 4 + (lane >> 4), cg = (lane & 15) ^ key_tr(kr);
+            const int64_t crem = g.N - n0;      // columns past the matrix edge: out of bounds -> zero fill (the descriptor only bounds the last row)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    vrb[h][it] = (h * 128 + cg * 8 >= crem) ? 0xFFFFFFF0u : (unsigned)((kr + it * 32) * ldb_b) + (unsigned)(cg << 4) + (unsigned)(h * 256);
+        }
+    }
+    const unsigned ld_dst = (unsigned)(wave * 1024);
+    // half-tile h of the stream (h = 4 t + w; w: 0 B-lo, 1 A-hi, 2 A-lo, 3 B-hi) -> the buffer of tile t; past the last tile: out-of-bounds
+    // DMA (zero fill into a dead slot, no memory traffic) so that the counted waits see the same number of instructions in every phase
+    auto issue = [&](int t, auto wv) {
+        constexpr int W = decltype(wv)::value;
+        // stream position W of a tile -> (operand, half):  walk 0: B-lo, A-hi, A-lo, B-hi    walk 1: A-lo, B-hi, B-lo, A-hi
+        constexpr bool isA = MICO_P8_WALK ? (W == 0 || W == 3) : (W == 1 || W == 2);
+        constexpr int half = (W == 1 || W == 3) ? 1 : 0;
+        const bool valid = t < T_;
+        const unsigned soff = isA ? (unsigned)(t * BK * 2) : (TB ? (unsigned)((int64_t)t * BK * ldb_b) : (unsigned)(t * BK * 2));   // (k-segment launches stay on the 32-deep kernel)
+        LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ld_dst;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            unsigned v = isA ? vra[half][it] : vrb[half][it];
+            if (!valid) v = 0xFFFFFFF0u;
+            if (MICO_GEMM_ABLATE == 4) v |= 0xFFFFFFF0u;
+            lds_dma16_soff(isA ? rsa : rsb, (LDS_AS void*)(dst + it * 8192), v, soff);
+        }
+    };
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using W3 = std::integral_constant<int, 3>;
+
+    // ---- fragments ----
+    const FragBase ab = frag_base<false, 256, BK>(wm * 64, lane);
+    const FragBase bb = TB ? frag_base<true, 128, BK>(wn * 32, lane) : frag_base<false, 256, BK>(wn * 32, lane);
+    s16x8 a0[4][2] = {}, a1[4][2] = {}, b0[2][2] = {}, b1[2][2] = {};   // [16-row / 16-column tile][k-step]
+    auto rdA = [&](s16x8 (&d)[4][2], int boff, int blk) {
+        if (MICO_GEMM_ABLATE == 2 && boff >= 0) {   // ablation: no LDS reads in the loop (fragments kept opaque)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(d[i][kk]));
+            return;
+        }
+        LDS_AS const char* t = lds + boff + blk * HALF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i][kk] = read_frag_b<false, 256, BK>(t, kk ? ab.b1 : ab.b0, i);
+    };
+    auto rdB = [&](s16x8 (&d)[2][2], int boff, int blk) {
+        if (MICO_GEMM_ABLATE == 2 && boff >= 0) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(d[j][kk]));
+            return;
+        }
+        LDS_AS const char* t = lds + boff + 2 * HALF + blk * HALF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) d[j][kk] = read_frag_b<TB, TB ? 128 : 256, BK>(t, kk ? bb.b1 : bb.b0, j);
+    };
+    auto mma = [&](const s16x8 (&a)[4][2], const s16x8 (&b)[2][2], auto iqv, auto jqv) {
+        constexpr int IQ = decltype(iqv)::value, JQ = decltype(jqv)::value;
+        if (MICO_GEMM_ABLATE == 3) {   // ablation: no MFMA (operands kept live)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[i][kk]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[j][kk]));
+            }
+            return;
+        }
+        if (MICO_P8_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[IQ * 4 + i][JQ * 2 + j] = T16<T>::mfma(b[j][kk], a[i][kk], acc[IQ * 4 + i][JQ * 2 + j]);
+        if (MICO_P8_PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    constexpr int L = MICO_P8_L, VMW = 2 * (L - 1);
+    auto wait_bar = [&]() {   // end of a load section: this wave's share of the half-tile read in the NEXT phase has landed; rendezvous
+        fence();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (MICO_P8_LGKM0) __builtin_amdgcn_s_waitcnt(0xC07F);
+        fence();
+    };
+    auto bar = [&]() {
+        fence();
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+
+    // ---- prologue: half-tiles 0 .. L + 1 of the stream; the two fragment sets phase 0 finds loaded ----
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto issue_h = [&](int t, auto pv) {   // the half-tile issued in phase p of tile t: h = 4 t + p + L + 2
+        constexpr int IDX = decltype(pv)::value + L + 2;
+        if (MICO_GEMM_ABLATE == 1) return;   // ablation: no DMA in the steady state (the counted waits pass at once)
+        issue(t + IDX / 4, std::integral_constant<int, IDX % 4>{});
+    };
+    issue(0, W0{}); issue(0, W1{}); issue(0, W2{}); issue(0, W3{});
+    if (L >= 3) issue(1, W0{});
+    if (L >= 4) issue(1, W1{});
+    if (L >= 5) issue(1, W2{});
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (L - 1)) : "memory");   // stream positions 0, 1, 2 of tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    fence();
+    if (MICO_P8_WALK == 0) { rdB(b0, 0, 0); rdA(a1, 0, 1); }
+    else { rdA(a0, 0, 0); rdB(b1, 0, 1); }
+    fence();
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: row group 1 runs half a phase behind row group 0
+    fence();
+    PHASE_STAMP(1);
+    // (a half-width edge tile - N = 1408 = 5.5 x 256 - runs all four quadrants: a run-time branch around the column-block-1 MFMAs leaves
+    // the b1 reads pending in hipcc's scoreboard on the skipping path and it then waits lgkmcnt(0) in front of the first DMA of EVERY
+    // iteration; an else-branch with a visible s_waitcnt, or two copies of the loop, cost 40-80 spilled registers)
+    int cur = 0;
+    for (int t = 0; t < T_; ++t) {
+        asm volatile("" : "+s"(cur));
+        const int nxt = cur ^ TILE;
+        if (MICO_P8_WALK == 0) {
+            rdA(a0, cur, 0);  issue_h(t, I0{}); wait_bar(); mma(a0, b0, I0{}, I0{}); bar();
+            rdB(b1, cur, 1);  issue_h(t, I1{}); wait_bar(); mma(a1, b0, I1{}, I0{}); bar();
+            rdB(b0, nxt, 0);  issue_h(t, std::integral_constant<int, 2>{}); wait_bar(); mma(a1, b1, I1{}, I1{}); bar();
+            rdA(a1, nxt, 1);  issue_h(t, std::integral_constant<int, 3>{}); wait_bar(); mma(a0, b1, I0{}, I1{}); bar();
+        } else {
+            rdB(b0, cur, 0);  issue_h(t, I0{}); wait_bar(); mma(a0, b0, I0{}, I0{}); bar();
+            rdA(a1, cur, 1);  issue_h(t, I1{}); wait_bar(); mma(a0, b1, I0{}, I1{}); bar();
+            rdA(a0, nxt, 0);  issue_h(t, std::integral_constant<int, 2>{}); wait_bar(); mma(a1, b1, I1{}, I1{}); bar();
+            rdB(b1, nxt, 1);  issue_h(t, std::integral_constant<int, 3>{}); wait_bar(); mma(a1, b0, I1{}, I0{}); bar();
+        }
+        cur = nxt;
+    }
+    PHASE_STAMP(2);
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued past the last tile must not land in the epilogue's staging
+    __syncthreads();
+    PHASE_STAMP(4);
+    if (MICO_GEMM_ABLATE == 6 && g.K > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        gemm_epilogue_block<T, 4, ACT, false, 96>(g, &acc[h * 4], lds + wave * 16384, m0 + h * 128 + wm * 64, n0 + wn * 32, lane);
+        if (h == 0) PHASE_STAMP(5);
+    }
+    PHASE_STAMP(3);
+#if MICO_GEMM_ABLATE == 7
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_STAMP(6);
+#endif
 }
 
 // ======================================================================================================================
@@ -2069,6 +2358,19 @@ void launch_mid(int tb, const GemmArgs& g, hipStream_t st) {
     else MICO_LAUNCH((gemm_mid_kernel<T, true, 0>), grid, block, 0, st, g);
 }
 
+template <typename T>
+void launch_p8(int tb, const GemmArgs& g, hipStream_t st) {
+    const dim3 grid(g.ntiles), block(P8C::THREADS);
+    if (resid_epilogue(g) && !tb) { MICO_LAUNCH((gemm_p8_kernel<T, false, ACT_RESID>), grid, block, 0, st, g); return; }
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_p8_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
+    if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_p8_kernel<T, true, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
+    const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
+    if (lean && !tb) MICO_LAUNCH((gemm_p8_kernel<T, false, ACT_LEAN>), grid, block, 0, st, g);
+    else if (lean) MICO_LAUNCH((gemm_p8_kernel<T, true, ACT_LEAN>), grid, block, 0, st, g);
+    else if (!tb) MICO_LAUNCH((gemm_p8_kernel<T, false, 0>), grid, block, 0, st, g);
+    else MICO_LAUNCH((gemm_p8_kernel<T, true, 0>), grid, block, 0, st, g);
+}
+
 #ifdef MICO_GEMM_W4
 #ifndef MICO_W4_P1
 #define MICO_W4_P1 16
@@ -2309,16 +2611,21 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // whose epilogue is heavy next to a short K loop gain from the second workgroup on the CU - fc1 forward with the GELU pair (two 16-bit
     // outputs: 845 -> 870 TFLOP/s) and the output projection's fp32 residual scatter at K = 1408 (727 -> 752 in the microbench); everywhere else
     // the two kernels are within +-2 % of each other and the 8-wave kernel keeps the launch.
-    const bool mid_default = g_mico_gemm_variant == 0 && M >= 8192 &&
+    const bool mid_default = (g_mico_gemm_variant == 0 || g_mico_gemm_variant == 11) && M >= 8192 &&
                              (g.e.act == MICO_ACT_GELU_SAVE_DERIV || (g.e.resid != nullptr && c_dtype == MICO_F32 && K <= 2048));
-    const bool mid64 = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
+    // the 8-phase 256x256x64 kernel: forward / dX orientation, no split, K % 64 == 0 (variant 10: every such problem, 11: those the
+    // 256x128 kernel does not take by default, 12: off)
+    const bool p8_ok = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && g.e.nseg == 0 &&
+                       256 * lda * 2 + K * 2 < 0x7FFFFF00ll && (tb ? (K + 64) * ldb * 2 : 256 * ldb * 2 + K * 2) < 0x7FFFFF00ll;
+    const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || (g_mico_gemm_variant == 11 && !mid_default) || (g_mico_gemm_variant == 0 && MICO_P8_DEFAULT));
+    const bool mid64 = big && !pc && !w4 && !p8 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
                        (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048) || mid_default);
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = (mid || mid64) ? 128 : (big ? 256 : 128);
     const int slots = big && !mid && !mid64 ? 256 : 512;
     g.ntm = (int)((M + BM - 1) / BM); g.ntn = (int)((N + BN - 1) / BN);
     g.ntiles = g.ntm * g.ntn;
     const bool deep = g_mico_gemm_variant == 3;
-    const int BKc = w4 ? (deep ? 32 : 64) : pc ? pc_bk(ta, tb) : mid64 ? Mid64::BK : mid ? Mid::BK : (big ? Big::BK : Small::BK);
+    const int BKc = w4 ? (deep ? 32 : 64) : pc ? pc_bk(ta, tb) : p8 ? P8C::BK : mid64 ? Mid64::BK : mid ? Mid::BK : (big ? Big::BK : Small::BK);
     g.ktiles = (int)((K + BKc - 1) / BKc);
     if (split_k <= 0) {
         if (!(c_dtype == MICO_F32 && g.e.accumulate)) split_k = 1;
@@ -2389,6 +2696,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else
 #endif
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
+    else if (p8) { g_mico_last_gemm_kernel = 8; DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st))); }
     else if (mid64) { g_mico_last_gemm_kernel = 7; DISPATCH_T16(dtype, (launch_mid<T>(tb, g, st))); }
     else if (mid) { g_mico_last_gemm_kernel = 6; DISPATCH_T16(dtype, (launch<T, Mid>(ta, tb, g, st))); }
     else if (big) {

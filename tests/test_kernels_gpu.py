@@ -94,11 +94,12 @@ def test_gemm_epilogues(cuda, dtype):
     assert rel_err(dW, 1 + 2.0 * dY.float().t() @ A.float()) < 1e-5 * math.sqrt(M)
 
 
-@pytest.mark.parametrize("variant", [0, 5, 8])
+@pytest.mark.parametrize("variant", [12, 5, 8, 10])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_chip_filling_kernels(cuda, dtype, variant):
     """The large-problem kernels on a problem that fills the chip (ragged M, N = 1368 not a multiple of the 128 / 256-wide tiles): the 8-wave
-    256x256 kernel (variant 0), the 256x128 two-workgroups-per-CU kernels (5: 32-deep stages, 8: 64-deep unit ring) - plain forward / dX,
+    256x256x32 kernel (variant 12), the 256x128 two-workgroups-per-CU kernels (5: 32-deep stages, 8: 64-deep unit ring), the 8-phase
+    256x256x64 kernel (10; its k-segment launch falls back to the 32-deep kernel) - plain forward / dX,
     the towers' residual-scatter epilogue (its own instantiation, ACT_RESID: frame map, per-frame scale, fp32 stream updated in place), the
     MLP's GELU pair, and a split-precision (2 k-segment) forward."""
     from mico_amd import ops, _lib
@@ -113,7 +114,7 @@ def test_gemm_chip_filling_kernels(cuda, dtype, variant):
     try:
         y = torch.empty(M, N, device=cuda, dtype=dtype)
         ops.gemm(A, W, y, bias=bias)
-        assert _lib.lib().mico_gemm_last_kernel() == {0: 1, 5: 6, 8: 7}[variant]
+        assert _lib.lib().mico_gemm_last_kernel() == {12: 1, 5: 6, 8: 7, 10: 8}[variant]
         assert rel_err(y, acc + bias) < tol(dtype)
         # dX orientation: the weight read reduction-major
         Wt = W.t().contiguous()
