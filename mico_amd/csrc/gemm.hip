@@ -121,6 +121,7 @@ struct GemmArgs {
     int ntm, ntn, ntiles, split_k, ktiles, ktiles_per_split;
     int c_dtype;
     int group_m;                // MID kernel: row-tiles per group of the tile order
+    int tm0;                    // first row tile of this launch (a problem split into a P8 launch over full rounds + a MID launch over the rest)
     int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
 };
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
         const int first = grp * g.group_m;
         const int gm = min(g.ntm - first, g.group_m);
         const int in = bid - grp * gsz;
-        tile_m = first + in % gm;
+        tile_m = first + in % gm + g.tm0;
         tile_n = in / gm;
     }
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
@@ -1224,6 +1225,9 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
 #ifndef MICO_P8_DEFAULT
 #define MICO_P8_DEFAULT 1  // 1: default routing (variant 0) sends the eligible forward / dX problems here
 #endif
+#ifndef MICO_P8_SPLIT
+#define MICO_P8_SPLIT 0    // 1: rows beyond the last full round of 256 tiles go to the 256x128 kernel (see mico_gemm); variant 14 forces it on
+#endif
 #ifndef MICO_P8_WALK
 #define MICO_P8_WALK 1     // quadrant walk: 0 = (a0,b0) (a1,b0) (a1,b1) (a0,b1) - a0's 8 reads are the ones needed in the phase that issues them;
 #endif                     //                1 = (a0,b0) (a0,b1) (a1,b1) (a1,b0) - b0's 4 reads are
@@ -1258,7 +1262,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
         const int first = grp * GROUP_M;
         const int gm = min(g.ntm - first, GROUP_M);
         const int in = bid - grp * gsz;
-        tile_m = first + in % gm;
+        tile_m = first + in % gm + g.tm0;
         tile_n = in / gm;
     }
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
@@ -2516,6 +2520,7 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
     g.A = (const char*)A; g.B = (const char*)B; g.C = (char*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.c_dtype = c_dtype;
+    g.tm0 = 0;
     if (epi) g.e = *epi;
     else { g.e = mico_gemm_epilogue{}; g.e.alpha = 1.f; }
     MICO_CHECK(g.e.nseg == 0, "mico_gemm_mx8: k-segments are a 16-bit feature");
@@ -2565,6 +2570,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.A = (const char*)A; g.B = (const char*)B; g.C = (char*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.c_dtype = c_dtype;
+    g.tm0 = 0;
     if (epi) g.e = *epi;
     else {
         g.e = mico_gemm_epilogue{};
@@ -2617,7 +2623,8 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // 256x128 kernel does not take by default, 12: off)
     const bool p8_ok = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && g.e.nseg == 0 &&
                        256 * lda * 2 + K * 2 < 0x7FFFFF00ll && (tb ? (K + 64) * ldb * 2 : 256 * ldb * 2 + K * 2) < 0x7FFFFF00ll;
-    const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || (g_mico_gemm_variant == 11 && !mid_default) || (g_mico_gemm_variant == 0 && MICO_P8_DEFAULT));
+    const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || g_mico_gemm_variant == 13 || g_mico_gemm_variant == 14 || (g_mico_gemm_variant == 11 && !mid_default) ||
+                              (g_mico_gemm_variant == 0 && MICO_P8_DEFAULT));
     const bool mid64 = big && !pc && !w4 && !p8 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
                        (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048) || mid_default);
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = (mid || mid64) ? 128 : (big ? 256 : 128);
@@ -2696,7 +2703,39 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else
 #endif
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
-    else if (p8) { g_mico_last_gemm_kernel = 8; DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st))); }
+    else if (p8) {
+        g_mico_last_gemm_kernel = 8;
+        // Round quantisation: T tiles on 256 CUs take ceil(T / 256) rounds and the towers' N = 1408 launches have only ~6 (M = kept frames x 257
+        // rows: 257 row tiles x 6 = 6.02 rounds is SEVEN).  The row tiles beyond the last full round can go to the 256x128 two-workgroups-per-CU
+        // kernel instead: the same rows as <= 512 half-size tiles in one pass (cost model below; MICO_P8_SPLIT in the build or variant 14).
+        int ntm1 = g.ntm;
+        if ((MICO_P8_SPLIT && g_mico_gemm_variant != 13) || g_mico_gemm_variant == 14) {
+            const int ntn128 = (int)((N + 127) / 128);
+            auto cost = [&](int rows_big) {
+                const long big_tiles = (long)rows_big * g.ntn, small_tiles = (long)(g.ntm - rows_big) * ntn128;
+                return (double)((big_tiles + 255) / 256) + 0.58 * (double)((small_tiles + 511) / 512);
+            };
+            double best = cost(g.ntm);
+            const int full = g.ntiles / 256;
+            for (int k = full; k >= 1 && k >= full - 1; --k) {
+                const int rows_big = (int)((long)k * 256 / g.ntn);
+                if (rows_big <= 0 || rows_big >= g.ntm) continue;
+                const double c = cost(rows_big);
+                if (c < best - 0.05) { best = c; ntm1 = rows_big; }
+            }
+        }
+        if (ntm1 < g.ntm) {
+            GemmArgs g2 = g;
+            g2.tm0 = ntm1;
+            g2.ntm = g.ntm - ntm1;
+            g2.ntn = (int)((N + 127) / 128);
+            g2.ntiles = g2.ntm * g2.ntn;
+            g.ntm = ntm1;
+            g.ntiles = g.ntm * g.ntn;
+            DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st)));
+            DISPATCH_T16(dtype, (launch_mid<T>(tb, g2, st)));
+        } else DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st)));
+    }
     else if (mid64) { g_mico_last_gemm_kernel = 7; DISPATCH_T16(dtype, (launch_mid<T>(tb, g, st))); }
     else if (mid) { g_mico_last_gemm_kernel = 6; DISPATCH_T16(dtype, (launch<T, Mid>(ta, tb, g, st))); }
     else if (big) {
