@@ -121,6 +121,7 @@ struct GemmArgs {
     int ntm, ntn, ntiles, split_k, ktiles, ktiles_per_split;
     int c_dtype;
     int group_m;                // MID kernel: row-tiles per group of the tile order
+    int fast16;                 // P8: the launch qualifies for p8_epilogue_fast16 (16-bit C, no row scale / map / residual / accumulate)
     int tm0;                    // first row tile of this launch (a problem split into a P8 launch over full rounds + a MID launch over the rest)
     int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
@@ -1219,11 +1220,110 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
 // Row group 1 executes one extra barrier before the loop (the stagger) and row group 0 one after it.
 // Forward (B k-contiguous) and dX (B reduction-major, transposing reads, two [64][128] images) orientations; K % 64 == 0; no split-K.
 // ======================================================================================================================
+// Specialised epilogue of the 8-phase kernel for its hot launches: 16-bit output (and the MLP pair's 16-bit auxiliary tensor), optional bias,
+// alpha - no row scale / frame scatter / residual / accumulate (host-checked, wave-uniform GemmArgs::fast16).  Same LDS staging image and
+// read-back ownership as gemm_epilogue_block (a lane owns 8 consecutive columns of each of the wave's two 32-column strips in one row per
+// pass), but straight-line: the bias is loaded once per tile (both 64-row blocks share the columns) and its latency hides behind the staging
+// writes, the four passes of a block are unrolled (16 ds_read_b128 in flight), addresses are 32-bit offsets from a per-block scalar base,
+// and none of the generic epilogue's per-pass bookkeeping (64-bit row arithmetic, row_map / row_scale lookups, feature branches) exists.
+// The generic epilogue takes ~3.3 us per 64-row block and wave (tools/probes/gemm_phases.py), most of it exposed latency.
+template <typename T, int ACT>
+__device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x4 (&acc)[8][4], LDS_AS char* wbuf, int64_t m0, int64_t n0, int wm, int wn,
+                                                   int lane) {
+    const int p = lane & 15, gq = lane >> 4, kp = epi_key(p);
+    const int q = lane & 3, rr = lane >> 2;
+    const float alpha = g.e.alpha;
+    const int64_t ncol0 = n0 + wn * 32;
+    // the lane's two 8-column groups (u = 0: strip 0, u = 1: strip 1) relative to ncol0, and the validity of their 4-column halves
+    const int gcol[2] = {q * 8, 128 + q * 8};
+    bool ok[2][2];
+    f32x4 bias[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ok[u][h] = ncol0 + gcol[u] + h * 4 < g.N;
+            bias[u][h] = (g.e.bias && ok[u][h]) ? *(const f32x4*)(g.e.bias + ncol0 + gcol[u] + h * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    const unsigned ldc2 = (unsigned)(g.ldc * 2), ldaux2 = (unsigned)(g.e.ldaux * 2);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int64_t mrow0 = m0 + hb * 128 + wm * 64;
+        char* const cbase = g.C + (mrow0 * g.ldc + ncol0) * 2;
+        char* const abase = (ACT == MICO_ACT_GELU_SAVE_DERIV) ? (char*)g.e.aux_out + (mrow0 * g.e.ldaux + ncol0) * 2
+                          : (ACT == MICO_ACT_MUL_AUX) ? (char*)g.e.aux_in + (mrow0 * g.e.ldaux + ncol0) * 2 : nullptr;
+        const int rows_left = (int)(g.M - mrow0 < 64 ? g.M - mrow0 : 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(LDS_AS f32x4*)(wbuf + (i * 16 + p) * 256 + (((j * 4 + gq) ^ kp) << 4)) = acc[hb * 4 + i][j] * alpha;
+        s16x8 aux[4][2];
+        if constexpr (ACT == MICO_ACT_MUL_AUX) {   // the stored derivative: requested before the staged block is read back
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = ps * 16 + rr;
+                    aux[ps][u] = (row < rows_left && ok[u][1]) ? *(const s16x8*)(abase + row * ldaux2 + gcol[u] * 2) : (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (row < rows_left && ok[u][0] && !ok[u][1]) {
+                        const s16x4 a4 = *(const s16x4*)(abase + row * ldaux2 + gcol[u] * 2);
+                        aux[ps][u] = (s16x8){a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+                    }
+                }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 16 + rr;
+            const int kr = epi_key(row);
+            f32x4 v[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    v[u][h] = *(LDS_AS const f32x4*)(wbuf + row * 256 + (((u * 8 + q * 2 + h) ^ kr) << 4)) + bias[u][h];
+            if (row >= rows_left) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!ok[u][0]) continue;
+                if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) {
+                    f32x4 d[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float e2;
+                            const float x = v[u][h][k];
+                            const float cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
+                            d[h][k] = fmaf(x * 0.39894228040143268f, e2, cdf);
+                            v[u][h][k] = x * cdf;
+                        }
+                    const s16x4 lo = pack4<T>(d[0][0], d[0][1], d[0][2], d[0][3]), hi = pack4<T>(d[1][0], d[1][1], d[1][2], d[1][3]);
+                    char* ap = abase + row * ldaux2 + gcol[u] * 2;
+                    if (ok[u][1]) *(s16x8*)ap = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    else *(s16x4*)ap = lo;
+                } else if constexpr (ACT == MICO_ACT_MUL_AUX) {
+                    const s16x8 a8 = aux[ps][u];
+                    v[u][0] *= unpack4<T>((s16x4){a8[0], a8[1], a8[2], a8[3]});
+                    v[u][1] *= unpack4<T>((s16x4){a8[4], a8[5], a8[6], a8[7]});
+                }
+                const s16x4 lo = pack4<T>(v[u][0][0], v[u][0][1], v[u][0][2], v[u][0][3]), hi = pack4<T>(v[u][1][0], v[u][1][1], v[u][1][2], v[u][1][3]);
+                char* cp = cbase + row * ldc2 + gcol[u] * 2;
+                if (ok[u][1]) *(s16x8*)cp = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                else *(s16x4*)cp = lo;
+            }
+        }
+    }
+}
+
 #ifndef MICO_P8_PRIO
 #define MICO_P8_PRIO 0     // s_setprio(1) around the 16-MFMA bursts
 #endif
 #ifndef MICO_P8_DEFAULT
 #define MICO_P8_DEFAULT 1  // 1: default routing (variant 0) sends the eligible forward / dX problems here
+#endif
+#ifndef MICO_P8_FAST16
+#define MICO_P8_FAST16 1   // specialised epilogue for plain 16-bit outputs (variant 15 = P8 with the generic epilogue, for A/B runs)
 #endif
 #ifndef MICO_P8_SPLIT
 #define MICO_P8_SPLIT 0    // 1: rows beyond the last full round of 256 tiles go to the 256x128 kernel (see mico_gemm); variant 14 forces it on
@@ -1458,6 +1558,15 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
+    }
+    if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX) {
+        // (256 rows of ldc / ldaux 16-bit elements fit 32-bit byte offsets: checked on the host - GemmArgs::fast16)
+        if (MICO_P8_FAST16 && g.fast16) {
+            p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
+            PHASE_STAMP(5);
+            PHASE_STAMP(3);
+            return;
+        }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -2521,6 +2630,7 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.c_dtype = c_dtype;
     g.tm0 = 0;
+    g.fast16 = 0;
     if (epi) g.e = *epi;
     else { g.e = mico_gemm_epilogue{}; g.e.alpha = 1.f; }
     MICO_CHECK(g.e.nseg == 0, "mico_gemm_mx8: k-segments are a 16-bit feature");
@@ -2571,6 +2681,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.c_dtype = c_dtype;
     g.tm0 = 0;
+    g.fast16 = 0;
     if (epi) g.e = *epi;
     else {
         g.e = mico_gemm_epilogue{};
@@ -2623,7 +2734,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // 256x128 kernel does not take by default, 12: off)
     const bool p8_ok = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && g.e.nseg == 0 &&
                        256 * lda * 2 + K * 2 < 0x7FFFFF00ll && (tb ? (K + 64) * ldb * 2 : 256 * ldb * 2 + K * 2) < 0x7FFFFF00ll;
-    const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || g_mico_gemm_variant == 13 || g_mico_gemm_variant == 14 || (g_mico_gemm_variant == 11 && !mid_default) ||
+    const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || g_mico_gemm_variant == 13 || g_mico_gemm_variant == 14 || g_mico_gemm_variant == 15 || (g_mico_gemm_variant == 11 && !mid_default) ||
                               (g_mico_gemm_variant == 0 && MICO_P8_DEFAULT));
     const bool mid64 = big && !pc && !w4 && !p8 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
                        (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048) || mid_default);
@@ -2705,6 +2816,9 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (p8) {
         g_mico_last_gemm_kernel = 8;
+        g.fast16 = c_dtype != MICO_F32 && !g.e.row_scale && !g.e.row_map && !g.e.resid && !g.e.accumulate && !g.e.pos && !g.e.remap_group && g.e.drop_p == 0.f &&
+                   (g.e.act == MICO_ACT_NONE ? (!g.e.aux_out && !g.e.aux_in) : true) && 256 * ldc * 2 < 0x7FFFFFFFll &&
+                   (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true) && g_mico_gemm_variant != 15;
         // Round quantisation: T tiles on 256 CUs take ceil(T / 256) rounds and the towers' N = 1408 launches have only ~6 (M = kept frames x 257
         // rows: 257 row tiles x 6 = 6.02 rounds is SEVEN).  The row tiles beyond the last full round can go to the 256x128 two-workgroups-per-CU
         // kernel instead: the same rows as <= 512 half-size tiles in one pass (cost model below; MICO_P8_SPLIT in the build or variant 14).
