@@ -1322,6 +1322,9 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
 #ifndef MICO_P8_DEFAULT
 #define MICO_P8_DEFAULT 1  // 1: default routing (variant 0) sends the eligible forward / dX problems here
 #endif
+#ifndef MICO_P8_STAGGER
+#define MICO_P8_STAGGER 0
+#endif
 #ifndef MICO_P8_FAST16
 #define MICO_P8_FAST16 1   // specialised epilogue for plain 16-bit outputs (variant 15 = P8 with the generic epilogue, for A/B runs)
 #endif
@@ -1349,6 +1352,15 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PHASE_STAMP(0);
+#if MICO_P8_STAGGER > 0
+    // experiment (negative result, tools/probes/README.md): the first round's workgroups start MICO_P8_STAGGER * 0.32 us apart in four
+    // groups per XCD so that the rounds' epilogue store bursts do not coincide - layer forward 1121 -> 1114 / 1108 / 1090 TFLOP/s at 8 / 16 / 32
+    if (blockIdx.x < 256) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long dl = (unsigned long long)(((blockIdx.x >> 3) & 3) * MICO_P8_STAGGER * 32);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < dl) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     // workgroup -> tile: XCD-contiguous remap (bijective), then grouped row-panel order (as gemm_kernel)
     int bid = blockIdx.x;
     {
