@@ -1722,6 +1722,201 @@ __global__ __launch_bounds__(Mx8::THREADS, 2) void gemm_mx8_kernel(const Mx8Args
         gemm_epilogue_block<T, 4, ACT>(g, &acc[h * 4], lds + wave * 16384, m0 + wrow + h * 64, n0 + wcol, lane);
 }
 
+// ======================================================================================================================
+// MX-fp8 GEMM on the 8-phase schedule (round 4).  A 128-deep K-tile of e4m3 bytes has exactly the LDS image of a 64-deep K-tile of
+// 16-bit elements, so the half-tile DMA stream, the slots, the waits, the quadrant walk and the fragment reads are those of gemm_p8_kernel
+// (walk 1, three half-tiles in flight); a phase issues 8 scaled MFMAs (16x16x128: 32 cycles each) where the 16-bit kernel issues 16 of 16
+// cycles - the same 256 matrix-pipe cycles per phase for twice the flops.  The E8M0 block scales (one uint32 per row and K-tile: four
+// 32-blocks) travel as 2 KiB per K-tile through a 4-slot LDS ring behind the operand buffers: every wave issues ONE 4-byte-per-lane
+// LDS-DMA per tile (waves 0-3: 64 A rows each, 4-7: B) in phase 0, two tiles ahead - that instruction is the 7th in flight at the waits
+// of phases 0-2 and has left the window of three issuing phases at phase 3's: vmcnt 7 / 7 / 7 / 6.  A lane reads its fragment row's word
+// next to the fragment and extracts the byte of its k-group (l / 16).  Replaces the 2-stage first version (one vmcnt(0) + __syncthreads
+// per K-tile, 1507 TFLOP/s in situ) for the lean / residual / MLP-pair launches.
+// ======================================================================================================================
+__device__ __forceinline__ void lds_dma4_soff(__amdgpu_buffer_rsrc_t rs, LDS_AS void* lds_dst, unsigned voff, unsigned soff) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs), "s"(soff) : "memory");
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8mx_kernel(const Mx8Args a) {
+    const GemmArgs& g = a.g;
+    constexpr int BM = P8C::BM, BN = P8C::BN, HALF = P8C::HALF, TILE = P8C::TILE, SCB = 2 * P8C::TILE;   // SCB: the scale ring (4 x 2 KiB)
+    __shared__ __attribute__((aligned(16))) char smem[P8C::LDS_BYTES + 4 * 2048];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = blockIdx.x;
+    {
+        const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    int tile_m, tile_n;
+    {
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        tile_m = first + in % gm;
+        tile_n = in / gm;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int T_ = g.ktiles;
+    // leading dimensions and k offsets in BYTES (one byte per element)
+    const char* a_base = g.A + m0 * g.lda;
+    const char* b_base = g.B + n0 * g.ldb;
+    int64_t a_bytes = (g.M - m0) * g.lda, b_bytes = (g.N - n0) * g.ldb;
+    if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+    if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+    __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+    // scale words: one descriptor per operand over the whole [K / 128][rows] array (rows past M / N of the last tile row read the next
+    // K-tile's words or zero-fill - they scale operand rows that are zero-filled themselves)
+    __amdgpu_buffer_rsrc_t rss = wave < 4
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)a.sa, 0, (int)min((int64_t)T_ * g.M * 4, (int64_t)0x7FFFFF00), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)a.sb, 0, (int)min((int64_t)T_ * g.N * 4, (int64_t)0x7FFFFF00), 0x00020000);
+    const unsigned vsc = (unsigned)(((wave < 4 ? m0 : n0) + (wave & 3) * 64 + lane) * 4);
+    const unsigned sc_stride = (unsigned)((wave < 4 ? g.M : g.N) * 4);
+    const unsigned sc_dst = (unsigned)(SCB + (wave < 4 ? 0 : 1024) + (wave & 3) * 256);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int rl = wave * 8 + (lane >> 3);
+    unsigned vra[2][2], vrb[2][2];   // [half][it]
+    {
+        const unsigned sw = (unsigned)(((lane & 7) ^ key_kc(rl)) << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                vra[h][it] = (unsigned)((rl + h * 128 + it * 64) * g.lda) + sw;
+                vrb[h][it] = (unsigned)((rl + h * 128 + it * 64) * g.ldb) + sw;
+            }
+    }
+    const unsigned ld_dst = (unsigned)(wave * 1024);
+    auto issue = [&](int t, auto wv) {   // stream position W of tile t: 0 A-lo, 1 B-hi, 2 B-lo, 3 A-hi
+        constexpr int W = decltype(wv)::value;
+        constexpr bool isA = (W == 0 || W == 3);
+        constexpr int half = (W == 1 || W == 3) ? 1 : 0;
+        const bool valid = t < T_;
+        const unsigned soff = (unsigned)(t * 128);
+        LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ld_dst;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            unsigned v = isA ? vra[half][it] : vrb[half][it];
+            if (!valid) v = 0xFFFFFFF0u;
+            lds_dma16_soff(isA ? rsa : rsb, (LDS_AS void*)(dst + it * 8192), v, soff);
+        }
+    };
+    auto issue_scales = [&](int t) {
+        lds_dma4_soff(rss, (LDS_AS void*)(lds + sc_dst + (t & 3) * 2048), t < T_ ? vsc : 0xFFFFFFF0u, t < T_ ? (unsigned)t * sc_stride : 0u);
+    };
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using W3 = std::integral_constant<int, 3>;
+
+    const FragBase ab = frag_base<false, 256, 64>(wm * 64, lane);
+    const FragBase bb = frag_base<false, 256, 64>(wn * 32, lane);
+    const int p = lane & 15, sh = (lane >> 4) * 8;
+    i32x8 a0[4], a1[4], b0[2], b1[2];
+    int sa0 = 0, sa1 = 0, sb0 = 0, sb1 = 0;   // the scale bytes of a fragment set packed into one register: byte i = tile i (the MFMA's op_sel picks it)
+    auto frag = [&](LDS_AS const char* t, const FragBase& fbs, int i) {
+        const u32x4 l4 = __builtin_bit_cast(u32x4, *(LDS_AS const s16x8*)(t + fbs.b0 + i * 2048));
+        const u32x4 h4 = __builtin_bit_cast(u32x4, *(LDS_AS const s16x8*)(t + fbs.b1 + i * 2048));
+        return (i32x8){(int)l4[0], (int)l4[1], (int)l4[2], (int)l4[3], (int)h4[0], (int)h4[1], (int)h4[2], (int)h4[3]};
+    };
+    auto rdA = [&](i32x8 (&d)[4], int& s, int boff, int blk, int sslot) {
+        LDS_AS const char* t = lds + boff + blk * HALF;
+        LDS_AS const unsigned* sc = (LDS_AS const unsigned*)(lds + SCB + sslot) + blk * 128 + wm * 64 + p;
+        unsigned pk = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = frag(t, ab, i);
+            pk |= ((sc[i * 16] >> sh) & 0xFFu) << (8 * i);
+        }
+        s = (int)pk;
+    };
+    auto rdB = [&](i32x8 (&d)[2], int& s, int boff, int blk, int sslot) {
+        LDS_AS const char* t = lds + boff + 2 * HALF + blk * HALF;
+        LDS_AS const unsigned* sc = (LDS_AS const unsigned*)(lds + SCB + sslot + 1024) + blk * 128 + wn * 32 + p;
+        unsigned pk = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            d[j] = frag(t, bb, j);
+            pk |= ((sc[j * 16] >> sh) & 0xFFu) << (8 * j);
+        }
+        s = (int)pk;
+    };
+    auto mma = [&](const i32x8 (&fa)[4], int sa, const i32x8 (&fb)[2], int sb, auto iqv, auto jqv) {
+        constexpr int IQ = decltype(iqv)::value, JQ = decltype(jqv)::value;
+        // operands swapped (D^T = B A^T) like the 16-bit kernels: a lane owns 4 consecutive columns; op_sel = the scale byte of the tile
+#define P8MX_MMA(I, J) acc[IQ * 4 + I][JQ * 2 + J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[J], fa[I], acc[IQ * 4 + I][JQ * 2 + J], 0, 0, J, sb, I, sa)
+        P8MX_MMA(0, 0); P8MX_MMA(0, 1); P8MX_MMA(1, 0); P8MX_MMA(1, 1); P8MX_MMA(2, 0); P8MX_MMA(2, 1); P8MX_MMA(3, 0); P8MX_MMA(3, 1);
+#undef P8MX_MMA
+    };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    auto wait_bar = [&](auto nv) {
+        fence();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(nv)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+    auto bar = [&]() {
+        fence();
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+    using N6 = std::integral_constant<int, 6>;
+    using N7 = std::integral_constant<int, 7>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // prologue: the scale words of tiles 0 and 1, half-tiles 0..5 of the stream; a0, b1 of tile 0
+    issue_scales(0); issue_scales(1);
+    issue(0, W0{}); issue(0, W1{}); issue(0, W2{}); issue(0, W3{}); issue(1, W0{}); issue(1, W1{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fence();
+    rdA(a0, sa0, 0, 0, 0);
+    rdB(b1, sb1, 0, 1, 0);
+    fence();
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger (see gemm_p8_kernel)
+    fence();
+    int cur = 0;
+    for (int t = 0; t < T_; ++t) {
+        asm volatile("" : "+s"(cur));
+        const int nxt = cur ^ TILE;
+        const int sc_cur = (t & 3) * 2048, sc_nxt = ((t + 1) & 3) * 2048;
+        // p0: half-tile h = 4 t + 6 (B-lo of t + 1) and the scales of tile t + 2
+        rdB(b0, sb0, cur, 0, sc_cur);  issue(t + 1, W2{}); issue_scales(t + 2); wait_bar(N7{}); mma(a0, sa0, b0, sb0, I0{}, I0{}); bar();
+        rdA(a1, sa1, cur, 1, sc_cur);  issue(t + 1, W3{}); wait_bar(N7{}); mma(a0, sa0, b1, sb1, I0{}, I1{}); bar();
+        rdA(a0, sa0, nxt, 0, sc_nxt);  issue(t + 2, W0{}); wait_bar(N7{}); mma(a1, sa1, b1, sb1, I1{}, I1{}); bar();
+        rdB(b1, sb1, nxt, 1, sc_nxt);  issue(t + 2, W1{}); wait_bar(N6{}); mma(a1, sa1, b0, sb0, I1{}, I0{}); bar();
+        cur = nxt;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (zero-fill DMAs past the last tile: see gemm_p8_kernel)
+    __syncthreads();
+    if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX) {
+        if (MICO_P8_FAST16 && g.fast16) {
+            p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
+            return;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        gemm_epilogue_block<T, 4, ACT, false, 96>(g, &acc[h * 4], lds + wave * 16384, m0 + h * 128 + wm * 64, n0 + wn * 32, lane);
+}
+
 // 16-bit [rows, cols] -> e4m3 [rows, cols] + E8M0 block scales (one per 32 consecutive columns, packed 4 per uint32, K-tile-major).
 // scale = 2^e with the smallest e such that amax / 2^e <= 448 (the largest e4m3 magnitude): nothing saturates, at most one binade of the
 // element format's range is given up.  A wave covers 512 columns of one row per pass (8 per lane: one 16-byte load), a 32-block is 4 lanes.
@@ -2661,11 +2856,18 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
     const dim3 grid(g.ntiles), block(Mx8::THREADS);
     hipStream_t st = (hipStream_t)stream;
     const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
-#define MX8(ACTV) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_mx8_kernel<T, ACTV>), grid, block, 0, st, a))
+    // the 8-phase form (gemm_p8mx_kernel) for the launches its epilogues cover; variant 16 = the 2-stage first version everywhere (A/B runs)
+    const bool p8mx = g_mico_gemm_variant != 16 && g.lda * 256 + K < 0x7FFFFF00ll && g.ldb * 256 + K < 0x7FFFFF00ll &&
+                      (lean || g.e.act == MICO_ACT_GELU_SAVE_DERIV || g.e.act == MICO_ACT_MUL_AUX);
+    g.tm0 = 0;
+    g.fast16 = p8mx && c_dtype != MICO_F32 && !g.e.row_scale && !g.e.row_map && !g.e.resid && !g.e.accumulate && 256 * ldc * 2 < 0x7FFFFFFFll &&
+               (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true);
+#define MX8(ACTV) do { if (p8mx) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_p8mx_kernel<T, ACTV>), grid, block, 0, st, a)); \
+                       else DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_mx8_kernel<T, ACTV>), grid, block, 0, st, a)); } while (0)
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MX8(MICO_ACT_GELU_SAVE_DERIV);
     else if (g.e.act == MICO_ACT_MUL_AUX) MX8(MICO_ACT_MUL_AUX);
     else if (lean) MX8(ACT_LEAN);
-    else MX8(0);
+    else DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_mx8_kernel<T, 0>), grid, block, 0, st, a));
 #undef MX8
     MICO_LAUNCH_CHECK();
     return MICO_OK;
