@@ -21,8 +21,12 @@ def variant(name):
         kind = "pc"
     elif "gemm_persist_kernel" in name:
         kind = "big"
-    elif "gemm_mx8_kernel" in name:
+    elif "gemm_mx8_kernel" in name or "gemm_p8mx_kernel" in name:
         return "NN_mx8"
+    elif "gemm_p8_kernel" in name:   # gemm_p8_kernel<T, TB, ACT>: forward (TB = false) or dX orientation
+        m = re.search(r"gemm_p8_kernelI\w+?Lb([01])E|gemm_p8_kernel<[^,]+,\s*(true|false)", name)
+        tb = bool(m) and (m.group(1) == "1" or m.group(2) == "true")
+        return ("dX" if tb else "NN") + "_p8"
     elif "gemm_mid_kernel" in name:   # gemm_mid_kernel<T, TB, ACT>: forward (TB = false) or dX orientation
         m = re.search(r"gemm_mid_kernelI\w+?Lb([01])E|gemm_mid_kernel<[^,]+,\s*(true|false)", name)
         tb = bool(m) and (m.group(1) == "1" or m.group(2) == "true")
