@@ -2235,6 +2235,374 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __rest
     }
 }
 
+// ======================================================================================================================
+// backward for the towers' unmasked self-attention in ONE pass (round 4): dQ, dK and dV of a (b, h) item from scores
+// that are computed once, every operand fetched from HBM once.  The two resident kernels above each stage half of the operands for the whole
+// item, recompute S and dP (7 matmuls for 5, every exponential twice), read Q / K / V / dO twice and serialise fetch -> barrier -> arithmetic ->
+// store per item on a CU whose LDS admits one workgroup.  Here a persistent 8-wave workgroup STREAMS the queries:
+//   * wave w owns keys 32 w .. 32 w + 31 (two 16-key blocks): their V rows sit in registers, dK^T / dV^T accumulate in registers over the
+//     whole item (no cross-wave reduction); K of the item is an LDS image (row fragments for S, transposed fragments for dQ);
+//   * Q and dO arrive in chunks of 32 queries through a three-stage LDS ring: every thread carries one 16-byte piece of Q, dO and O per chunk
+//     through registers (requested three chunks ahead of its use, committed one barrier later), and the sixteen threads of a row reduce
+//     delta = rowsum(dO * O) on the way - the flat chunk sequence runs across item boundaries, so the next item's first chunks are in LDS
+//     before the current item ends;
+//   * phase 1 of a chunk (all waves): S = Q K^T, dP = dO V^T for the wave's keys, P and dS (lse saved by the forward), dV^T += dO^T P,
+//     dK^T += Q^T dS (transposing reads of the ring tiles), dS -> a 16-bit LDS image [key][query] (double buffered);
+//   * ONE barrier;
+//   * phase 2 (the barrier's other side): six waves own one 16-wide head-dim tile each and reduce dQ^T[d][query] = K^T[d][key] dS^T[key][query]
+//     over ALL keys with transposing reads of the K image and the dS image, and store the chunk's dQ rows; meanwhile the other two waves
+//     run key 256 (the 257th token, a 17th key block with one real row) for the NEXT chunk - its dS rows join the next image, its dK / dV
+//     row accumulates in LDS - and every thread commits chunk G + 2 to the ring and requests chunk G + 3.
+// Zero rows make masks unnecessary except in ragged key blocks: Q / dO rows beyond Sq and K / V rows beyond Sk are zero in LDS, so whatever
+// P and dS hold there multiplies zeros (they stay finite: lse of a dead query is 0), and dead rows are never stored.
+// LDS: K image 272 x 256 B, V rows 256.. (16 x 256 B), ring 3 x 16 KiB, dS 2 x 17 KiB, statistics, key-256 rows = 156.3 KiB.
+// ======================================================================================================================
+template <int HDP> struct OpCfg {
+    using C = Cfg<HDP>;
+    static constexpr int NST = 3;                         // ring stages
+    static constexpr int QT = 32 * C::RS;                 // one [32][HDP] tile image
+    static constexpr int STAGE = 2 * QT;                  // Q chunk | dO chunk
+    static constexpr int KROWS = 272;
+    static constexpr int KT = KROWS * C::RS;
+    static constexpr int V16 = 16 * C::RS;
+    static constexpr int DSK = 32 * 64;                   // dS image of one 32-key step: [32 keys][32 queries] 16-bit, 64-byte rows
+    static constexpr int DSB = 8 * DSK + DSK / 2;         // steps 0..7 and the 16 rows (keys 256..271) of step 8
+    static constexpr int STAT = NST * 64 * 4;             // [stage][lse * log2 e | delta * scale][32]
+    static constexpr int X16 = 2 * 2 * HDP * 4;           // [helper wave][dK | dV][HDP]: the key-256 row, summed over the chunks
+    static constexpr int LDS = KT + V16 + NST * STAGE + 2 * DSB + STAT + X16;
+};
+// byte offset of (key row kl of the step, query tile qt) in a dS step image: the two 32-byte halves of a 64-byte row swap with bit 2 of the
+// row, so that the 8-byte writes of a score tile (16 rows x 32 bytes) and the transposing reads (4 rows x 32 bytes per lane group) both
+// spread over all banks
+__device__ __forceinline__ int ds_off(int kl, int qt) { return kl * 64 + ((qt ^ ((kl >> 2) & 1)) << 5); }
+
+template <typename T, int HDP>
+__global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                                  const T* __restrict__ o, const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                                  T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, const mico_attn_params p) {
+    using C = Cfg<HDP>;
+    using O = OpCfg<HDP>;
+    constexpr int CPR = HDP / 8;
+    __shared__ __attribute__((aligned(16))) char smem[O::LDS];
+    LDS_AS char* kimg = (LDS_AS char*)smem;
+    LDS_AS char* v16 = kimg + O::KT;
+    LDS_AS char* ring = v16 + O::V16;
+    LDS_AS char* dsb = ring + O::NST * O::STAGE;
+    LDS_AS float* stat = (LDS_AS float*)(dsb + 2 * O::DSB);
+    LDS_AS float* x16 = stat + O::NST * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc2 = p.scale * LOG2E;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nitems = p.B * p.H;
+    const int NC = (p.Sq + 31) >> 5;             // 32-query chunks per item
+    const int nks = (p.Sk + 31) >> 5;            // 32-key steps of the dQ reduction
+    const bool has16 = p.Sk > 256;
+    // roles in phase 2: waves 0-2 / 4-6 own head-dim tiles 0-2 / 3-5 of dQ^T, waves 3 and 7 run key block 16 for query tile 0 / 1 of the next chunk
+    const int dq_td = (wave & 3) < 3 ? (wave & 3) + 3 * (wave >> 2) : -1;
+    const int hw = (wave & 3) == 3 ? (wave >> 2) : -1;
+
+    // XCD-contiguous runs of items (see attn_fwd_res_kernel)
+    const int nwg = gridDim.x;
+    int item0 = (int)blockIdx.x, item_step = nwg, n_my = (nitems - (int)blockIdx.x + nwg - 1) / nwg;
+    if ((nwg & 7) == 0 && nitems % nwg == 0) {
+        n_my = nitems / nwg;
+        item0 = ((int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3)) * n_my;
+        item_step = 1;
+    }
+    const int total = n_my * NC;                 // this workgroup's flat chunk sequence
+
+    for (int c = tid; c < 2 * O::DSB / 16; c += 512) *(LDS_AS s16x8*)(dsb + c * 16) = zero8;   // rows of key blocks nobody owns stay zero
+
+    // ---- the loader: thread = (chunk row tid >> 4, 16-byte piece tid & 15) ----
+    struct Piece { s16x8 q, d, o; float l; };
+    const int lrow = tid >> 4, lch = tid & 15;
+    const bool lch_ok = lch * 8 < p.hd;
+    const int loff = lrow * C::RS + ((lch ^ ((lrow & 7) << 1)) << 4);
+    const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2), obytes = (int)(((int64_t)(p.Sq - 1) * p.o_rs + p.hd) * 2);
+    int pf_ii = 0, pf_c = 0;                     // the next chunk to request
+    auto issue = [&](Piece& pc) {
+        const bool live = pf_ii < n_my;
+        const int item = item0 + (live ? pf_ii : n_my - 1) * item_step;
+        const int b = item / p.H, h = item - b * p.H;
+        const int row = pf_c * 32 + lrow;
+        const bool rl = live && row < p.Sq;
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)b * p.q_bs + h * p.hd), 0, qbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(d_o + (int64_t)b * p.o_bs + h * p.hd), 0, obytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(o + (int64_t)b * p.o_bs + h * p.hd), 0, obytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rl_ = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((int64_t)b * p.H + h) * p.Sq), 0, p.Sq * 4, 0x00020000);
+        const unsigned qo = (rl && lch_ok) ? (unsigned)(row * p.q_rs * 2 + lch * 16) : 0xFFFFFFF0u;
+        const unsigned oo = (rl && lch_ok) ? (unsigned)(row * p.o_rs * 2 + lch * 16) : 0xFFFFFFF0u;
+        pc.q = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qo, 0, 0));
+        pc.d = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rd, oo, 0, 0));
+        pc.o = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, oo, 0, 0));
+        pc.l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl_, (rl && lch == 15) ? (unsigned)(row * 4) : 0xFFFFFFF0u, 0, 0));
+        if (++pf_c == NC) { pf_c = 0; ++pf_ii; }
+    };
+    auto commit = [&](const Piece& pc, int stage) {
+        LDS_AS char* st = ring + stage * O::STAGE;
+        if (lch < CPR) {
+            *(LDS_AS s16x8*)(st + loff) = pc.q;
+            *(LDS_AS s16x8*)(st + O::QT + loff) = pc.d;
+        }
+        float a[8], c8[8], dl = 0.f;
+        unpack8<T>(pc.o, a);
+        unpack8<T>(pc.d, c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += a[e] * c8[e];
+        dl = row16_sum(dl);
+        LDS_AS float* ss = stat + stage * 64;
+        if (lch == 0) ss[32 + lrow] = dl * p.scale;
+        if (lch == 15) ss[lrow] = pc.l * LOG2E;
+    };
+
+    // ---- per-item state ----
+    s16x8 vf[2][C::KS];                          // V rows of this wave's keys (B operand of dP)
+    f32x4 dkacc[2][C::TD], dvacc[2][C::TD];
+    int b = 0, h = 0;
+
+    // score tile of (16 queries at ring rows qt*16.., 16 keys) -> P, dS
+    auto probs = [&](f32x4& s, f32x4& dp, const f32x4& lv, const f32x4& dl4, const bool keep) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[r]));
+            float ds = pv * fmaf(dp[r], p.scale, -dl4[r]);
+            if (!keep) { pv = 0.f; ds = 0.f; }
+            s[r] = pv;
+            dp[r] = ds;
+        }
+    };
+
+    auto phase1 = [&](int stage, int dsbuf) {
+        LDS_AS const char* qs = ring + stage * O::STAGE;
+        LDS_AS const char* dos = qs + O::QT;
+        LDS_AS const float* ss = stat + stage * 64;
+        LDS_AS char* dsi = dsb + dsbuf * O::DSB + wave * O::DSK;
+        s16x4 plo[2], dlo[2];
+        s16x8 pf[2], df[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // one operand family at a time (S, then dP): a query fragment is read once and serves both key blocks, and only one is live
+            f32x4 s[2] = {zero4, zero4}, dp[2] = {zero4, zero4};
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const s16x8 qf = lds_row_frag<HDP>(qs, qt * 16, ks, lane);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    if (wave * 32 + rb * 16 < p.Sk) s[rb] = T16<T>::mfma(qf, lds_row_frag<HDP>(kimg, wave * 32 + rb * 16, ks, lane), s[rb]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const s16x8 dof = lds_row_frag<HDP>(dos, qt * 16, ks, lane);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    if (wave * 32 + rb * 16 < p.Sk) dp[rb] = T16<T>::mfma(dof, vf[rb][ks], dp[rb]);
+            }
+            const f32x4 lv = *(LDS_AS const f32x4*)(ss + qt * 16 + g * 4);
+            const f32x4 dl4 = *(LDS_AS const f32x4*)(ss + 32 + qt * 16 + g * 4);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int kb0 = wave * 32 + rb * 16;
+                probs(s[rb], dp[rb], lv, dl4, kb0 + 16 <= p.Sk || kb0 + l15 < p.Sk);
+                const s16x4 p4 = pack4<T>(s[rb][0], s[rb][1], s[rb][2], s[rb][3]), d4 = pack4<T>(dp[rb][0], dp[rb][1], dp[rb][2], dp[rb][3]);
+                if (kb0 < p.Sk) *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt) + g * 8) = d4;
+                if (qt == 0) { plo[rb] = p4; dlo[rb] = d4; }
+                else {
+                    pf[rb] = (s16x8){plo[rb][0], plo[rb][1], plo[rb][2], plo[rb][3], p4[0], p4[1], p4[2], p4[3]};
+                    df[rb] = (s16x8){dlo[rb][0], dlo[rb][1], dlo[rb][2], dlo[rb][3], d4[0], d4[1], d4[2], d4[3]};
+                }
+            }
+        }
+#pragma unroll
+        for (int td = 0; td < C::TD; ++td) {
+            const s16x8 ado = lds_tr_frag<HDP>(dos, td, 0, lane), aq = lds_tr_frag<HDP>(qs, td, 0, lane);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                if (wave * 32 + rb * 16 >= p.Sk) continue;
+                dvacc[rb][td] = T16<T>::mfma(ado, pf[rb], dvacc[rb][td]);
+                dkacc[rb][td] = T16<T>::mfma(aq, df[rb], dkacc[rb][td]);
+            }
+        }
+    };
+
+    // key block 16 (keys 256..271; row 0 real) against query tile qt of the chunk in `stage`
+    auto helper16 = [&](int stage, int dsbuf, int qt) {
+        LDS_AS const char* qs = ring + stage * O::STAGE;
+        LDS_AS const char* dos = qs + O::QT;
+        LDS_AS const float* ss = stat + stage * 64;
+        f32x4 s = zero4, dp = zero4;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            s = T16<T>::mfma(lds_row_frag<HDP>(qs, qt * 16, ks, lane), lds_row_frag<HDP>(kimg, 256, ks, lane), s);
+            dp = T16<T>::mfma(lds_row_frag<HDP>(dos, qt * 16, ks, lane), lds_row_frag<HDP>(v16, 0, ks, lane), dp);
+        }
+        const f32x4 lv = *(LDS_AS const f32x4*)(ss + qt * 16 + g * 4);
+        const f32x4 dl4 = *(LDS_AS const f32x4*)(ss + 32 + qt * 16 + g * 4);
+        probs(s, dp, lv, dl4, 256 + l15 < p.Sk);
+        const s16x4 p4 = pack4<T>(s[0], s[1], s[2], s[3]), d4 = pack4<T>(dp[0], dp[1], dp[2], dp[3]);
+        *(LDS_AS s16x4*)(dsb + dsbuf * O::DSB + 8 * O::DSK + ds_off(l15, qt) + g * 8) = d4;
+        const s16x8 pf = qt == 0 ? (s16x8){p4[0], p4[1], p4[2], p4[3], 0, 0, 0, 0} : (s16x8){0, 0, 0, 0, p4[0], p4[1], p4[2], p4[3]};
+        const s16x8 df = qt == 0 ? (s16x8){d4[0], d4[1], d4[2], d4[3], 0, 0, 0, 0} : (s16x8){0, 0, 0, 0, d4[0], d4[1], d4[2], d4[3]};
+        LDS_AS float* xr = x16 + qt * 2 * HDP;
+#pragma unroll
+        for (int td = 0; td < C::TD; ++td) {
+            const f32x4 dvx = T16<T>::mfma(lds_tr_frag<HDP>(dos, td, 0, lane), pf, zero4);
+            const f32x4 dkx = T16<T>::mfma(lds_tr_frag<HDP>(qs, td, 0, lane), df, zero4);
+            if (l15 == 0) {
+                LDS_AS f32x4* xk = (LDS_AS f32x4*)(xr + td * 16 + g * 4);
+                LDS_AS f32x4* xv = (LDS_AS f32x4*)(xr + HDP + td * 16 + g * 4);
+                *xk = *xk + dkx;
+                *xv = *xv + dvx;
+            }
+        }
+    };
+
+    // dQ^T tile td of the chunk's two query tiles over all keys; rows q0.. of item (b, h)
+    auto phase2_dq = [&](int dsbuf, int td, int q0) {
+        LDS_AS const char* dsi = dsb + dsbuf * O::DSB;
+        const int rlo = g * 4 + (l15 >> 2);
+        const int koff = rlo * C::RS + (((td * 2 + ((l15 >> 1) & 1)) ^ ((rlo & 7) << 1)) << 4) + (l15 & 1) * 8;   // rows rlo + 16 n share the key
+        const int doff0 = ds_off(rlo, 0) + (l15 & 3) * 8, doff1 = ds_off(rlo, 1) + (l15 & 3) * 8;
+        f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            if (s >= nks) continue;
+            const s16x4 z4 = {0, 0, 0, 0};
+            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + s * 32 * C::RS + koff));
+            const s16x4 ahi = s < 8 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + (s * 32 + 16) * C::RS + koff)) : z4;
+            const s16x4 b0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff0));
+            const s16x4 b0hi = s < 8 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff0)) : z4;
+            const s16x4 b1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff1));
+            const s16x4 b1hi = s < 8 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff1)) : z4;
+            const s16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            const s16x8 b0 = {b0lo[0], b0lo[1], b0lo[2], b0lo[3], b0hi[0], b0hi[1], b0hi[2], b0hi[3]};
+            const s16x8 b1 = {b1lo[0], b1lo[1], b1lo[2], b1lo[3], b1hi[0], b1hi[1], b1hi[2], b1hi[3]};
+            acc0 = T16<T>::mfma(a, b0, acc0);
+            acc1 = T16<T>::mfma(a, b1, acc1);
+        }
+        const int d = td * 16 + g * 4;
+        if (d < p.hd) {
+            T* dqb = dq + (int64_t)b * p.q_bs + h * p.hd + d;
+            const int i0 = q0 + l15, i1 = q0 + 16 + l15;
+            if (i0 < p.Sq) *(s16x4*)(dqb + (int64_t)i0 * p.q_rs) = pack4<T>(acc0[0], acc0[1], acc0[2], acc0[3]);
+            if (i1 < p.Sq) *(s16x4*)(dqb + (int64_t)i1 * p.q_rs) = pack4<T>(acc1[0], acc1[1], acc1[2], acc1[3]);
+        }
+    };
+
+    auto item_start = [&](int item) {
+        b = item / p.H;
+        h = item - b * p.H;
+        const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
+        const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
+        constexpr int NKL = (O::KROWS * CPR + 511) / 512;
+        s16x8 kr[NKL];
+#pragma unroll
+        for (int it = 0; it < NKL; ++it) {
+            const int c = it * 512 + tid;
+            const int row = c / CPR, ch = c - row * CPR;
+            s16x8 a = zero8;
+            if (row < p.Sk && ch * 8 < p.hd) a = *(const s16x8*)(kb + (int64_t)row * p.k_rs + ch * 8);
+            kr[it] = a;
+        }
+        s16x8 vx = zero8;
+        {
+            const int row = 256 + tid / CPR, ch = tid - (tid / CPR) * CPR;
+            if (tid < 16 * CPR && row < p.Sk && ch * 8 < p.hd) vx = *(const s16x8*)(vb + (int64_t)row * p.v_rs + ch * 8);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) row_frags<T, HDP>(vf[rb], vb, p.v_rs, wave * 32 + rb * 16 + l15, p.Sk, p.hd, lane);
+        __syncthreads();   // every wave has left the previous item's phase 2: the K image and the key-256 rows are free
+#pragma unroll
+        for (int it = 0; it < NKL; ++it) {
+            const int c = it * 512 + tid;
+            const int row = c / CPR, ch = c - row * CPR;
+            if (row < O::KROWS) *(LDS_AS s16x8*)(kimg + row * C::RS + ((ch ^ ((row & 7) << 1)) << 4)) = kr[it];
+        }
+        if (tid < 16 * CPR) {
+            const int row = tid / CPR, ch = tid - row * CPR;
+            *(LDS_AS s16x8*)(v16 + row * C::RS + ((ch ^ ((row & 7) << 1)) << 4)) = vx;
+        }
+        if (tid < 4 * HDP) x16[tid] = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int td = 0; td < C::TD; ++td) {
+                dkacc[rb][td] = zero4;
+                dvacc[rb][td] = zero4;
+            }
+        __syncthreads();
+    };
+
+    auto item_end = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int j = wave * 32 + rb * 16 + l15;
+            if (j < p.Sk) {
+                T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * p.hd;
+                T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * p.hd;
+#pragma unroll
+                for (int td = 0; td < C::TD; ++td) {
+                    const int d = td * 16 + g * 4;
+                    if (d < p.hd) {
+                        *(s16x4*)(dkb + d) = pack4<T>(dkacc[rb][td][0], dkacc[rb][td][1], dkacc[rb][td][2], dkacc[rb][td][3]);
+                        *(s16x4*)(dvb + d) = pack4<T>(dvacc[rb][td][0], dvacc[rb][td][1], dvacc[rb][td][2], dvacc[rb][td][3]);
+                    }
+                }
+            }
+        }
+        if (has16 && wave == 3 && lane < 2 * (HDP / 4)) {   // the key-256 row: both helpers' sums (complete since the last barrier)
+            const int which = lane / (HDP / 4), d = (lane - which * (HDP / 4)) * 4;
+            const f32x4 a0 = *(LDS_AS const f32x4*)(x16 + which * HDP + d), a1 = *(LDS_AS const f32x4*)(x16 + 2 * HDP + which * HDP + d);
+            if (d < p.hd) {
+                T* out = (which ? dv + (int64_t)b * p.v_bs + (int64_t)256 * p.v_rs : dk + (int64_t)b * p.k_bs + (int64_t)256 * p.k_rs) + h * p.hd + d;
+                *(s16x4*)out = pack4<T>(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
+            }
+        }
+    };
+
+    // ---- prologue: chunks 0 and 1 into the ring, chunk 2 requested ----
+    Piece pc;
+    issue(pc);
+    commit(pc, 0);
+    issue(pc);
+    commit(pc, 1);
+    issue(pc);
+
+    int cur_ii = 0, cur_c = 0, st = 0;           // the chunk in hand: item index, chunk of the item, ring stage (flat index % 3)
+    PH_DECL;
+    for (int G = 0; G < total; ++G) {
+        if (cur_c == 0) {
+            item_start(item0 + cur_ii * item_step);
+            PH(0);
+            if (has16 && hw >= 0) helper16(st, G & 1, hw);
+            PH(1);
+        }
+        phase1(st, G & 1);
+        PH(2);
+        __syncthreads();
+        PH(3);
+        // chunk G + 2 -> ring stage (G + 2) % 3 (last read before this barrier), chunk G + 3 -> registers
+        commit(pc, st == 0 ? 2 : st - 1);
+        PH(4);
+        issue(pc);
+        PH(5);
+        if (dq_td >= 0) {
+            if (dq_td < C::TD) phase2_dq(G & 1, dq_td, cur_c * 32);
+        } else if (has16 && cur_c + 1 < NC) {
+            helper16(st == 2 ? 0 : st + 1, (G + 1) & 1, hw);
+        }
+        PH(6);
+        if (cur_c == NC - 1) item_end();
+        PH(7);
+        st = st == 2 ? 0 : st + 1;
+        if (++cur_c == NC) { cur_c = 0; ++cur_ii; }
+    }
+#ifdef MICO_ATTN_PHASES
+    if (lane == 0 && blockIdx.x < 512) for (int e_ = 0; e_ < 8; ++e_) g_attn_phase[(blockIdx.x * 8 + wave) * 8 + e_] = ph_acc[e_];   // per wave
+#endif
+}
+
 int check_params(const mico_attn_params* p, const char* who) {
     MICO_CHECK(p, "%s: null params", who);
     MICO_CHECK(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Sk > 0, "%s: empty problem", who);
@@ -2327,6 +2695,17 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;
     const bool res = !no_res && p->kv_batch_mod == 0 && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 &&
                      p->Sq <= 256 + ResCfg<96>::NXMAX;
+    // the towers' self-attention (g/14: 257 tokens, hd 88): one pass, scores computed once (MICO_ATTN_NOONEPASS=1: the two resident kernels, for A/B runs)
+    static const bool no_onepass = getenv("MICO_ATTN_NOONEPASS") != nullptr;
+    if (res && !no_onepass && p->hd > 64 && p->Sk <= 257) {
+        static const int n_cu1 = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int nitems = p->B * p->H;
+        const dim3 grid(nitems < n_cu1 ? nitems : n_cu1);
+        DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_onepass_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse,
+                                        (T*)dq, (T*)dk, (T*)dv, *p));
+        MICO_LAUNCH_CHECK();
+        return MICO_OK;
+    }
     if (res) {
         static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int nitems = p->B * p->H;
