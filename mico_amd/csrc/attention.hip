@@ -9,6 +9,7 @@
 // gives the backward: dQ^T = K^T dS^T in the per-query-block kernel and dK^T = Q^T dS, dV^T = dO^T P in the
 // per-key-block kernel.  hd = 88 (EVA01-g) is zero-padded to 96 in LDS/registers only.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -2271,12 +2272,16 @@ template <int HDP> struct OpCfg {
     static constexpr int X16 = 2 * 2 * HDP * 4;           // [helper wave][dK | dV][HDP]: the key-256 row, summed over the chunks
     static constexpr int LDS = KT + V16 + NST * STAGE + 2 * DSB + STAT + X16;
 };
+// an opaque copy of a lane-dependent value: address arithmetic derived from it is redone where it is used instead of being hoisted out of
+// the item / chunk loops into registers that live (spilled) through them
+__device__ __forceinline__ int launder(int x) { asm volatile("" : "+v"(x)); return x; }
 // byte offset of (key row kl of the step, query tile qt) in a dS step image: the two 32-byte halves of a 64-byte row swap with bit 2 of the
 // row, so that the 8-byte writes of a score tile (16 rows x 32 bytes) and the transposing reads (4 rows x 32 bytes per lane group) both
 // spread over all banks
 __device__ __forceinline__ int ds_off(int kl, int qt) { return kl * 64 + ((qt ^ ((kl >> 2) & 1)) << 5); }
 
-template <typename T, int HDP>
+// KMODE 2: Sk == 257 (the towers), 1: Sk == 256, 0: Sk < 256 (ragged / dead key blocks: masks and run-time loops, no 17th block)
+template <typename T, int HDP, int KMODE>
 __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                                   const T* __restrict__ o, const T* __restrict__ d_o, const float* __restrict__ lse,
                                                                   T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, const mico_attn_params p) {
@@ -2297,8 +2302,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int nitems = p.B * p.H;
     const int NC = (p.Sq + 31) >> 5;             // 32-query chunks per item
-    const int nks = (p.Sk + 31) >> 5;            // 32-key steps of the dQ reduction
-    const bool has16 = p.Sk > 256;
+    const int nks = KMODE == 2 ? 9 : (KMODE == 1 ? 8 : (p.Sk + 31) >> 5);   // 32-key steps of the dQ reduction
+    constexpr bool has16 = KMODE == 2, FULLK = KMODE != 0;
     // roles in phase 2: waves 0-2 / 4-6 own head-dim tiles 0-2 / 3-5 of dQ^T, waves 3 and 7 run key block 16 for query tile 0 / 1 of the next chunk
     const int dq_td = (wave & 3) < 3 ? (wave & 3) + 3 * (wave >> 2) : -1;
     const int hw = (wave & 3) == 3 ? (wave >> 2) : -1;
@@ -2315,46 +2320,55 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
 
     for (int c = tid; c < 2 * O::DSB / 16; c += 512) *(LDS_AS s16x8*)(dsb + c * 16) = zero8;   // rows of key blocks nobody owns stay zero
 
-    // ---- the loader: thread = (chunk row tid >> 4, 16-byte piece tid & 15) ----
-    struct Piece { s16x8 q, d, o; float l; };
-    const int lrow = tid >> 4, lch = tid & 15;
+    // ---- the loader: thread = (chunk row tid >> 4, 16-byte slot tid & 15 of the 256-byte LDS row) ----
+    // Q and dO go straight into the ring by LDS-DMA (no registers): a wave's instruction fills four consecutive rows, lane -> (row, slot), and
+    // the slot holds the head-dim piece slot ^ key(row) - the tiles' swizzle, applied on the global side.  O (only needed for delta) and lse
+    // travel through registers; they are requested AFTER the two DMA instructions, so the moment the compiler has waited for O the thread's
+    // own DMA pieces have landed as well (loads return in order) and the next barrier publishes the stage.
+    struct Piece { s16x8 o; float l; };
+    const int lrow = tid >> 4, lch = (tid & 15) ^ (((tid >> 4) & 7) << 1);
     const bool lch_ok = lch * 8 < p.hd;
-    const int loff = lrow * C::RS + ((lch ^ ((lrow & 7) << 1)) << 4);
     const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2), obytes = (int)(((int64_t)(p.Sq - 1) * p.o_rs + p.hd) * 2);
-    int pf_ii = 0, pf_c = 0;                     // the next chunk to request
-    auto issue = [&](Piece& pc) {
-        const bool live = pf_ii < n_my;
-        const int item = item0 + (live ? pf_ii : n_my - 1) * item_step;
-        const int b = item / p.H, h = item - b * p.H;
-        const int row = pf_c * 32 + lrow;
-        const bool rl = live && row < p.Sq;
-        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)b * p.q_bs + h * p.hd), 0, qbytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(d_o + (int64_t)b * p.o_bs + h * p.hd), 0, obytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(o + (int64_t)b * p.o_bs + h * p.hd), 0, obytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rl_ = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((int64_t)b * p.H + h) * p.Sq), 0, p.Sq * 4, 0x00020000);
-        const unsigned qo = (rl && lch_ok) ? (unsigned)(row * p.q_rs * 2 + lch * 16) : 0xFFFFFFF0u;
-        const unsigned oo = (rl && lch_ok) ? (unsigned)(row * p.o_rs * 2 + lch * 16) : 0xFFFFFFF0u;
-        pc.q = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, qo, 0, 0));
-        pc.d = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rd, oo, 0, 0));
+    // the next chunk to request: chunk pf_c of item (pf_b, pf_h), pf_left items of this workgroup still to come after it
+    int pf_c = 0, pf_left = n_my - 1, pf_b = item0 / p.H, pf_h = item0 - (item0 / p.H) * p.H;
+    const unsigned ring_u = (unsigned)(uintptr_t)ring + (unsigned)(wave * 4 * C::RS);
+    auto issue = [&](Piece& pc, int stage) {
+        const int t = launder(tid);
+        const int row = pf_c * 32 + (t >> 4);
+        const bool rl = pf_left >= 0 && row < p.Sq, rp = rl && lch_ok;
+        __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)pf_b * p.q_bs + pf_h * p.hd), 0, qbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(d_o + (int64_t)pf_b * p.o_bs + pf_h * p.hd), 0, obytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(o + (int64_t)pf_b * p.o_bs + pf_h * p.hd), 0, obytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((int64_t)pf_b * p.H + pf_h) * p.Sq), 0, p.Sq * 4, 0x00020000);
+        const unsigned qo = rp ? (unsigned)(row * p.q_rs * 2 + lch * 16) : 0xFFFFFFF0u, oo = rp ? (unsigned)(row * p.o_rs * 2 + lch * 16) : 0xFFFFFFF0u;
+        lds_dma16(rq, ring_u + stage * O::STAGE, qo);
+        lds_dma16(rd, ring_u + stage * O::STAGE + O::QT, oo);
         pc.o = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, oo, 0, 0));
-        pc.l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl_, (rl && lch == 15) ? (unsigned)(row * 4) : 0xFFFFFFF0u, 0, 0));
-        if (++pf_c == NC) { pf_c = 0; ++pf_ii; }
-    };
-    auto commit = [&](const Piece& pc, int stage) {
-        LDS_AS char* st = ring + stage * O::STAGE;
-        if (lch < CPR) {
-            *(LDS_AS s16x8*)(st + loff) = pc.q;
-            *(LDS_AS s16x8*)(st + O::QT + loff) = pc.d;
+        pc.l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rl && (t & 15) == 15) ? (unsigned)(row * 4) : 0xFFFFFFF0u, 0, 0));
+        if (++pf_c == NC) {
+            pf_c = 0;
+            if (--pf_left >= 0) {
+                pf_h += item_step;
+                if (pf_h >= p.H) { const int nb = pf_h / p.H; pf_b += nb; pf_h -= nb * p.H; }
+            }
         }
+    };
+    // delta * scale and lse * log2(e) of the chunk in `stage` (whose dO pieces this thread's own DMA has delivered)
+    auto commit = [&](const Piece& pc, int stage) {
+        // the read-back of the thread's own dO piece is ordered behind the arrival of O (hence of the older DMA) through a data dependence
+        // the compiler can see: the LDS address passes through a statement that consumes O
+        int t = tid;
+        asm volatile("" : "+v"(t) : "v"(pc.o));
+        const s16x8 dpc = *(LDS_AS const s16x8*)(ring + stage * O::STAGE + O::QT + t * 16);
         float a[8], c8[8], dl = 0.f;
         unpack8<T>(pc.o, a);
-        unpack8<T>(pc.d, c8);
+        unpack8<T>(dpc, c8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += a[e] * c8[e];
         dl = row16_sum(dl);
         LDS_AS float* ss = stat + stage * 64;
-        if (lch == 0) ss[32 + lrow] = dl * p.scale;
-        if (lch == 15) ss[lrow] = pc.l * LOG2E;
+        if ((t & 15) == 0) ss[32 + (t >> 4)] = dl * p.scale;
+        if ((t & 15) == 15) ss[t >> 4] = pc.l * LOG2E;
     };
 
     // ---- per-item state ----
@@ -2362,23 +2376,28 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     f32x4 dkacc[2][C::TD], dvacc[2][C::TD];
     int b = 0, h = 0;
 
-    // score tile of (16 queries at ring rows qt*16.., 16 keys) -> P, dS
-    auto probs = [&](f32x4& s, f32x4& dp, const f32x4& lv, const f32x4& dl4, const bool keep) {
+    // score tile (16 queries x 16 keys) -> P (into s), dS (into dp); packed fp32 arithmetic, two elements per instruction
+    auto probs = [&](f32x4& s, f32x4& dp, const f32x4& lv, const f32x4& dl4) {
+        const f32x2 sc = {sc2, sc2}, sl = {p.scale, p.scale};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lv[r]));
-            float ds = pv * fmaf(dp[r], p.scale, -dl4[r]);
-            if (!keep) { pv = 0.f; ds = 0.f; }
-            s[r] = pv;
-            dp[r] = ds;
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2 x = __builtin_elementwise_fma((f32x2){s[r], s[r + 1]}, sc, -(f32x2){lv[r], lv[r + 1]});
+            const f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            const f32x2 t = __builtin_elementwise_fma((f32x2){dp[r], dp[r + 1]}, sl, -(f32x2){dl4[r], dl4[r + 1]});
+            const f32x2 ds = pv * t;
+            s[r] = pv[0]; s[r + 1] = pv[1];
+            dp[r] = ds[0]; dp[r + 1] = ds[1];
         }
     };
 
+    // FULL: both key blocks of every wave hold 16 real keys (Sk >= 256) - one basic block, no masks
     auto phase1 = [&](int stage, int dsbuf) {
+        constexpr bool FULL = FULLK;
         LDS_AS const char* qs = ring + stage * O::STAGE;
         LDS_AS const char* dos = qs + O::QT;
         LDS_AS const float* ss = stat + stage * 64;
         LDS_AS char* dsi = dsb + dsbuf * O::DSB + wave * O::DSK;
+        const bool live0 = FULL || wave * 32 < p.Sk, live1 = FULL || wave * 32 + 16 < p.Sk;   // wave-uniform
         s16x4 plo[2], dlo[2];
         s16x8 pf[2], df[2];
 #pragma unroll
@@ -2388,46 +2407,50 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 const s16x8 qf = lds_row_frag<HDP>(qs, qt * 16, ks, lane);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-                    if (wave * 32 + rb * 16 < p.Sk) s[rb] = T16<T>::mfma(qf, lds_row_frag<HDP>(kimg, wave * 32 + rb * 16, ks, lane), s[rb]);
+                if (live0) s[0] = T16<T>::mfma(qf, lds_row_frag<HDP>(kimg, wave * 32, ks, lane), s[0]);
+                if (live1) s[1] = T16<T>::mfma(qf, lds_row_frag<HDP>(kimg, wave * 32 + 16, ks, lane), s[1]);
             }
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 const s16x8 dof = lds_row_frag<HDP>(dos, qt * 16, ks, lane);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-                    if (wave * 32 + rb * 16 < p.Sk) dp[rb] = T16<T>::mfma(dof, vf[rb][ks], dp[rb]);
+                if (live0) dp[0] = T16<T>::mfma(dof, vf[0][ks], dp[0]);
+                if (live1) dp[1] = T16<T>::mfma(dof, vf[1][ks], dp[1]);
             }
             const f32x4 lv = *(LDS_AS const f32x4*)(ss + qt * 16 + g * 4);
             const f32x4 dl4 = *(LDS_AS const f32x4*)(ss + 32 + qt * 16 + g * 4);
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise pulls the next query tile's fragment reads up here and spills)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int kb0 = wave * 32 + rb * 16;
-                probs(s[rb], dp[rb], lv, dl4, kb0 + 16 <= p.Sk || kb0 + l15 < p.Sk);
+                probs(s[rb], dp[rb], lv, dl4);
+                if (!FULL && kb0 + l15 >= p.Sk) { s[rb] = zero4; dp[rb] = zero4; }
                 const s16x4 p4 = pack4<T>(s[rb][0], s[rb][1], s[rb][2], s[rb][3]), d4 = pack4<T>(dp[rb][0], dp[rb][1], dp[rb][2], dp[rb][3]);
-                if (kb0 < p.Sk) *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt) + g * 8) = d4;
+                if (rb == 0 ? live0 : live1) *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt) + g * 8) = d4;
                 if (qt == 0) { plo[rb] = p4; dlo[rb] = d4; }
                 else {
                     pf[rb] = (s16x8){plo[rb][0], plo[rb][1], plo[rb][2], plo[rb][3], p4[0], p4[1], p4[2], p4[3]};
                     df[rb] = (s16x8){dlo[rb][0], dlo[rb][1], dlo[rb][2], dlo[rb][3], d4[0], d4[1], d4[2], d4[3]};
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int td = 0; td < C::TD; ++td) {
             const s16x8 ado = lds_tr_frag<HDP>(dos, td, 0, lane), aq = lds_tr_frag<HDP>(qs, td, 0, lane);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                if (wave * 32 + rb * 16 >= p.Sk) continue;
-                dvacc[rb][td] = T16<T>::mfma(ado, pf[rb], dvacc[rb][td]);
-                dkacc[rb][td] = T16<T>::mfma(aq, df[rb], dkacc[rb][td]);
+            if (live0) {
+                dvacc[0][td] = T16<T>::mfma(ado, pf[0], dvacc[0][td]);
+                dkacc[0][td] = T16<T>::mfma(aq, df[0], dkacc[0][td]);
+            }
+            if (live1) {
+                dvacc[1][td] = T16<T>::mfma(ado, pf[1], dvacc[1][td]);
+                dkacc[1][td] = T16<T>::mfma(aq, df[1], dkacc[1][td]);
             }
         }
     };
 
     // key block 16 (keys 256..271; row 0 real) against query tile qt of the chunk in `stage`
     auto helper16 = [&](int stage, int dsbuf, int qt) {
+        const int lane = launder((int)threadIdx.x) & 63, l15 = lane & 15, g = lane >> 4;
         LDS_AS const char* qs = ring + stage * O::STAGE;
         LDS_AS const char* dos = qs + O::QT;
         LDS_AS const float* ss = stat + stage * 64;
@@ -2439,47 +2462,59 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         }
         const f32x4 lv = *(LDS_AS const f32x4*)(ss + qt * 16 + g * 4);
         const f32x4 dl4 = *(LDS_AS const f32x4*)(ss + 32 + qt * 16 + g * 4);
-        probs(s, dp, lv, dl4, 256 + l15 < p.Sk);
+        probs(s, dp, lv, dl4);
+        if (256 + l15 >= p.Sk) { s = zero4; dp = zero4; }
         const s16x4 p4 = pack4<T>(s[0], s[1], s[2], s[3]), d4 = pack4<T>(dp[0], dp[1], dp[2], dp[3]);
         *(LDS_AS s16x4*)(dsb + dsbuf * O::DSB + 8 * O::DSK + ds_off(l15, qt) + g * 8) = d4;
         const s16x8 pf = qt == 0 ? (s16x8){p4[0], p4[1], p4[2], p4[3], 0, 0, 0, 0} : (s16x8){0, 0, 0, 0, p4[0], p4[1], p4[2], p4[3]};
         const s16x8 df = qt == 0 ? (s16x8){d4[0], d4[1], d4[2], d4[3], 0, 0, 0, 0} : (s16x8){0, 0, 0, 0, d4[0], d4[1], d4[2], d4[3]};
         LDS_AS float* xr = x16 + qt * 2 * HDP;
+        f32x4 dkx[C::TD], dvx[C::TD];
 #pragma unroll
         for (int td = 0; td < C::TD; ++td) {
-            const f32x4 dvx = T16<T>::mfma(lds_tr_frag<HDP>(dos, td, 0, lane), pf, zero4);
-            const f32x4 dkx = T16<T>::mfma(lds_tr_frag<HDP>(qs, td, 0, lane), df, zero4);
-            if (l15 == 0) {
+            dvx[td] = T16<T>::mfma(lds_tr_frag<HDP>(dos, td, 0, lane), pf, zero4);
+            dkx[td] = T16<T>::mfma(lds_tr_frag<HDP>(qs, td, 0, lane), df, zero4);
+        }
+        if (l15 == 0) {
+#pragma unroll
+            for (int td = 0; td < C::TD; ++td) {
                 LDS_AS f32x4* xk = (LDS_AS f32x4*)(xr + td * 16 + g * 4);
                 LDS_AS f32x4* xv = (LDS_AS f32x4*)(xr + HDP + td * 16 + g * 4);
-                *xk = *xk + dkx;
-                *xv = *xv + dvx;
+                *xk = *xk + dkx[td];
+                *xv = *xv + dvx[td];
             }
         }
     };
 
-    // dQ^T tile td of the chunk's two query tiles over all keys; rows q0.. of item (b, h)
+    // dQ^T tile td of the chunk's two query tiles over all keys (NKS 32-key steps; step 8 holds keys 256..271 only); rows q0.. of item (b, h)
     auto phase2_dq = [&](int dsbuf, int td, int q0) {
+        const int lane = launder((int)threadIdx.x) & 63, l15 = lane & 15, g = lane >> 4;
         LDS_AS const char* dsi = dsb + dsbuf * O::DSB;
         const int rlo = g * 4 + (l15 >> 2);
         const int koff = rlo * C::RS + (((td * 2 + ((l15 >> 1) & 1)) ^ ((rlo & 7) << 1)) << 4) + (l15 & 1) * 8;   // rows rlo + 16 n share the key
         const int doff0 = ds_off(rlo, 0) + (l15 & 3) * 8, doff1 = ds_off(rlo, 1) + (l15 & 3) * 8;
         f32x4 acc0 = zero4, acc1 = zero4;
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            if (s >= nks) continue;
-            const s16x4 z4 = {0, 0, 0, 0};
+        const s16x4 z4 = {0, 0, 0, 0};
+        auto kstep = [&](const int s, const bool both) {
             const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + s * 32 * C::RS + koff));
-            const s16x4 ahi = s < 8 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + (s * 32 + 16) * C::RS + koff)) : z4;
+            const s16x4 ahi = both ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + (s * 32 + 16) * C::RS + koff)) : z4;
             const s16x4 b0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff0));
-            const s16x4 b0hi = s < 8 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff0)) : z4;
+            const s16x4 b0hi = both ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff0)) : z4;
             const s16x4 b1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff1));
-            const s16x4 b1hi = s < 8 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff1)) : z4;
+            const s16x4 b1hi = both ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff1)) : z4;
             const s16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
             const s16x8 b0 = {b0lo[0], b0lo[1], b0lo[2], b0lo[3], b0hi[0], b0hi[1], b0hi[2], b0hi[3]};
             const s16x8 b1 = {b1lo[0], b1lo[1], b1lo[2], b1lo[3], b1hi[0], b1hi[1], b1hi[2], b1hi[3]};
             acc0 = T16<T>::mfma(a, b0, acc0);
             acc1 = T16<T>::mfma(a, b1, acc1);
+        };
+        if (KMODE != 0) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kstep(s, true);
+            if (KMODE == 2) kstep(8, false);     // keys 256..271 only
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < nks; ++s) kstep(s, true);
         }
         const int d = td * 16 + g * 4;
         if (d < p.hd) {
@@ -2490,29 +2525,38 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         }
     };
 
-    auto item_start = [&](int item) {
-        b = item / p.H;
-        h = item - b * p.H;
-        const T* kb = k + (int64_t)b * p.k_bs + h * p.hd;
-        const T* vb = v + (int64_t)b * p.v_bs + h * p.hd;
-        constexpr int NKL = (O::KROWS * CPR + 511) / 512;
-        s16x8 kr[NKL];
+    // K rows of an item (all threads), its V row 256.. and this wave's V rows: requested into registers ...
+    constexpr int NKL = (O::KROWS * CPR + 511) / 512;
+    s16x8 kr[NKL], vx;
+    auto item_fetch = [&](int item) {
+        const int fb = item / p.H, fh = item - fb * p.H;
+        const int tid = launder((int)threadIdx.x), l15 = tid & 15, g = (tid >> 4) & 3;
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)fb * p.k_bs + fh * p.hd), 0, (int)(((int64_t)(p.Sk - 1) * p.k_rs + p.hd) * 2), 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)fb * p.v_bs + fh * p.hd), 0, (int)(((int64_t)(p.Sk - 1) * p.v_rs + p.hd) * 2), 0x00020000);
 #pragma unroll
         for (int it = 0; it < NKL; ++it) {
             const int c = it * 512 + tid;
             const int row = c / CPR, ch = c - row * CPR;
-            s16x8 a = zero8;
-            if (row < p.Sk && ch * 8 < p.hd) a = *(const s16x8*)(kb + (int64_t)row * p.k_rs + ch * 8);
-            kr[it] = a;
+            kr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (row < p.Sk && ch * 8 < p.hd) ? (unsigned)(row * p.k_rs * 2 + ch * 16) : 0xFFFFFFF0u, 0, 0));
         }
-        s16x8 vx = zero8;
         {
             const int row = 256 + tid / CPR, ch = tid - (tid / CPR) * CPR;
-            if (tid < 16 * CPR && row < p.Sk && ch * 8 < p.hd) vx = *(const s16x8*)(vb + (int64_t)row * p.v_rs + ch * 8);
+            vx = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (tid < 16 * CPR && row < p.Sk && ch * 8 < p.hd) ? (unsigned)(row * p.v_rs * 2 + ch * 16) : 0xFFFFFFF0u, 0, 0));
         }
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) row_frags<T, HDP>(vf[rb], vb, p.v_rs, wave * 32 + rb * 16 + l15, p.Sk, p.hd, lane);
-        __syncthreads();   // every wave has left the previous item's phase 2: the K image and the key-256 rows are free
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const int row = wave * 32 + rb * 16 + l15, d = ks * 32 + g * 8;
+                vf[rb][ks] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (row < p.Sk && d < p.hd) ? (unsigned)(row * p.v_rs * 2 + d * 2) : 0xFFFFFFF0u, 0, 0));
+            }
+    };
+    // ... and moved into LDS once every wave has left the previous item's phase 2
+    auto item_start = [&](int item) {
+        b = item / p.H;
+        h = item - b * p.H;
+        const int tid = launder((int)threadIdx.x);
+        __syncthreads();   // the K image and the key-256 rows are free
 #pragma unroll
         for (int it = 0; it < NKL; ++it) {
             const int c = it * 512 + tid;
@@ -2535,6 +2579,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     };
 
     auto item_end = [&]() {
+        const int lane = launder((int)threadIdx.x) & 63, l15 = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int j = wave * 32 + rb * 16 + l15;
@@ -2561,43 +2606,53 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         }
     };
 
-    // ---- prologue: chunks 0 and 1 into the ring, chunk 2 requested ----
+    // ---- prologue: chunks 0, 1, 2 requested into the three ring stages, statistics of chunks 0 and 1 written, the first item's K / V requested ----
     Piece pc;
-    issue(pc);
+    issue(pc, 0);
     commit(pc, 0);
-    issue(pc);
+    issue(pc, 1);
     commit(pc, 1);
-    issue(pc);
+    issue(pc, 2);
+    item_fetch(item0);
 
-    int cur_ii = 0, cur_c = 0, st = 0;           // the chunk in hand: item index, chunk of the item, ring stage (flat index % 3)
+    int G = 0, st = 0;                           // flat chunk index of this workgroup and its ring stage (G % 3)
     PH_DECL;
-    for (int G = 0; G < total; ++G) {
-        if (cur_c == 0) {
-            item_start(item0 + cur_ii * item_step);
-            PH(0);
-            if (has16 && hw >= 0) helper16(st, G & 1, hw);
-            PH(1);
-        }
+    // one chunk: c of the item in hand; LAST: the item's last chunk (its phase 2 also stores dK / dV and requests the next item's K / V, so
+    // that those registers are live from here to the next item_start only)
+    auto chunk = [&](auto last_tag, const int c, const int next_item) {
+        constexpr bool LAST = decltype(last_tag)::value;
         phase1(st, G & 1);
         PH(2);
         __syncthreads();
         PH(3);
-        // chunk G + 2 -> ring stage (G + 2) % 3 (last read before this barrier), chunk G + 3 -> registers
+        // statistics of chunk G + 2 (requested one barrier ago; published by the next barrier), then chunk G + 3 into the stage chunk G just left
         commit(pc, st == 0 ? 2 : st - 1);
         PH(4);
-        issue(pc);
+        issue(pc, st);
         PH(5);
+        if (LAST) {
+            item_end();
+            item_fetch(next_item);
+        }
+        PH(7);
         if (dq_td >= 0) {
-            if (dq_td < C::TD) phase2_dq(G & 1, dq_td, cur_c * 32);
-        } else if (has16 && cur_c + 1 < NC) {
+            if (dq_td < C::TD) phase2_dq(G & 1, dq_td, c * 32);
+        } else if (!LAST && has16) {
             helper16(st == 2 ? 0 : st + 1, (G + 1) & 1, hw);
         }
         PH(6);
-        if (cur_c == NC - 1) item_end();
-        PH(7);
         st = st == 2 ? 0 : st + 1;
-        if (++cur_c == NC) { cur_c = 0; ++cur_ii; }
+        ++G;
+    };
+    for (int ii = 0; ii < n_my; ++ii) {
+        item_start(item0 + ii * item_step);
+        PH(0);
+        if (has16 && hw >= 0) helper16(st, G & 1, hw);
+        PH(1);
+        for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c, 0);
+        chunk(std::true_type{}, NC - 1, item0 + (ii + 1 < n_my ? ii + 1 : ii) * item_step);   // (the last item re-requests itself: no branch around the loads)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring requests beyond the last chunk (zero-fill DMA) must not outlive the workgroup's LDS
 #ifdef MICO_ATTN_PHASES
     if (lane == 0 && blockIdx.x < 512) for (int e_ = 0; e_ < 8; ++e_) g_attn_phase[(blockIdx.x * 8 + wave) * 8 + e_] = ph_acc[e_];   // per wave
 #endif
@@ -2701,8 +2756,9 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
         static const int n_cu1 = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int nitems = p->B * p->H;
         const dim3 grid(nitems < n_cu1 ? nitems : n_cu1);
-        DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_onepass_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse,
-                                        (T*)dq, (T*)dk, (T*)dv, *p));
+#define OP_LAUNCH(KMODE) MICO_LAUNCH((attn_bwd_onepass_kernel<T, 96, KMODE>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, *p)
+        DISPATCH_T16(dtype, { if (p->Sk == 257) OP_LAUNCH(2); else if (p->Sk == 256) OP_LAUNCH(1); else OP_LAUNCH(0); });
+#undef OP_LAUNCH
         MICO_LAUNCH_CHECK();
         return MICO_OK;
     }

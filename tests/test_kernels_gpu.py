@@ -660,8 +660,10 @@ torch.save(dqkv.float().cpu(), sys.argv[1])
         for m in ("", mode):
             env = dict(os.environ)
             env.pop("MICO_ATTN_DKV", None)
-            if m:
+            env.pop("MICO_ATTN_NOONEPASS", None)
+            if m:   # the experiments are variants of the two-kernel path; the default is the one-pass kernel (round 4), which they cross-check here
                 env["MICO_ATTN_DKV"] = m
+                env["MICO_ATTN_NOONEPASS"] = "1"
             f = os.path.join(td, f"g_{m or 'default'}.pt")
             subprocess.run([sys.executable, "-c", code, f], check=True, env=env)
             outs[m] = torch.load(f)
