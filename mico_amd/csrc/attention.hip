@@ -2250,13 +2250,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __rest
 //   * phase 1 of a chunk (all waves): S = Q K^T, dP = dO V^T for the wave's keys, P and dS (lse saved by the forward), dV^T += dO^T P,
 //     dK^T += Q^T dS (transposing reads of the ring tiles), dS -> a 16-bit LDS image [key][query] (double buffered);
 //   * ONE barrier;
-//   * phase 2 (the barrier's other side): six waves own one 16-wide head-dim tile each and reduce dQ^T[d][query] = K^T[d][key] dS^T[key][query]
-//     over ALL keys with transposing reads of the K image and the dS image, and store the chunk's dQ rows; meanwhile the other two waves
-//     run key 256 (the 257th token, a 17th key block with one real row) for the NEXT chunk - its dS rows join the next image, its dK / dV
-//     row accumulates in LDS - and every thread commits chunk G + 2 to the ring and requests chunk G + 3.
+//   * phase 2 (the barrier's other side): the waves share the twelve (head-dim tile, query tile) pairs of dQ^T[d][query] = K^T[d][key] dS^T[key][query],
+//     reduced over keys 0..255 with transposing reads of the K image and the dS image, and store the chunk's dQ rows; every thread also finishes
+//     chunk G + 2 (below) and requests chunk G + 3.
+//   * key 256 (the 257th token) never becomes a 17th key block - a block with one real row made the two waves that ran it the critical path
+//     (+36 % against 256 keys).  It is a rank-one problem, and the loader threads hold exactly its operands: the thread of (query row, 16-byte
+//     piece) multiplies its Q / dO pieces with the matching pieces of K[256] / V[256] (registers, per item), the row's sixteen threads reduce
+//     s, dP and delta together, all of them know P and dS of (row, key 256), and dK[256] += dS Q, dV[256] += P dO accumulate in fp32 registers per
+//     thread over the item (per item: lane-swap sums over the wave's four rows, one partial row per wave in LDS, eight of them added at the item's end); dS[.][256] rides in the stage's statistics and the
+//     dQ waves apply it as a rank-one update from row 256 of the K image.
 // Zero rows make masks unnecessary except in ragged key blocks: Q / dO rows beyond Sq and K / V rows beyond Sk are zero in LDS, so whatever
 // P and dS hold there multiplies zeros (they stay finite: lse of a dead query is 0), and dead rows are never stored.
-// LDS: K image 272 x 256 B, V rows 256.. (16 x 256 B), ring 3 x 16 KiB, dS 2 x 17 KiB, statistics, key-256 rows = 156.3 KiB.
+// LDS: K image 272 x 256 B, ring 3 x 16 KiB, dS 2 x 16 KiB, statistics, the key-256 row = 149.9 KiB.
 // ======================================================================================================================
 template <int HDP> struct OpCfg {
     using C = Cfg<HDP>;
@@ -2265,12 +2270,12 @@ template <int HDP> struct OpCfg {
     static constexpr int STAGE = 2 * QT;                  // Q chunk | dO chunk
     static constexpr int KROWS = 272;
     static constexpr int KT = KROWS * C::RS;
-    static constexpr int V16 = 16 * C::RS;
     static constexpr int DSK = 32 * 64;                   // dS image of one 32-key step: [32 keys][32 queries] 16-bit, 64-byte rows
-    static constexpr int DSB = 8 * DSK + DSK / 2;         // steps 0..7 and the 16 rows (keys 256..271) of step 8
-    static constexpr int STAT = NST * 64 * 4;             // [stage][lse * log2 e | delta * scale][32]
-    static constexpr int X16 = 2 * 2 * HDP * 4;           // [helper wave][dK | dV][HDP]: the key-256 row, summed over the chunks
-    static constexpr int LDS = KT + V16 + NST * STAGE + 2 * DSB + STAT + X16;
+    static constexpr int DSB = 8 * DSK;                   // keys 0..255 (key 256 travels as one fp32 column, see below)
+    static constexpr int SST = 96;                        // floats per stage: lse * log2 e | delta * scale | dS[.][256]
+    static constexpr int STAT = NST * SST * 4;
+    static constexpr int X16 = 8 * 2 * HDP * 4;           // [wave][dK | dV][HDP]: the key-256 row of the item, one partial row per wave
+    static constexpr int LDS = KT + NST * STAGE + 2 * DSB + STAT + X16;
 };
 // an opaque copy of a lane-dependent value: address arithmetic derived from it is redone where it is used instead of being hoisted out of
 // the item / chunk loops into registers that live (spilled) through them
@@ -2290,11 +2295,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     constexpr int CPR = HDP / 8;
     __shared__ __attribute__((aligned(16))) char smem[O::LDS];
     LDS_AS char* kimg = (LDS_AS char*)smem;
-    LDS_AS char* v16 = kimg + O::KT;
-    LDS_AS char* ring = v16 + O::V16;
+    LDS_AS char* ring = kimg + O::KT;
     LDS_AS char* dsb = ring + O::NST * O::STAGE;
     LDS_AS float* stat = (LDS_AS float*)(dsb + 2 * O::DSB);
-    LDS_AS float* x16 = stat + O::NST * 64;
+    LDS_AS float* x16 = stat + O::NST * O::SST;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
     constexpr float LOG2E = 1.4426950408889634f;
     const float sc2 = p.scale * LOG2E;
@@ -2304,9 +2308,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     const int NC = (p.Sq + 31) >> 5;             // 32-query chunks per item
     const int nks = KMODE == 2 ? 9 : (KMODE == 1 ? 8 : (p.Sk + 31) >> 5);   // 32-key steps of the dQ reduction
     constexpr bool has16 = KMODE == 2, FULLK = KMODE != 0;
-    // roles in phase 2: waves 0-2 / 4-6 own head-dim tiles 0-2 / 3-5 of dQ^T, waves 3 and 7 run key block 16 for query tile 0 / 1 of the next chunk
-    const int dq_td = (wave & 3) < 3 ? (wave & 3) + 3 * (wave >> 2) : -1;
-    const int hw = (wave & 3) == 3 ? (wave >> 2) : -1;
+    // roles in phase 2: wave w < 4 owns head-dim tile w of dQ^T for both query tiles of the chunk, waves 4..7 one (tile 4 or 5, query tile) pair
+    // each - three of the twelve pairs per SIMD (waves w and w + 4 share one)
+    const int dq_td = wave < 4 ? wave : 4 + ((wave - 4) >> 1);
+    const int dq_qt = wave < 4 ? -1 : (wave & 1);   // -1: both
 
     // XCD-contiguous runs of items (see attn_fwd_res_kernel)
     const int nwg = gridDim.x;
@@ -2326,8 +2331,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     // travel through registers; they are requested AFTER the two DMA instructions, so the moment the compiler has waited for O the thread's
     // own DMA pieces have landed as well (loads return in order) and the next barrier publishes the stage.
     struct Piece { s16x8 o; float l; };
-    const int lrow = tid >> 4, lch = (tid & 15) ^ (((tid >> 4) & 7) << 1);
-    const bool lch_ok = lch * 8 < p.hd;
+    // lch: the head-dim piece this thread's DMA lane fetches (it lands in slot tid & 15 of the row); ach = tid & 15: the piece it accumulates
+    // (O, the K[256] / V[256] pieces, and the Q / dO pieces read back from slot ach ^ key(row) - written by a lane of the same wave's DMA
+    // instructions, which have landed as a whole once the wave's wait for O is over).  One piece index per lane position in every row and wave.
+    const int lrow = tid >> 4, lch = (tid & 15) ^ (((tid >> 4) & 7) << 1), ach = tid & 15;
+    const bool lch_ok = lch * 8 < p.hd, ach_ok = ach * 8 < p.hd;
     const int qbytes = (int)(((int64_t)(p.Sq - 1) * p.q_rs + p.hd) * 2), obytes = (int)(((int64_t)(p.Sq - 1) * p.o_rs + p.hd) * 2);
     // the next chunk to request: chunk pf_c of item (pf_b, pf_h), pf_left items of this workgroup still to come after it
     int pf_c = 0, pf_left = n_my - 1, pf_b = item0 / p.H, pf_h = item0 - (item0 / p.H) * p.H;
@@ -2335,7 +2343,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     auto issue = [&](Piece& pc, int stage) {
         const int t = launder(tid);
         const int row = pf_c * 32 + (t >> 4);
-        const bool rl = pf_left >= 0 && row < p.Sq, rp = rl && lch_ok;
+        const bool rl = pf_left >= 0 && row < p.Sq, rp = rl && lch_ok, ra = rl && ach_ok;
         __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(q + (int64_t)pf_b * p.q_bs + pf_h * p.hd), 0, qbytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(d_o + (int64_t)pf_b * p.o_bs + pf_h * p.hd), 0, obytes, 0x00020000);
         __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(o + (int64_t)pf_b * p.o_bs + pf_h * p.hd), 0, obytes, 0x00020000);
@@ -2343,8 +2351,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         const unsigned qo = rp ? (unsigned)(row * p.q_rs * 2 + lch * 16) : 0xFFFFFFF0u, oo = rp ? (unsigned)(row * p.o_rs * 2 + lch * 16) : 0xFFFFFFF0u;
         lds_dma16(rq, ring_u + stage * O::STAGE, qo);
         lds_dma16(rd, ring_u + stage * O::STAGE + O::QT, oo);
-        pc.o = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, oo, 0, 0));
-        pc.l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rl && (t & 15) == 15) ? (unsigned)(row * 4) : 0xFFFFFFF0u, 0, 0));
+        pc.o = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(ro, ra ? (unsigned)(row * p.o_rs * 2 + ach * 16) : 0xFFFFFFF0u, 0, 0));
+        pc.l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, rl ? (unsigned)(row * 4) : 0xFFFFFFF0u, 0, 0));   // (all 16 lanes of the row: one dword)
         if (++pf_c == NC) {
             pf_c = 0;
             if (--pf_left >= 0) {
@@ -2353,22 +2361,77 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
             }
         }
     };
-    // delta * scale and lse * log2(e) of the chunk in `stage` (whose dO pieces this thread's own DMA has delivered)
+    // The commit side runs two chunks ahead of the arithmetic and keeps its own item state: chunk cm_c of item (cm_b, cm_h) is the next one to
+    // finish; xk / xv = this thread's piece of K[256] / V[256] of that item; dk8 / dv8 = its share of dK[256] / dV[256].
+    int cm_c = 0, cm_left = n_my - 1, cm_b = pf_b, cm_h = pf_h;
+    s16x8 xk = zero8, xv = zero8;
+    float dk8[8], dv8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dk8[e] = 0.f; dv8[e] = 0.f; }
+    auto fetch256 = [&]() {
+        if (KMODE != 2) return;
+        const bool ok = cm_left >= 0 && ach_ok;
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)cm_b * p.k_bs + cm_h * p.hd), 0, (int)(((int64_t)(p.Sk - 1) * p.k_rs + p.hd) * 2), 0x00020000);
+        __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)cm_b * p.v_bs + cm_h * p.hd), 0, (int)(((int64_t)(p.Sk - 1) * p.v_rs + p.hd) * 2), 0x00020000);
+        xk = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (unsigned)(256 * p.k_rs * 2 + ach * 16) : 0xFFFFFFF0u, 0, 0));
+        xv = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (unsigned)(256 * p.v_rs * 2 + ach * 16) : 0xFFFFFFF0u, 0, 0));
+    };
+    // delta * scale and lse * log2(e) of the chunk in `stage` (whose Q / dO pieces this thread's own DMA has delivered), and key 256 against
+    // the chunk's 32 queries
     auto commit = [&](const Piece& pc, int stage) {
-        // the read-back of the thread's own dO piece is ordered behind the arrival of O (hence of the older DMA) through a data dependence
+        // the read-back of the thread's own pieces is ordered behind the arrival of O (hence of the older DMA) through a data dependence
         // the compiler can see: the LDS address passes through a statement that consumes O
         int t = tid;
         asm volatile("" : "+v"(t) : "v"(pc.o));
-        const s16x8 dpc = *(LDS_AS const s16x8*)(ring + stage * O::STAGE + O::QT + t * 16);
+        const int roff = (t >> 4) * C::RS + (((t & 15) ^ (((t >> 4) & 7) << 1)) << 4);   // piece ach of the row
+        const s16x8 dpc = *(LDS_AS const s16x8*)(ring + stage * O::STAGE + O::QT + roff);
         float a[8], c8[8], dl = 0.f;
         unpack8<T>(pc.o, a);
         unpack8<T>(dpc, c8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += a[e] * c8[e];
-        dl = row16_sum(dl);
-        LDS_AS float* ss = stat + stage * 64;
-        if ((t & 15) == 0) ss[32 + (t >> 4)] = dl * p.scale;
-        if ((t & 15) == 15) ss[t >> 4] = pc.l * LOG2E;
+        dl = row16_sum(dl) * p.scale;
+        const float l2 = pc.l * LOG2E;
+        LDS_AS float* ss = stat + stage * O::SST;
+        if ((t & 15) == 0) { ss[32 + (t >> 4)] = dl; ss[t >> 4] = l2; }
+        if (KMODE == 2) {
+            const s16x8 qpc = *(LDS_AS const s16x8*)(ring + stage * O::STAGE + roff);
+            float q8[8], k8[8], v8[8], sp = 0.f, dpp = 0.f;
+            unpack8<T>(qpc, q8);
+            unpack8<T>(xk, k8);
+            unpack8<T>(xv, v8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sp += q8[e] * k8[e]; dpp += c8[e] * v8[e]; }
+            sp = row16_sum(sp);
+            dpp = row16_sum(dpp);
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sp, sc2, -l2));     // a dead row (Q = dO = 0, lse = 0): P = 1 times dO = 0, dS = 0
+            const float ds = pv * fmaf(dpp, p.scale, -dl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dk8[e] = fmaf(ds, q8[e], dk8[e]); dv8[e] = fmaf(pv, c8[e], dv8[e]); }
+            if ((t & 15) == 1) ss[64 + (t >> 4)] = ds;
+            if (++cm_c == NC) {   // the item's last chunk: the 32 rows' shares of its key-256 row meet in LDS (read out by item_end two barriers later)
+                cm_c = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {   // the wave's four rows (lanes l, l + 16, l + 32, l + 48 hold the same piece)
+                    dk8[e] = group_sum(dk8[e]);
+                    dv8[e] = group_sum(dv8[e]);
+                }
+                if (t < 16 + (t & ~63) && ach_ok) {   // the first row of the wave writes the wave's partial row
+                    LDS_AS float* xw = x16 + wave * 2 * HDP + ach * 8;
+                    *(LDS_AS f32x4*)xw = (f32x4){dk8[0], dk8[1], dk8[2], dk8[3]};
+                    *(LDS_AS f32x4*)(xw + 4) = (f32x4){dk8[4], dk8[5], dk8[6], dk8[7]};
+                    *(LDS_AS f32x4*)(xw + HDP) = (f32x4){dv8[0], dv8[1], dv8[2], dv8[3]};
+                    *(LDS_AS f32x4*)(xw + HDP + 4) = (f32x4){dv8[4], dv8[5], dv8[6], dv8[7]};
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dk8[e] = 0.f; dv8[e] = 0.f; }
+                if (--cm_left >= 0) {
+                    cm_h += item_step;
+                    if (cm_h >= p.H) { const int nb = cm_h / p.H; cm_b += nb; cm_h -= nb * p.H; }
+                }
+                fetch256();
+            }
+        }
     };
 
     // ---- per-item state ----
@@ -2395,7 +2458,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         constexpr bool FULL = FULLK;
         LDS_AS const char* qs = ring + stage * O::STAGE;
         LDS_AS const char* dos = qs + O::QT;
-        LDS_AS const float* ss = stat + stage * 64;
+        LDS_AS const float* ss = stat + stage * O::SST;
         LDS_AS char* dsi = dsb + dsbuf * O::DSB + wave * O::DSK;
         const bool live0 = FULL || wave * 32 < p.Sk, live1 = FULL || wave * 32 + 16 < p.Sk;   // wave-uniform
         s16x4 plo[2], dlo[2];
@@ -2448,86 +2511,83 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         }
     };
 
-    // key block 16 (keys 256..271; row 0 real) against query tile qt of the chunk in `stage`
-    auto helper16 = [&](int stage, int dsbuf, int qt) {
-        const int lane = launder((int)threadIdx.x) & 63, l15 = lane & 15, g = lane >> 4;
-        LDS_AS const char* qs = ring + stage * O::STAGE;
-        LDS_AS const char* dos = qs + O::QT;
-        LDS_AS const float* ss = stat + stage * 64;
-        f32x4 s = zero4, dp = zero4;
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-            s = T16<T>::mfma(lds_row_frag<HDP>(qs, qt * 16, ks, lane), lds_row_frag<HDP>(kimg, 256, ks, lane), s);
-            dp = T16<T>::mfma(lds_row_frag<HDP>(dos, qt * 16, ks, lane), lds_row_frag<HDP>(v16, 0, ks, lane), dp);
-        }
-        const f32x4 lv = *(LDS_AS const f32x4*)(ss + qt * 16 + g * 4);
-        const f32x4 dl4 = *(LDS_AS const f32x4*)(ss + 32 + qt * 16 + g * 4);
-        probs(s, dp, lv, dl4);
-        if (256 + l15 >= p.Sk) { s = zero4; dp = zero4; }
-        const s16x4 p4 = pack4<T>(s[0], s[1], s[2], s[3]), d4 = pack4<T>(dp[0], dp[1], dp[2], dp[3]);
-        *(LDS_AS s16x4*)(dsb + dsbuf * O::DSB + 8 * O::DSK + ds_off(l15, qt) + g * 8) = d4;
-        const s16x8 pf = qt == 0 ? (s16x8){p4[0], p4[1], p4[2], p4[3], 0, 0, 0, 0} : (s16x8){0, 0, 0, 0, p4[0], p4[1], p4[2], p4[3]};
-        const s16x8 df = qt == 0 ? (s16x8){d4[0], d4[1], d4[2], d4[3], 0, 0, 0, 0} : (s16x8){0, 0, 0, 0, d4[0], d4[1], d4[2], d4[3]};
-        LDS_AS float* xr = x16 + qt * 2 * HDP;
-        f32x4 dkx[C::TD], dvx[C::TD];
-#pragma unroll
-        for (int td = 0; td < C::TD; ++td) {
-            dvx[td] = T16<T>::mfma(lds_tr_frag<HDP>(dos, td, 0, lane), pf, zero4);
-            dkx[td] = T16<T>::mfma(lds_tr_frag<HDP>(qs, td, 0, lane), df, zero4);
-        }
-        if (l15 == 0) {
-#pragma unroll
-            for (int td = 0; td < C::TD; ++td) {
-                LDS_AS f32x4* xk = (LDS_AS f32x4*)(xr + td * 16 + g * 4);
-                LDS_AS f32x4* xv = (LDS_AS f32x4*)(xr + HDP + td * 16 + g * 4);
-                *xk = *xk + dkx[td];
-                *xv = *xv + dvx[td];
-            }
-        }
-    };
-
-    // dQ^T tile td of the chunk's two query tiles over all keys (NKS 32-key steps; step 8 holds keys 256..271 only); rows q0.. of item (b, h)
-    auto phase2_dq = [&](int dsbuf, int td, int q0) {
+    // dQ^T tile td of the chunk's query tiles (QT: both, or one) over keys 0..255 (+ key 256 as a rank-one update); rows q0.. of item (b, h)
+    auto phase2_dq = [&](auto both_tag, int dsbuf, int stage, int td, int qsel, int q0) {
+        constexpr bool BOTH = decltype(both_tag)::value;
         const int lane = launder((int)threadIdx.x) & 63, l15 = lane & 15, g = lane >> 4;
         LDS_AS const char* dsi = dsb + dsbuf * O::DSB;
         const int rlo = g * 4 + (l15 >> 2);
         const int koff = rlo * C::RS + (((td * 2 + ((l15 >> 1) & 1)) ^ ((rlo & 7) << 1)) << 4) + (l15 & 1) * 8;   // rows rlo + 16 n share the key
-        const int doff0 = ds_off(rlo, 0) + (l15 & 3) * 8, doff1 = ds_off(rlo, 1) + (l15 & 3) * 8;
+        const int doff0 = ds_off(rlo, BOTH ? 0 : qsel) + (l15 & 3) * 8, doff1 = ds_off(rlo, 1) + (l15 & 3) * 8;
         f32x4 acc0 = zero4, acc1 = zero4;
-        const s16x4 z4 = {0, 0, 0, 0};
-        auto kstep = [&](const int s, const bool both) {
-            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + s * 32 * C::RS + koff));
-            const s16x4 ahi = both ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + (s * 32 + 16) * C::RS + koff)) : z4;
-            const s16x4 b0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff0));
-            const s16x4 b0hi = both ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff0)) : z4;
-            const s16x4 b1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff1));
-            const s16x4 b1hi = both ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff1)) : z4;
-            const s16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-            const s16x8 b0 = {b0lo[0], b0lo[1], b0lo[2], b0lo[3], b0hi[0], b0hi[1], b0hi[2], b0hi[3]};
-            const s16x8 b1 = {b1lo[0], b1lo[1], b1lo[2], b1lo[3], b1hi[0], b1hi[1], b1hi[2], b1hi[3]};
-            acc0 = T16<T>::mfma(a, b0, acc0);
-            acc1 = T16<T>::mfma(a, b1, acc1);
+        const int d = td * 16 + g * 4;
+        // key 256's operands first: they are needed last and have the whole loop to arrive
+        s16x4 k4r = {0, 0, 0, 0};
+        float ds0 = 0.f, ds1 = 0.f;
+        if (KMODE == 2) {
+            k4r = *(LDS_AS const s16x4*)(kimg + 256 * C::RS + (d >> 3) * 16 + (d & 7) * 2);   // (row 256: swizzle key 0)
+            LDS_AS const float* ss = stat + stage * O::SST + 64;
+            ds0 = ss[(BOTH ? 0 : qsel * 16) + l15];
+            if (BOTH) ds1 = ss[16 + l15];
+        }
+        struct Fr { s16x4 alo, ahi, b0lo, b0hi, b1lo, b1hi; };
+        auto rd = [&](Fr& f, const int s) {
+            f.alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + s * 32 * C::RS + koff));
+            f.ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(kimg + (s * 32 + 16) * C::RS + koff));
+            f.b0lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff0));
+            f.b0hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff0));
+            if (BOTH) {
+                f.b1lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + doff1));
+                f.b1hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(dsi + s * O::DSK + 1024 + doff1));
+            }
         };
-        if (KMODE != 0) {
+        auto mm = [&](const Fr& f) {
+            const s16x8 a = {f.alo[0], f.alo[1], f.alo[2], f.alo[3], f.ahi[0], f.ahi[1], f.ahi[2], f.ahi[3]};
+            const s16x8 b0 = {f.b0lo[0], f.b0lo[1], f.b0lo[2], f.b0lo[3], f.b0hi[0], f.b0hi[1], f.b0hi[2], f.b0hi[3]};
+            acc0 = T16<T>::mfma(a, b0, acc0);
+            if (BOTH) {
+                const s16x8 b1 = {f.b1lo[0], f.b1lo[1], f.b1lo[2], f.b1lo[3], f.b1hi[0], f.b1hi[1], f.b1hi[2], f.b1hi[3]};
+                acc1 = T16<T>::mfma(a, b1, acc1);
+            }
+        };
+        if (KMODE != 0) {   // eight steps, the fragments of three steps in flight ahead of the MFMAs (the order is pinned: left alone the
+                            // compiler reuses one register set and waits for every read)
+            constexpr int AH = 3;
+            Fr ringf[AH];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) kstep(s, true);
-            if (KMODE == 2) kstep(8, false);     // keys 256..271 only
+            for (int i = 0; i < AH; ++i) rd(ringf[i], i);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const Fr cur = ringf[s % AH];
+                if (s + AH < 8) rd(ringf[s % AH], s + AH);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
 #pragma unroll 1
-            for (int s = 0; s < nks; ++s) kstep(s, true);
+            for (int s = 0; s < nks; ++s) {
+                Fr f;
+                rd(f, s);
+                mm(f);
+            }
         }
-        const int d = td * 16 + g * 4;
+        if (KMODE == 2) {   // key 256: dQ[q][d] += dS[q][256] K[256][d]
+            const f32x4 k4 = unpack4<T>(k4r);
+            acc0 += k4 * ds0;
+            if (BOTH) acc1 += k4 * ds1;
+        }
         if (d < p.hd) {
             T* dqb = dq + (int64_t)b * p.q_bs + h * p.hd + d;
-            const int i0 = q0 + l15, i1 = q0 + 16 + l15;
+            const int i0 = q0 + (BOTH ? 0 : qsel * 16) + l15, i1 = q0 + 16 + l15;
             if (i0 < p.Sq) *(s16x4*)(dqb + (int64_t)i0 * p.q_rs) = pack4<T>(acc0[0], acc0[1], acc0[2], acc0[3]);
-            if (i1 < p.Sq) *(s16x4*)(dqb + (int64_t)i1 * p.q_rs) = pack4<T>(acc1[0], acc1[1], acc1[2], acc1[3]);
+            if (BOTH && i1 < p.Sq) *(s16x4*)(dqb + (int64_t)i1 * p.q_rs) = pack4<T>(acc1[0], acc1[1], acc1[2], acc1[3]);
         }
     };
 
     // K rows of an item (all threads), its V row 256.. and this wave's V rows: requested into registers ...
     constexpr int NKL = (O::KROWS * CPR + 511) / 512;
-    s16x8 kr[NKL], vx;
+    s16x8 kr[NKL];
     auto item_fetch = [&](int item) {
         const int fb = item / p.H, fh = item - fb * p.H;
         const int tid = launder((int)threadIdx.x), l15 = tid & 15, g = (tid >> 4) & 3;
@@ -2538,10 +2598,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
             const int c = it * 512 + tid;
             const int row = c / CPR, ch = c - row * CPR;
             kr[it] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (row < p.Sk && ch * 8 < p.hd) ? (unsigned)(row * p.k_rs * 2 + ch * 16) : 0xFFFFFFF0u, 0, 0));
-        }
-        {
-            const int row = 256 + tid / CPR, ch = tid - (tid / CPR) * CPR;
-            vx = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (tid < 16 * CPR && row < p.Sk && ch * 8 < p.hd) ? (unsigned)(row * p.v_rs * 2 + ch * 16) : 0xFFFFFFF0u, 0, 0));
         }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -2556,18 +2612,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         b = item / p.H;
         h = item - b * p.H;
         const int tid = launder((int)threadIdx.x);
-        __syncthreads();   // the K image and the key-256 rows are free
+        // the V rows requested with the K rows are consumed HERE as far as the compiler's wait counters go: first used inside the chunk loop, their
+        // wait (vmcnt(0): they are the youngest loads of item_fetch) would sit in every chunk's phase 1 and drain the ring requests in flight
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(vf[rb][ks]));
+        __syncthreads();   // the K image is free
 #pragma unroll
         for (int it = 0; it < NKL; ++it) {
             const int c = it * 512 + tid;
             const int row = c / CPR, ch = c - row * CPR;
             if (row < O::KROWS) *(LDS_AS s16x8*)(kimg + row * C::RS + ((ch ^ ((row & 7) << 1)) << 4)) = kr[it];
         }
-        if (tid < 16 * CPR) {
-            const int row = tid / CPR, ch = tid - row * CPR;
-            *(LDS_AS s16x8*)(v16 + row * C::RS + ((ch ^ ((row & 7) << 1)) << 4)) = vx;
-        }
-        if (tid < 4 * HDP) x16[tid] = 0.f;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -2580,34 +2637,43 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
 
     auto item_end = [&]() {
         const int lane = launder((int)threadIdx.x) & 63, l15 = lane & 15, g = lane >> 4;
+        // 16-byte stores: a lane holds 4 head dims of a key row per tile; v_permlane16_swap trades one tile's quartet with the neighbouring
+        // lane group for the other tile's, so that even groups hold 8 consecutive head dims of tile td and odd groups of tile td + 1 - half the
+        // store instructions (each touches 16 rows; the address path, not the bytes, is what they cost)
+        static_assert(C::TD % 2 == 0, "tile pairs");
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int j = wave * 32 + rb * 16 + l15;
-            if (j < p.Sk) {
-                T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * p.hd;
-                T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * p.hd;
+            T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * p.hd;
+            T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * p.hd;
 #pragma unroll
-                for (int td = 0; td < C::TD; ++td) {
-                    const int d = td * 16 + g * 4;
-                    if (d < p.hd) {
-                        *(s16x4*)(dkb + d) = pack4<T>(dkacc[rb][td][0], dkacc[rb][td][1], dkacc[rb][td][2], dkacc[rb][td][3]);
-                        *(s16x4*)(dvb + d) = pack4<T>(dvacc[rb][td][0], dvacc[rb][td][1], dvacc[rb][td][2], dvacc[rb][td][3]);
-                    }
+            for (int tp = 0; tp < C::TD; tp += 2) {
+                const int d = (tp + (g & 1)) * 16 + (g >> 1) * 8;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f32x4 ta = m ? dvacc[rb][tp] : dkacc[rb][tp], tb = m ? dvacc[rb][tp + 1] : dkacc[rb][tp + 1];
+                    u32x2 a = __builtin_bit_cast(u32x2, pack4<T>(ta[0], ta[1], ta[2], ta[3])), c = __builtin_bit_cast(u32x2, pack4<T>(tb[0], tb[1], tb[2], tb[3]));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a[0]), "+v"(c[0]));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a[1]), "+v"(c[1]));
+                    if (j < p.Sk && d < p.hd) *(u32x4*)((m ? dvb : dkb) + d) = (u32x4){a[0], a[1], c[0], c[1]};
                 }
             }
         }
-        if (has16 && wave == 3 && lane < 2 * (HDP / 4)) {   // the key-256 row: both helpers' sums (complete since the last barrier)
+        if (has16 && wave == 7 && lane < 2 * (HDP / 4)) {   // the key-256 row: every loader thread's share arrived two barriers ago
             const int which = lane / (HDP / 4), d = (lane - which * (HDP / 4)) * 4;
-            const f32x4 a0 = *(LDS_AS const f32x4*)(x16 + which * HDP + d), a1 = *(LDS_AS const f32x4*)(x16 + 2 * HDP + which * HDP + d);
+            f32x4 a0 = zero4;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a0 += *(LDS_AS const f32x4*)(x16 + w * 2 * HDP + which * HDP + d);
             if (d < p.hd) {
                 T* out = (which ? dv + (int64_t)b * p.v_bs + (int64_t)256 * p.v_rs : dk + (int64_t)b * p.k_bs + (int64_t)256 * p.k_rs) + h * p.hd + d;
-                *(s16x4*)out = pack4<T>(a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]);
+                *(s16x4*)out = pack4<T>(a0[0], a0[1], a0[2], a0[3]);
             }
         }
     };
 
-    // ---- prologue: chunks 0, 1, 2 requested into the three ring stages, statistics of chunks 0 and 1 written, the first item's K / V requested ----
+    // ---- prologue: chunks 0, 1, 2 requested into the three ring stages, chunks 0 and 1 finished, the first item's K / V requested ----
     Piece pc;
+    fetch256();
     issue(pc, 0);
     commit(pc, 0);
     issue(pc, 1);
@@ -2625,7 +2691,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         PH(2);
         __syncthreads();
         PH(3);
-        // statistics of chunk G + 2 (requested one barrier ago; published by the next barrier), then chunk G + 3 into the stage chunk G just left
+        // chunk G + 2 finished (requested one barrier ago; published by the next barrier), then chunk G + 3 into the stage chunk G just left
         commit(pc, st == 0 ? 2 : st - 1);
         PH(4);
         issue(pc, st);
@@ -2635,10 +2701,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
             item_fetch(next_item);
         }
         PH(7);
-        if (dq_td >= 0) {
-            if (dq_td < C::TD) phase2_dq(G & 1, dq_td, c * 32);
-        } else if (!LAST && has16) {
-            helper16(st == 2 ? 0 : st + 1, (G + 1) & 1, hw);
+        if (dq_td < C::TD) {
+            if (dq_qt < 0) phase2_dq(std::true_type{}, G & 1, st, dq_td, 0, c * 32);
+            else phase2_dq(std::false_type{}, G & 1, st, dq_td, dq_qt, c * 32);
         }
         PH(6);
         st = st == 2 ? 0 : st + 1;
@@ -2647,8 +2712,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     for (int ii = 0; ii < n_my; ++ii) {
         item_start(item0 + ii * item_step);
         PH(0);
-        if (has16 && hw >= 0) helper16(st, G & 1, hw);
-        PH(1);
         for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c, 0);
         chunk(std::true_type{}, NC - 1, item0 + (ii + 1 < n_my ? ii + 1 : ii) * item_step);   // (the last item re-requests itself: no branch around the loads)
     }
