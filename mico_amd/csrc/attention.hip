@@ -2453,9 +2453,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         }
     };
 
-    // FULL: both key blocks of every wave hold 16 real keys (Sk >= 256) - one basic block, no masks
-    auto phase1 = [&](int stage, int dsbuf) {
-        constexpr bool FULL = FULLK;
+    // the general form (Sk < 256: ragged or dead key blocks, masks; the compiler's schedule)
+    auto phase1_generic = [&](int stage, int dsbuf) {
+        constexpr bool FULL = false;
         LDS_AS const char* qs = ring + stage * O::STAGE;
         LDS_AS const char* dos = qs + O::QT;
         LDS_AS const float* ss = stat + stage * O::SST;
@@ -2508,6 +2508,96 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
                 dvacc[1][td] = T16<T>::mfma(ado, pf[1], dvacc[1][td]);
                 dkacc[1][td] = T16<T>::mfma(aq, df[1], dkacc[1][td]);
             }
+        }
+    };
+
+    // Sk >= 256: both key blocks of every wave hold 16 real keys - no masks, and the order of LDS reads and MFMAs is pinned (sched_barrier):
+    // left alone hipcc reuses one fragment register set and waits for every read in front of the MFMA that consumes it (the function sits near
+    // its register budget).  S for the four (query tile, key block) pairs advances one head-dim step at a time - four independent MFMA chains,
+    // the K fragments of the next step requested under them - then dP (V fragments live in registers: no LDS), the softmax arithmetic, and the
+    // dV / dK accumulation with the transposed fragments of the next head-dim tile in flight.
+    auto phase1 = [&](int stage, int dsbuf) {
+        if (!FULLK) { phase1_generic(stage, dsbuf); return; }
+        LDS_AS const char* qs = ring + stage * O::STAGE;
+        LDS_AS const char* dos = qs + O::QT;
+        LDS_AS const float* ss = stat + stage * O::SST;
+        LDS_AS char* dsi = dsb + dsbuf * O::DSB + wave * O::DSK;
+        LDS_AS const char* kw = kimg + wave * 32 * C::RS;
+        f32x4 sc[2][2] = {{zero4, zero4}, {zero4, zero4}}, dp[2][2] = {{zero4, zero4}, {zero4, zero4}};   // [query tile][key block]
+        s16x8 qf[2][C::KS], dof[2][C::KS];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) qf[qt][ks] = lds_row_frag<HDP>(qs, qt * 16, ks, lane);
+        s16x8 kc[2] = {lds_row_frag<HDP>(kw, 0, 0, lane), lds_row_frag<HDP>(kw, 16, 0, lane)};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            s16x8 kn[2] = {zero8, zero8};
+            if (ks + 1 < C::KS) {
+                kn[0] = lds_row_frag<HDP>(kw, 0, ks + 1, lane);
+                kn[1] = lds_row_frag<HDP>(kw, 16, ks + 1, lane);
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dof[qt][ks] = lds_row_frag<HDP>(dos, qt * 16, ks, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) sc[qt][rb] = T16<T>::mfma(qf[qt][ks], kc[rb], sc[qt][rb]);
+            __builtin_amdgcn_sched_barrier(0);
+            kc[0] = kn[0];
+            kc[1] = kn[1];
+        }
+        f32x4 lv[2], dl4[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            lv[qt] = *(LDS_AS const f32x4*)(ss + qt * 16 + g * 4);
+            dl4[qt] = *(LDS_AS const f32x4*)(ss + 32 + qt * 16 + g * 4);
+        }
+        s16x8 ado = lds_tr_frag<HDP>(dos, 0, 0, lane), aq = lds_tr_frag<HDP>(qs, 0, 0, lane);   // head-dim tile 0 of the dV / dK step
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) dp[qt][rb] = T16<T>::mfma(dof[qt][ks], vf[rb][ks], dp[qt][rb]);
+        __builtin_amdgcn_sched_barrier(0);
+        s16x8 pf[2], df[2];
+        {
+            s16x4 p4[2][2], d4[2][2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    probs(sc[qt][rb], dp[qt][rb], lv[qt], dl4[qt]);
+                    p4[qt][rb] = pack4<T>(sc[qt][rb][0], sc[qt][rb][1], sc[qt][rb][2], sc[qt][rb][3]);
+                    d4[qt][rb] = pack4<T>(dp[qt][rb][0], dp[qt][rb][1], dp[qt][rb][2], dp[qt][rb][3]);
+                    *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt) + g * 8) = d4[qt][rb];
+                }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                pf[rb] = (s16x8){p4[0][rb][0], p4[0][rb][1], p4[0][rb][2], p4[0][rb][3], p4[1][rb][0], p4[1][rb][1], p4[1][rb][2], p4[1][rb][3]};
+                df[rb] = (s16x8){d4[0][rb][0], d4[0][rb][1], d4[0][rb][2], d4[0][rb][3], d4[1][rb][0], d4[1][rb][1], d4[1][rb][2], d4[1][rb][3]};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int td = 0; td < C::TD; ++td) {
+            s16x8 ado_n = zero8, aq_n = zero8;
+            if (td + 1 < C::TD) {
+                ado_n = lds_tr_frag<HDP>(dos, td + 1, 0, lane);
+                aq_n = lds_tr_frag<HDP>(qs, td + 1, 0, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dvacc[0][td] = T16<T>::mfma(ado, pf[0], dvacc[0][td]);
+            dkacc[0][td] = T16<T>::mfma(aq, df[0], dkacc[0][td]);
+            dvacc[1][td] = T16<T>::mfma(ado, pf[1], dvacc[1][td]);
+            dkacc[1][td] = T16<T>::mfma(aq, df[1], dkacc[1][td]);
+            __builtin_amdgcn_sched_barrier(0);
+            ado = ado_n;
+            aq = aq_n;
         }
     };
 
@@ -2692,20 +2782,20 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         __syncthreads();
         PH(3);
         // chunk G + 2 finished (requested one barrier ago; published by the next barrier), then chunk G + 3 into the stage chunk G just left
+        // (order: the stores of this phase are OLDER than the requests that follow them - the wait for O at the next commit then passes stores that
+        // had a whole chunk to retire; issued after the requests they sat between the wait and the loads it was for)
         commit(pc, st == 0 ? 2 : st - 1);
         PH(4);
-        issue(pc, st);
-        PH(5);
-        if (LAST) {
-            item_end();
-            item_fetch(next_item);
-        }
+        if (LAST) item_end();
         PH(7);
         if (dq_td < C::TD) {
             if (dq_qt < 0) phase2_dq(std::true_type{}, G & 1, st, dq_td, 0, c * 32);
             else phase2_dq(std::false_type{}, G & 1, st, dq_td, dq_qt, c * 32);
         }
         PH(6);
+        issue(pc, st);
+        if (LAST) item_fetch(next_item);
+        PH(5);
         st = st == 2 ? 0 : st + 1;
         ++G;
     };
