@@ -218,6 +218,13 @@ typedef struct mico_attn_params {
      * ITM triplet [own | hard-negative | own] of vast.py:438-447 is one [own | hard-negative] K/V buffer with kv_batch_mod = 2 b.
      * dK / dV are still written per batch entry b (the caller adds the aliased parts).  0: every batch entry has its own K/V. */
     int kv_batch_mod;
+    /* A launch over a SLICE of a larger batch: batch0 = index of the slice's first entry in the whole batch - the dropout counters use
+     * b + batch0, so that a backward issued in several launches regenerates the masks of a forward issued in one.  0 otherwise. */
+    int batch0;
+    /* != 0 (mico_attn_bwd, one-pass kernel for Sq <= 80 at hd 64 only): dK / dV are ADDED to what the buffers hold (16-bit
+     * read-modify-write) instead of overwriting it - the second launch over the ITM triplet's third third, whose K/V set is the first
+     * third's, leaves the sum in place (no per-entry dK/dV buffer, no add pass). */
+    int dkv_accumulate;
 } mico_attn_params;
 
 int mico_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,

@@ -37,7 +37,7 @@ class AttnParams(C.Structure):
         ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int), ("hd", c_int),
         ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64), ("v_bs", c_i64), ("v_rs", c_i64),
         ("o_bs", c_i64), ("o_rs", c_i64), ("scale", c_f), ("mask", c_vp), ("mask_mode", c_int),
-        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("kv_batch_mod", c_int),
+        ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("kv_batch_mod", c_int), ("batch0", c_int), ("dkv_accumulate", c_int),
     ]
 
 
@@ -104,7 +104,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 107   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 108   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
             if (DROP) {   // dropout on the probabilities (compile-time variant: the ViT towers never pay its registers): the row sum above stays the undropped one
                 const unsigned thr = drop_threshold(p.drop_p);
                 const float ik = 1.f / (1.f - p.drop_p);
-                const unsigned long long rowbase = (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
-                if ((unsigned long long)p.B * p.H * p.Sq * p.Sk <= 0xFFFFFFFFull) {   // (launch-uniform) every index below 2^32: the incremental hash
+                const unsigned long long rowbase = (((unsigned long long)(b + p.batch0) * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk;
+                if ((unsigned long long)(p.B + p.batch0) * p.H * p.Sq * p.Sk <= 0xFFFFFFFFull) {   // (launch-uniform) every index below 2^32: the incremental hash
                     const unsigned h0 = p.drop_seed ^ ((unsigned)p.drop_site * 0x9E3779B9u);
                     const unsigned tb = ((unsigned)rowbase + (unsigned)(t * 64 + g * 4)) * 0x85EBCA6Bu;
 #pragma unroll
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
                     const float pr = __expf(x - lse_i);
                     float dpe = dp[tn][r];
                     if (DROP)
-                        dpe *= drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
+                        dpe *= drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)(b + p.batch0) * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
                                          drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
                     ds = pr * (dpe - dl) * p.scale;
                 }
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
                         pv = __builtin_amdgcn_exp2f(x - lv[r]);
                         float dm = 1.f;
                         if (DROP)
-                            dm = drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)b * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
+                            dm = drop_mult(p.drop_seed, p.drop_site, (((unsigned long long)(b + p.batch0) * p.H + h) * p.Sq + i) * (unsigned long long)p.Sk + j,
                                            drop_threshold(p.drop_p), 1.f / (1.f - p.drop_p));
                         ds = pv * fmaf(dp[ti][r] * dm, p.scale, -dv4[r]);
                         pv *= dm;      // dV sees the dropped probabilities
@@ -2099,7 +2099,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __rest
 
     const int nti = (p.Sq + 15) >> 4;                  // 16-query blocks holding real queries (<= 5)
     // dropout: idx = ((b H + h) Sq + i) Sk + j, below 2^32 for every launch routed here (mico_attn_bwd) -> the incremental form of the hash
-    const unsigned ibase = (unsigned)((((unsigned long long)b * p.H + h) * p.Sq) * (unsigned long long)p.Sk);
+    const unsigned ibase = (unsigned)((((unsigned long long)(b + p.batch0) * p.H + h) * p.Sq) * (unsigned long long)p.Sk);
     const unsigned h0 = p.drop_seed ^ ((unsigned)p.drop_site * 0x9E3779B9u), tstep = (unsigned)p.Sk * 0x85EBCA6Bu;
     const unsigned thr = drop_threshold(p.drop_p);
     const float inv_keep = 1.f / (1.f - p.drop_p);
@@ -2191,6 +2191,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __rest
 #pragma unroll
                     for (int td = 0; td < 4; ++td) {
                         const int d = td * 16 + g * 4;
+                        if (p.dkv_accumulate) {   // (launch-uniform) the rows already hold another batch entry's gradient for the same K/V set
+                            dka[td] += unpack4<T>(*(const s16x4*)(dkb + d));
+                            dva[td] += unpack4<T>(*(const s16x4*)(dvb + d));
+                        }
                         *(s16x4*)(dkb + d) = pack4<T>(dka[td][0], dka[td][1], dka[td][2], dka[td][3]);
                         *(s16x4*)(dvb + d) = pack4<T>(dva[td][0], dva[td][1], dva[td][2], dva[td][3]);
                     }
@@ -2821,6 +2825,7 @@ int check_params(const mico_attn_params* p, const char* who) {
     MICO_CHECK(p->mask_mode >= 0 && p->mask_mode <= 2 && (p->mask_mode == 0 || p->mask), "%s: bad mask", who);
     MICO_CHECK(p->drop_p >= 0.f && p->drop_p < 1.f, "%s: drop_p must be in [0, 1)", who);
     MICO_CHECK(p->kv_batch_mod >= 0, "%s: kv_batch_mod must be >= 0", who);
+    MICO_CHECK(p->batch0 >= 0, "%s: batch0 must be >= 0", who);
     return MICO_OK;
 }
 
@@ -2888,7 +2893,7 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     const dim3 block(256);
     // short query sequences at hd 64 (BERT's self- and cross-attention): the fused one-pass kernel
     static const bool no_smallq = getenv("MICO_ATTN_NOSMALLQ") != nullptr;   // A/B switch (tools/probes/drop_cost.py)
-    if (!no_smallq && p->hd == 64 && p->Sq <= SqCfg::QMAX && (p->drop_p <= 0.f || (unsigned long long)p->B * p->H * p->Sq * p->Sk <= 0xFFFFFFFFull)) {
+    if (!no_smallq && p->hd == 64 && p->Sq <= SqCfg::QMAX && (p->drop_p <= 0.f || (unsigned long long)(p->B + p->batch0) * p->H * p->Sq * p->Sk <= 0xFFFFFFFFull)) {
         const dim3 grid(p->H, p->B);
 #define SQ_LAUNCH(DROP, MASK) MICO_LAUNCH((attn_bwd_smallq_kernel<T, DROP, MASK>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, *p)
         DISPATCH_T16(dtype, {
@@ -2899,6 +2904,7 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
         MICO_LAUNCH_CHECK();
         return MICO_OK;
     }
+    MICO_CHECK(!p->dkv_accumulate, "mico_attn_bwd: dkv_accumulate is implemented by the short-query kernel only (Sq <= %d at hd 64)", SqCfg::QMAX);
     const dim3 gq((p->Sq + 63) / 64, p->H, p->B), gk((p->Sk + 63) / 64, p->H, p->B);
     static const bool no_res = getenv("MICO_ATTN_NORES") != nullptr;
     const bool res = !no_res && p->kv_batch_mod == 0 && p->mask_mode == 0 && p->drop_p <= 0.f && p->hd <= 96 && p->k_rs == p->v_rs && p->Sq > 128 && p->Sk <= 272 &&

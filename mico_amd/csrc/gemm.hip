@@ -2778,7 +2778,7 @@ static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-
 static int g_mico_mid_group = 0;       // sweeps: variant / 100 overrides the MID kernel's tile-order group height
 extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant + 100 * g_mico_mid_group; g_mico_gemm_variant = v % 100; g_mico_mid_group = v / 100; return old; }
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 107; }
+extern "C" int mico_version(void) { return 108; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {
@@ -2798,7 +2798,7 @@ extern "C" int mico_struct_layout(int* out, int n) {
         OFF(mico_attn_params, q_bs), OFF(mico_attn_params, q_rs), OFF(mico_attn_params, k_bs), OFF(mico_attn_params, k_rs), OFF(mico_attn_params, v_bs),
         OFF(mico_attn_params, v_rs), OFF(mico_attn_params, o_bs), OFF(mico_attn_params, o_rs), OFF(mico_attn_params, scale), OFF(mico_attn_params, mask),
         OFF(mico_attn_params, mask_mode), OFF(mico_attn_params, drop_p), OFF(mico_attn_params, drop_seed), OFF(mico_attn_params, drop_site),
-        OFF(mico_attn_params, kv_batch_mod),
+        OFF(mico_attn_params, kv_batch_mod), OFF(mico_attn_params, batch0), OFF(mico_attn_params, dkv_accumulate),
         -1,
     };
 #undef OFF

@@ -82,6 +82,68 @@ class GradArena:
     def result(self):
         return tuple(self.views)
 
+    # ---- one arena for all the autograd nodes of a backward pass that differentiate the same parameters --------------------------------------
+    # BERT runs three to four times per step (ITM per retrieval sub-task, CAP) on the same parameters.  With an arena per node autograd sums
+    # the nodes' gradients parameter by parameter (~900 add launches and 3 extra arena fills per step).  Inside ONE graph task the nodes
+    # therefore share one arena: every node accumulates straight into it (the kernels add anyway), and a parameter's view is handed to
+    # autograd by the FIRST node that touched it - later nodes return None for it (an undefined gradient is skipped by the engine, and the
+    # parameter's AccumulateGrad only runs once all the nodes that feed it have, i.e. after the last in-place accumulation).  Parameters no
+    # node touched keep grad None exactly as before.
+    _shared = {}
+
+    # The scheme needs the handed-out view to stay autograd's accumulator for the parameter until the last node has run: true as long as only
+    # these nodes feed it.  A parameter with OTHER consumers (BERT's word embeddings are the LM head's tied decoder weight) is `private`: every
+    # node gets a buffer of its own for it and autograd sums them as it always did (a second defined gradient makes the engine replace its
+    # accumulator by an out-of-place sum, after which in-place additions to the view would be lost).
+    @classmethod
+    def session(cls, params, groups=None, private=()):
+        gid = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
+        if gid < 0 or not runtime.CFG.share_grad_arena:
+            return _ArenaSession(cls(params, groups))
+        for k in [k for k in cls._shared if k[0] != gid]:    # arenas of finished backward passes
+            del cls._shared[k]
+        key = (gid, id(params[0]), len(params))
+        arena = cls._shared.get(key)
+        if arena is None:
+            arena = cls._shared[key] = cls(params, groups)
+            arena.handed = set()
+        return _ArenaSession(arena, private)
+
+
+class _ArenaSession:
+    """One autograd node's window on a (possibly shared) GradArena: same accessors; result() hands out the views of the parameters THIS node
+    touched and nobody handed out before."""
+
+    def __init__(self, arena, private=()):
+        self.arena, self.touched = arena, set()
+        self.flat = arena.flat
+        self.private, self.own = frozenset(private), {}
+
+    def get(self, i):
+        if i in self.private:
+            if i not in self.own:
+                self.own[i] = torch.zeros(self.arena.shapes[i], dtype=torch.float32, device=self.arena.flat.device)
+            return self.own[i]
+        self.touched.add(i)
+        return self.arena.get(i)
+
+    def fused(self, idxs, shape):
+        self.touched.update(idxs)
+        return self.arena.fused(idxs, shape)
+
+    def span(self, i0, i1):
+        self.touched.update(range(i0, i1))
+        return self.arena.span(i0, i1)
+
+    def result(self):
+        handed = getattr(self.arena, "handed", None)
+        if handed is None:
+            return self.arena.result()
+        out = tuple(self.own[i] if i in self.own else (self.arena.views[i] if (i in self.touched and i not in handed) else None)
+                    for i in range(len(self.arena.views)))
+        handed.update(self.touched)
+        return out
+
 
 def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None, dbias=None):
     """dw[N_out, N_in] += inv_s * dy16^T x16   (reduction over the rows);  dbias[N_out] += inv_s * column sums of dy16 in the same launch
@@ -1212,7 +1274,7 @@ class BertFn(torch.autograd.Function):
         Sg = runtime.grad_scale()
         inv_s = 1.0 / Sg
         scale = 1.0 / math.sqrt(hd)
-        grads = GradArena(params, spec.grad_groups)
+        grads = GradArena.session(params, spec.grad_groups, private=(spec.idx["embeddings.word_embeddings.weight"],))   # (tied to the LM head's decoder)
 
         def G(name):
             return grads.get(spec.idx[name])
@@ -1225,8 +1287,15 @@ class BertFn(torch.autograd.Function):
         shared, has_neg, kv_mod = ctx.kv_shared
         n_own = (b // 3 if has_neg else b) if shared else 0
         # gradients of the shared K/V memory, still in the 16-bit gradient scale (CrossKVFn.backward removes it)
-        dkv_own = _empty((spec.L, n_own * E, 2 * D), dt, dev) if shared else None
-        dkv_neg = _empty((spec.L, n_own * E, 2 * D), dt, dev) if has_neg else None
+        # (ITM triplet: [own | neg] adjacent per layer - batch entries 0 .. 2 n of the backward write their dK / dV rows straight into the pair, the
+        # third third accumulates onto the own half in a second launch: no per-entry buffer, no add / copy passes)
+        if has_neg:
+            dkv_pair = _empty((spec.L, 2 * n_own * E, 2 * D), dt, dev)
+            dkv_own, dkv_neg = dkv_pair[:, :n_own * E], dkv_pair[:, n_own * E:]
+        else:
+            dkv_pair = None
+            dkv_own = _empty((spec.L, n_own * E, 2 * D), dt, dev) if shared else None
+            dkv_neg = None
 
         def ln_bwd(gin, u, m_, r_, pre, site):
             """d(LN input) fp32 (in place into gin: the residual branch's gradient) and its scaled 16-bit copy for the dense
@@ -1258,17 +1327,30 @@ class BertFn(torch.autograd.Function):
                 dcc = _empty((rows, D), dt, dev)
                 ops.gemm(d16, _fused_w("w1", [P(p + "crossattention.output.dense.weight")]), dcc, tb=True, M=rows, N=D, K=D)
                 dq = _empty((rows, D), dt, dev)
-                dkv = dkv_own[li] if (shared and not has_neg) else _empty((b * E, 2 * D), dt, dev)
                 delta = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 kv = a["kv"]
-                ops.attn_bwd(a["q"], kv, kv[:, D:], a["cc"], dcc, a["lse_c"], dq, dkv, dkv[:, D:], delta, B=b, H=H, Sq=S, Sk=E,
-                             hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod, **stc)
+                if shared and has_neg and S <= ops.ATTN_SMALLQ_MAX and hd == 64:
+                    # two launches over the triplet: entries [0, 2 n) own exactly the [own | neg] K/V sets, entries [2 n, 3 n) read the own sets again
+                    # and ADD their dK / dV (mico_attn_params.batch0 keeps the dropout counters of the one-launch forward)
+                    dkv = dkv_pair[li]
+                    r2 = 2 * n_own * S
+                    ops.attn_bwd(a["q"][:r2], kv, kv[:, D:], a["cc"][:r2], dcc[:r2], a["lse_c"][:2 * n_own], dq[:r2], dkv, dkv[:, D:], delta,
+                                 B=2 * n_own, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), **stc)
+                    ops.attn_bwd(a["q"][r2:], kv, kv[:, D:], a["cc"][r2:], dcc[r2:], a["lse_c"][2 * n_own:], dq[r2:], dkv, dkv[:, D:], delta,
+                                 B=n_own, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), batch0=2 * n_own,
+                                 dkv_accumulate=True, **stc)
+                    split_done = True
+                else:
+                    split_done = False
+                    dkv = dkv_own[li] if (shared and not has_neg) else _empty((b * E, 2 * D), dt, dev)
+                    ops.attn_bwd(a["q"], kv, kv[:, D:], a["cc"], dcc, a["lse_c"], dq, dkv, dkv[:, D:], delta, B=b, H=H, Sq=S, Sk=E,
+                                 hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod, **stc)
                 linear_wgrad(dq, a["x16a"], G(ca + "query.weight"), inv_s)
                 ops.colsum(dq, G(ca + "query.bias"), scale=inv_s, accumulate=True)
                 if shared:   # dK/dV per batch entry -> per K/V set: the triplet's first and third thirds read the same (own) set
                     ne = n_own * E
-                    if has_neg:
+                    if has_neg and not split_done:
                         torch.add(dkv[:ne], dkv[2 * ne:], out=dkv_own[li])
                         dkv_neg[li].copy_(dkv[ne:2 * ne])
                 else:

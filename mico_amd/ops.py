@@ -245,9 +245,14 @@ def dropout_(x, drop):
     return x
 
 
-def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop=None, kv_batch_mod=0):
+ATTN_SMALLQ_MAX = 80   # query rows of the one-pass short-query backward (SqCfg::QMAX in csrc/attention.hip; hd 64 only)
+
+
+def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop=None, kv_batch_mod=0, batch0=0,
+                 dkv_accumulate=False):
     p = AttnParams()
     p.kv_batch_mod = int(kv_batch_mod)
+    p.batch0, p.dkv_accumulate = int(batch0), int(bool(dkv_accumulate))
     if drop is not None:
         p.drop_p, p.drop_seed, p.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2])
     p.B, p.H, p.Sq, p.Sk, p.hd = B, H, Sq, Sk, hd
@@ -276,9 +281,10 @@ def attn_fwd(q, k, v, o, lse, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, 
 
 
 def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, delta, *, B, H, Sq, Sk, hd, scale, mask=None, q_strides, k_strides,
-             v_strides, o_strides, drop=None, kv_batch_mod=0):
-    """kv_batch_mod > 0: k / v hold kv_batch_mod batch entries shared modulo (see mico_attn_params); dk / dv are [B, ...] as always."""
-    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop, kv_batch_mod)
+             v_strides, o_strides, drop=None, kv_batch_mod=0, batch0=0, dkv_accumulate=False):
+    """kv_batch_mod > 0: k / v hold kv_batch_mod batch entries shared modulo (see mico_attn_params); dk / dv are [B, ...] as always.
+    batch0: this launch covers entries batch0 .. batch0 + B of a larger batch (dropout counters); dkv_accumulate: dk / dv += (short-query kernel)."""
+    p = _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop, kv_batch_mod, batch0, dkv_accumulate)
     rc = _lib.lib().mico_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(dq), _p(dk), _p(dv), _p(delta),
                                   C.byref(p), dt_code(q.dtype), _st())
     check(rc, "mico_attn_bwd")

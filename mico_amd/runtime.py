@@ -37,6 +37,8 @@ class _Cfg:
     fp8 = False
     # training: project the cross-attention K/V of a step's condition tokens once (functional.CrossKVFn) instead of in every BERT pass
     share_cross_kv = True
+    # one gradient arena per backward pass for all the BERT passes of a step (functional.GradArena.session): no per-parameter sums by autograd
+    share_grad_arena = True
 
 
 CFG = _Cfg()

@@ -234,3 +234,55 @@ def test_drop_plan_transitions_and_grad_arena_groups():
     assert plain.offsets == [0, 32, 40, 72, 80, 112, 120]        # registration order (the towers' block spans rely on it)
     with pytest.raises(AssertionError):
         plain.fused([0, 2], (12, 4))
+
+
+def test_shared_grad_arena_sessions():
+    """functional.GradArena.session: several autograd nodes over the same parameters accumulate in ONE arena per backward pass; a view is handed
+    to autograd by the first node that touched the parameter; untouched parameters keep grad None; a parameter with another consumer is private
+    (per-node buffers, summed by autograd) - against plain autograd, with the sharing on and off, twice in a row (a new arena per pass)."""
+    import torch
+    from mico_amd import runtime
+    from mico_amd.functional import GradArena
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, use_b, *params):
+            w, bias, unused, tied = params
+            ctx.save_for_backward(x)
+            ctx.params, ctx.use_b = params, use_b
+            y = x @ w.detach() + tied.detach().sum()
+            return y + bias.detach() if use_b else y
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            grads = GradArena.session(ctx.params, private=(3,))
+            grads.get(0).add_(x.t() @ g)                 # kernels accumulate into the arena views
+            if ctx.use_b:
+                grads.get(1).add_(g.sum(0))
+            grads.get(3).add_(g.sum())
+            return (None, None) + grads.result()
+
+    torch.manual_seed(0)
+    xs = [torch.randn(5, 4) for _ in range(3)]
+    ref = None
+    for share in (False, True, True):
+        runtime.CFG.share_grad_arena = share
+        try:
+            w, bias, unused, tied = (torch.nn.Parameter(torch.randn(*s)) for s in ((4, 3), (3,), (2,), (6,)))
+            torch.manual_seed(1)
+            for p, v in zip((w, bias, unused, tied), (torch.randn(4, 3), torch.randn(3), torch.randn(2), torch.randn(6))):
+                p.data.copy_(v)
+            # the first node does not touch `bias`, the later ones do; `tied` has a consumer outside the nodes
+            loss = sum((Node.apply(x, i > 0, w, bias, unused, tied) ** 2).sum() for i, x in enumerate(xs)) + (tied * 3.0).sum()
+            loss.backward()
+            got = [None if p.grad is None else p.grad.clone() for p in (w, bias, unused, tied)]
+        finally:
+            runtime.CFG.share_grad_arena = True
+        assert got[2] is None                                # nobody touched it
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert (a is None) == (b is None) and (a is None or torch.allclose(a, b, rtol=1e-6, atol=1e-6))
+    assert len(GradArena._shared) <= 1

@@ -333,6 +333,51 @@ def test_attention_shared_kv(cuda, dtype, drop):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("drop", [None, (0.1, 77, 5)])
+def test_attention_triplet_backward_in_two_launches(cuda, dtype, drop):
+    """mico_attn_params.batch0 / dkv_accumulate: the ITM triplet [own | neg | own] (b = 3 n entries on 2 n K/V sets) differentiated in two
+    launches - entries [0, 2 n) write dK / dV of the [own | neg] sets, entries [2 n, 3 n) ADD theirs onto the own sets, dropout counters of
+    the one-launch forward - against one launch with per-entry dK / dV and the caller's add."""
+    from mico_amd import ops
+    torch.manual_seed(5)
+    n, H, Sq, Sk, hd = 3, 12, 41, 150, 64
+    B, D = 3 * n, H * hd
+    q = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    kv = torch.randn(2 * n, Sk, 2 * D, device=cuda).to(dtype)
+    do = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    st = dict(q_strides=(Sq * D, D), k_strides=(Sk * 2 * D, 2 * D), v_strides=(Sk * 2 * D, 2 * D), o_strides=(Sq * D, D))
+    kw = dict(H=H, Sq=Sq, Sk=Sk, hd=hd, scale=hd ** -0.5, drop=drop, **st)
+    k, v = kv[..., :D], kv[..., D:]
+    o = torch.empty(B, Sq, D, device=cuda, dtype=dtype)
+    lse = torch.empty(B, H, Sq, device=cuda)
+    ops.attn_fwd(q, k, v, o, lse, B=B, kv_batch_mod=2 * n, **kw)
+    delta = torch.empty(B, H, Sq, device=cuda)
+    # reference: one launch, dK / dV per entry
+    dq1 = torch.empty_like(q)
+    dkv1 = torch.empty(B, Sk, 2 * D, device=cuda, dtype=dtype)
+    ops.attn_bwd(q, k, v, o, do, lse, dq1, dkv1[..., :D], dkv1[..., D:], delta, B=B, kv_batch_mod=2 * n, **kw)
+    want = dkv1[:2 * n].float()
+    want[:n] += dkv1[2 * n:].float()
+    # two launches
+    dq2 = torch.full_like(q, float("nan"))
+    dkv2 = torch.full((2 * n, Sk, 2 * D), float("nan"), device=cuda, dtype=dtype)
+    ops.attn_bwd(q[:2 * n], k, v, o[:2 * n], do[:2 * n], lse[:2 * n], dq2[:2 * n], dkv2[..., :D], dkv2[..., D:], delta, B=2 * n, **kw)
+    ops.attn_bwd(q[2 * n:], k, v, o[2 * n:], do[2 * n:], lse[2 * n:], dq2[2 * n:], dkv2[..., :D], dkv2[..., D:], delta, B=n, batch0=2 * n,
+                 dkv_accumulate=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dq1, dq2)
+    assert torch.equal(dkv1[n:2 * n], dkv2[n:])                      # the negative sets: written once
+    err = (dkv2[:n].float() - want[:n]).abs().max() / want[:n].abs().max()
+    assert err < (4e-3 if dtype == torch.bfloat16 else 5e-4), err   # the own sets: one 16-bit rounding of the sum instead of two of the parts
+    # the tiled kernels refuse the accumulate mode instead of ignoring it
+    with pytest.raises(Exception):
+        big = torch.randn(1, 200, D, device=cuda).to(dtype)
+        ops.attn_bwd(big, big, big, big, big, torch.empty(1, H, 200, device=cuda), torch.empty_like(big), torch.empty_like(big), torch.empty_like(big),
+                     torch.empty(1, H, 200, device=cuda), B=1, H=H, Sq=200, Sk=200, hd=hd, scale=1.0, q_strides=(200 * D, D), k_strides=(200 * D, D),
+                     v_strides=(200 * D, D), o_strides=(200 * D, D), dkv_accumulate=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["vit_g", "vit_b", "bert_self2d", "bert_self3d", "bert_cross"])
 def test_attention(cuda, dtype, case):
     from mico_amd import ops
