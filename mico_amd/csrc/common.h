@@ -134,6 +134,45 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return fmaf(x * 0.39894228040143268f, e2, cdf);
 }
 
+// The same arithmetic, operation for operation, on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two elements per
+// instruction; the reciprocal, the exponential and the sign select stay per element): the GEMM epilogues' GELU and GELU / GELU' pair over
+// the four accumulator values a lane holds.  One definition for every kernel, so a value computed by the pair epilogue and by the GELU-only
+// epilogue is the same bit pattern (the activation diet recomputes what the forward produced).
+__device__ __forceinline__ void gelu_terms2(const f32x2 x, f32x2& cdf, f32x2& e2) {
+    const f32x2 z = x * 0.70710678118654752f;
+    const f32x2 az = {fabsf(z[0]), fabsf(z[1])};
+    const f32x2 den = __builtin_elementwise_fma(az, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
+    const f32x2 w = (az * az) * -1.4426950408889634f;
+    e2 = (f32x2){__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    const f32x2 y = poly * t * e2;
+    const f32x2 y2 = (f32x2){2.0f, 2.0f} - y;
+    const f32x2 ope = {z[0] >= 0.f ? y2[0] : y[0], z[1] >= 0.f ? y2[1] : y[1]};   // 1 + erf(z)
+    cdf = ope * 0.5f;
+}
+__device__ __forceinline__ f32x4 gelu4(const f32x4 x) {
+    f32x2 c0, c1, e0, e1;
+    gelu_terms2((f32x2){x[0], x[1]}, c0, e0);
+    gelu_terms2((f32x2){x[2], x[3]}, c1, e1);
+    const f32x2 g0 = (f32x2){x[0], x[1]} * c0, g1 = (f32x2){x[2], x[3]} * c1;
+    return (f32x4){g0[0], g0[1], g1[0], g1[1]};
+}
+// x -> gelu(x) (returned), deriv = gelu'(x) = cdf + x pdf
+__device__ __forceinline__ f32x4 gelu_pair4(const f32x4 x, f32x4& deriv) {
+    f32x2 c0, c1, e0, e1;
+    const f32x2 x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
+    gelu_terms2(x0, c0, e0);
+    gelu_terms2(x1, c1, e1);
+    const f32x2 d0 = __builtin_elementwise_fma(x0 * 0.39894228040143268f, e0, c0), d1 = __builtin_elementwise_fma(x1 * 0.39894228040143268f, e1, c1);
+    const f32x2 g0 = x0 * c0, g1 = x1 * c1;
+    deriv = (f32x4){d0[0], d0[1], d1[0], d1[1]};
+    return (f32x4){g0[0], g0[1], g1[0], g1[1]};
+}
+
 // wave64 reductions
 // ---- stateless dropout decision (documented at mico_dropout in include/mico_hip.h; oracle/mico_oracle.py restates it) ----
 __device__ __forceinline__ unsigned drop_hash(unsigned seed, int site, unsigned long long idx) {

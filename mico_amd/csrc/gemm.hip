@@ -451,18 +451,11 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
             for (int u = 0; u < 2; ++u) {
                 f32x4 a0 = v4[2 * u], a1 = v4[2 * u + 1];
                 if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) {   // gelu and gelu' share the erf and the Gaussian; v becomes gelu(v) here
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float e2;
-                        float x = a0[k];
-                        float cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
-                        a0[k] = fmaf(x * 0.39894228040143268f, e2, cdf);
-                        v4[2 * u][k] = x * cdf;
-                        x = a1[k];
-                        cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
-                        a1[k] = fmaf(x * 0.39894228040143268f, e2, cdf);
-                        v4[2 * u + 1][k] = x * cdf;
-                    }
+                    f32x4 d0, d1;
+                    v4[2 * u] = gelu_pair4(a0, d0);
+                    v4[2 * u + 1] = gelu_pair4(a1, d1);
+                    a0 = d0;
+                    a1 = d1;
                 }
                 const s16x4 lo = pack4<T>(a0[0], a0[1], a0[2], a0[3]);
                 const s16x4 hi = pack4<T>(a1[0], a1[1], a1[2], a1[3]);
@@ -481,7 +474,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         } else if constexpr (ACT == 0) {
             if (e.act == MICO_ACT_GELU) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { v4[v][0] = gelu_f(v4[v][0]); v4[v][1] = gelu_f(v4[v][1]); v4[v][2] = gelu_f(v4[v][2]); v4[v][3] = gelu_f(v4[v][3]); }
+                for (int v = 0; v < 4; ++v) v4[v] = gelu4(v4[v]);
             } else if (e.act == MICO_ACT_GELU_GRAD) {
                 const T* hp = (const T*)e.aux_in + m * e.ldaux + ncol0;
 #pragma unroll
@@ -1289,15 +1282,7 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
                 if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) {
                     f32x4 d[2];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float e2;
-                            const float x = v[u][h][k];
-                            const float cdf = 0.5f * one_plus_erf(x * 0.70710678118654752f, e2);
-                            d[h][k] = fmaf(x * 0.39894228040143268f, e2, cdf);
-                            v[u][h][k] = x * cdf;
-                        }
+                    for (int h = 0; h < 2; ++h) v[u][h] = gelu_pair4(v[u][h], d[h]);
                     const s16x4 lo = pack4<T>(d[0][0], d[0][1], d[0][2], d[0][3]), hi = pack4<T>(d[1][0], d[1][1], d[1][2], d[1][3]);
                     char* ap = abase + row * ldaux2 + gcol[u] * 2;
                     if (ok[u][1]) *(s16x8*)ap = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1306,6 +1291,9 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
                     const s16x8 a8 = aux[ps][u];
                     v[u][0] *= unpack4<T>((s16x4){a8[0], a8[1], a8[2], a8[3]});
                     v[u][1] *= unpack4<T>((s16x4){a8[4], a8[5], a8[6], a8[7]});
+                } else if constexpr (ACT == MICO_ACT_GELU) {   // GELU alone (fc1 of a forward that keeps no derivative: no grad / activation diet)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) v[u][h] = gelu4(v[u][h]);
                 }
                 const s16x4 lo = pack4<T>(v[u][0][0], v[u][0][1], v[u][0][2], v[u][0][3]), hi = pack4<T>(v[u][1][0], v[u][1][1], v[u][1][2], v[u][1][3]);
                 char* cp = cbase + row * ldc2 + gcol[u] * 2;
@@ -1571,7 +1559,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX) {
+    if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX || ACT == MICO_ACT_GELU) {
         // (256 rows of ldc / ldaux 16-bit elements fit 32-bit byte offsets: checked on the host - GemmArgs::fast16)
         if (MICO_P8_FAST16 && g.fast16) {
             p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
@@ -1906,7 +1894,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8mx_kernel(const Mx8Arg
     if (wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (zero-fill DMAs past the last tile: see gemm_p8_kernel)
     __syncthreads();
-    if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX) {
+    if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX || ACT == MICO_ACT_GELU) {
         if (MICO_P8_FAST16 && g.fast16) {
             p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
             return;
@@ -2684,6 +2672,8 @@ void launch_p8(int tb, const GemmArgs& g, hipStream_t st) {
     if (resid_epilogue(g) && !tb) { MICO_LAUNCH((gemm_p8_kernel<T, false, ACT_RESID>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_p8_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_MUL_AUX) { MICO_LAUNCH((gemm_p8_kernel<T, true, MICO_ACT_MUL_AUX>), grid, block, 0, st, g); return; }
+    // plain GELU with the straight-line 16-bit epilogue (the towers' fc1 when the forward keeps no derivative)
+    if (g.e.act == MICO_ACT_GELU && g.fast16 && !tb && !g.e.aux_out && !g.e.aux_in) { MICO_LAUNCH((gemm_p8_kernel<T, false, MICO_ACT_GELU>), grid, block, 0, st, g); return; }
     const bool lean = g.e.act == MICO_ACT_NONE && !g.e.aux_out && !g.e.aux_in && g.e.drop_p == 0.f && !g.e.pos && !g.e.remap_group;
     if (lean && !tb) MICO_LAUNCH((gemm_p8_kernel<T, false, ACT_LEAN>), grid, block, 0, st, g);
     else if (lean) MICO_LAUNCH((gemm_p8_kernel<T, true, ACT_LEAN>), grid, block, 0, st, g);

@@ -448,13 +448,17 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
                 _gemm_fwd(hlnb, Hp, [P(b + "mlp.w3.weight")], "w", x_out, bias=P(b + "mlp.w3.bias"), k_pad=npad, **epi)
                 a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
             else:
-                h = _empty((M2, Hd), dt, dev)
                 act = _empty((M2, Hd), dt, dev)
-                _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
+                if (save and diet == 0) or runtime.fp8_enabled() or not runtime.CFG.fc1_plain_gelu:   # (the 8-phase fp8 kernel has the pair epilogue only)
+                    h = _empty((M2, Hd), dt, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
+                    if diet == 0:
+                        a.update(h=h, act=act)
+                    del h
+                else:   # nobody will read GELU' (no backward, or the activation diet recomputes the pair): half the output bytes of the launch
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), act=ops.ACT_GELU)
                 _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), ln=False, **epi)
-                if diet == 0:
-                    a.update(h=h, act=act)
-                del h, act
+                del act
             a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=None if diet >= 2 else ln2,
                      ln2b=ln2b if diet == 1 else None)
             x = x_out

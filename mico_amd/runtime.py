@@ -39,6 +39,9 @@ class _Cfg:
     share_cross_kv = True
     # one gradient arena per backward pass for all the BERT passes of a step (functional.GradArena.session): no per-parameter sums by autograd
     share_grad_arena = True
+    # fc1 of a tower forward that keeps no GELU' (no backward, or the activation diet recomputes the pair) runs the GELU-only epilogue
+    # (half the output bytes); MICO_FC1_PAIR_ALWAYS=1: the pair epilogue everywhere (A/B runs)
+    fc1_plain_gelu = os.environ.get("MICO_FC1_PAIR_ALWAYS") is None
 
 
 CFG = _Cfg()

@@ -149,3 +149,24 @@ def test_split_k_slabs_equal_atomics(cuda, rows, n_out, n_in, split):
     finally:
         ops._splitk_scratch = old
     assert rel_err(dw, ref) < 2e-5 * math.sqrt(rows) and bool((guard == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_p8_plain_gelu_epilogue(cuda, dtype):
+    """fc1 of a forward that keeps no derivative (no grad / activation diet): GELU alone on the 8-phase kernel's straight-line 16-bit
+    epilogue (K % 64 == 0, no aux buffer), at a ragged row count and the towers' widths - against fp32, and equal to the value half of the
+    GELU-pair launch bit for bit (same accumulation order, same GELU arithmetic)."""
+    from mico_amd import ops
+    torch.manual_seed(8)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    M, N, K = 257 * 40 + 3, 6144, 1408
+    A = (0.5 * torch.randn(M, K, device=cuda)).to(dtype)
+    W = (0.05 * torch.randn(N, K, device=cuda)).to(dtype)
+    bias = torch.randn(N, device=cuda)
+    ref = F.gelu(A.float() @ W.float().t() + bias)
+    out = torch.full((M, N), float("nan"), device=cuda, dtype=dtype)
+    ops.gemm(A, W, out, bias=bias, act=ops.ACT_GELU)
+    assert rel_err(out, ref) < tol
+    pair_v, pair_d = torch.empty_like(out), torch.empty_like(out)
+    ops.gemm(A, W, pair_v, bias=bias, aux_out=pair_d, act=ops.ACT_GELU_SAVE_DERIV)
+    assert torch.equal(out, pair_v)
