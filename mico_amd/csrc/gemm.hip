@@ -1330,6 +1330,11 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
 #endif
 struct P8C {
     static constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512, HALF = 16384, TILE = 65536, LDS_BYTES = 2 * TILE;
+    // LDS-DMA instructions one wave issues per half-tile (16 bytes per lane): every hand-counted `s_waitcnt vmcnt(N)` of the 8-phase kernels
+    // is a multiple of it (+ the scale-word loads of the fp8 form) - the asm DMA is invisible to the compiler's counters, so a change of the
+    // stage size or the workgroup shape has to fail HERE, not as an LDS race
+    static constexpr int DMA_PER_HALF = HALF / (THREADS * 16);
+    static_assert(DMA_PER_HALF * THREADS * 16 == HALF && DMA_PER_HALF == 2, "the vmcnt immediates of gemm_p8_kernel / gemm_p8mx_kernel assume two DMA instructions per wave and half-tile");
 };
 
 template <typename T, bool TB, int ACT>
@@ -1492,7 +1497,8 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
         if (MICO_P8_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
-    constexpr int L = MICO_P8_L, VMW = 2 * (L - 1);
+    constexpr int L = MICO_P8_L, VMW = P8C::DMA_PER_HALF * (L - 1);   // L - 1 half-tiles stay in flight across every barrier
+    static_assert(L >= 3 && L <= 5, "lookahead of the half-tile stream");
     auto wait_bar = [&]() {   // end of a load section: this wave's share of the half-tile read in the NEXT phase has landed; rendezvous
         fence();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");
@@ -1518,7 +1524,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
     if (L >= 3) issue(1, W0{});
     if (L >= 4) issue(1, W1{});
     if (L >= 5) issue(1, W2{});
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (L - 1)) : "memory");   // stream positions 0, 1, 2 of tile 0 have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");   // stream positions 0, 1, 2 of tile 0 have landed
     __builtin_amdgcn_s_barrier();
     fence();
     if (MICO_P8_WALK == 0) { rdB(b0, 0, 0); rdA(a1, 0, 1); }
@@ -1863,15 +1869,15 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8mx_kernel(const Mx8Arg
         __builtin_amdgcn_s_barrier();
         fence();
     };
-    using N6 = std::integral_constant<int, 6>;
-    using N7 = std::integral_constant<int, 7>;
+    using N6 = std::integral_constant<int, 3 * P8C::DMA_PER_HALF>;       // three half-tiles in flight
+    using N7 = std::integral_constant<int, 3 * P8C::DMA_PER_HALF + 1>;   // ... and one scale-word load behind them
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
     // prologue: the scale words of tiles 0 and 1, half-tiles 0..5 of the stream; a0, b1 of tile 0
     issue_scales(0); issue_scales(1);
     issue(0, W0{}); issue(0, W1{}); issue(0, W2{}); issue(0, W3{}); issue(1, W0{}); issue(1, W1{});
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N6::value) : "memory");
     __builtin_amdgcn_s_barrier();
     fence();
     rdA(a0, sa0, 0, 0, 0);

@@ -8,9 +8,12 @@ operands are 16-bit (runtime.compute_dtype()).
 import math
 import os
 
+import logging
 import torch
 
 from . import ops, runtime
+
+_log = logging.getLogger("mico_amd")
 
 
 def _split_k(m_out, n_out, k_red):
@@ -290,21 +293,34 @@ class DropPlan:
         for c in self.counts:
             self.starts.append(self.starts[-1] + c)
         self.n_frames = n_frames
+        self._keep, self._dev, self._tr = keep, dev, None      # (the hand-over tables are built when the backward first asks for one)
+
+    def _build_transitions(self):
         # Backward hand-over between consecutive branches (j = 2 block + which is processed in DEScending order): the LayerNorm backward of
         # branch j produces the residual-stream gradient that branch j - 1's GEMMs read as a compact 16-bit operand over ITS kept frames.
         # For every j >= 1: where each kept frame of j sits in j - 1's compact list (-1: not kept there), and the frames only j - 1 keeps.
+        # Built lazily (no-grad forwards and the plan that only prices a chunked step never need them), vectorised over all branches, and
+        # shipped in ONE host -> device copy.
+        keep = self._keep
+        nb = keep.shape[0]
         pos = keep.long().cumsum(1) - 1
-        dsts, dfr, ddst, self.tr_dst_starts, self.tr_diff_starts = [], [], [], [0], [0]
-        for j in range(1, keep.shape[0]):
-            fx = keep[j].nonzero()[:, 0]
-            dsts.append(torch.where(keep[j - 1, fx], pos[j - 1, fx], torch.full_like(fx, -1)))
-            only = (keep[j - 1] & ~keep[j]).nonzero()[:, 0]
-            dfr.append(only)
-            ddst.append(pos[j - 1, only])
-            self.tr_dst_starts.append(self.tr_dst_starts[-1] + fx.numel())
-            self.tr_diff_starts.append(self.tr_diff_starts[-1] + only.numel())
-        cat = lambda xs: (torch.cat(xs) if xs else torch.zeros(0, dtype=torch.long)).to(torch.int32).to(dev)
-        self.tr_dst, self.tr_diff_frames, self.tr_diff_dst = cat(dsts), cat(dfr), cat(ddst)
+        cur, prev, ppos = keep[1:], keep[:-1], pos[:-1]
+        jj, fx = cur.nonzero(as_tuple=True)                                # kept frames of branch j = jj + 1, row-major
+        dst = torch.where(prev[jj, fx], ppos[jj, fx], torch.full_like(fx, -1))
+        oj, of = (prev & ~cur).nonzero(as_tuple=True)                      # frames only branch j - 1 keeps
+        n_dst, n_diff = cur.sum(1).tolist(), (prev & ~cur).sum(1).tolist()
+        self.tr_dst_starts, self.tr_diff_starts = [0], [0]
+        for a_, d_ in zip(n_dst, n_diff):
+            self.tr_dst_starts.append(self.tr_dst_starts[-1] + a_)
+            self.tr_diff_starts.append(self.tr_diff_starts[-1] + d_)
+        flat = torch.cat((dst, of, ppos[oj, of])).to(torch.int32)
+        if self._dev.type == "cuda":
+            flat = flat.pin_memory().to(self._dev, non_blocking=True)
+        else:
+            flat = flat.to(self._dev)
+        n1, n2 = dst.numel(), of.numel()
+        self.tr_dst, self.tr_diff_frames, self.tr_diff_dst = flat[:n1], flat[n1:n1 + n2], flat[n1 + n2:]
+        self._tr = nb
 
     def transition(self, block, which):
         """Hand-over from branch j = 2 block + which to branch j - 1 in the backward: (slot of each of j's kept frames in j - 1's compact
@@ -312,6 +328,8 @@ class DropPlan:
         j = block * 2 + which
         if j == 0:
             return None
+        if self._tr is None:
+            self._build_transitions()
         a0, a1 = self.tr_dst_starts[j - 1], self.tr_dst_starts[j]
         d0, d1 = self.tr_diff_starts[j - 1], self.tr_diff_starts[j]
         return self.tr_dst[a0:a1], self.tr_diff_frames[d0:d1], self.tr_diff_dst[d0:d1]
@@ -760,6 +778,8 @@ def tower_chunk_frames(spec, n_frames, device):
 
 
 class EvaTowerFn(torch.autograd.Function):
+    _logged_plan = None
+
     @staticmethod
     def forward(ctx, spec, groups, dp_scale, *params):
         runtime.remember_precision(ctx)
@@ -776,11 +796,35 @@ class EvaTowerFn(torch.autograd.Function):
             kept = plan.kept_fraction() if plan is not None else 1.0
             chunk, diet = tower_plan(spec, Bf, params[0].device, kept)
             runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet, kept_fraction=kept)
+            if (Bf, min(chunk, Bf), diet) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
+                EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet)
+                _log.info("tower plan: %d frames, %d per pass, activation diet %d (kept fraction %.3f)", Bf, min(chunk, Bf), diet, kept)
         ctx.spec, ctx.params, ctx.diet = spec, params, diet
         if chunk >= Bf:
-            out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad, diet=diet, plan=plan)
-            ctx.chunked = None
-            return out
+            try:
+                out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad, diet=diet, plan=plan)
+                ctx.chunked = None
+                return out
+            except torch.cuda.OutOfMemoryError:
+                # The plan is priced from a fitted headroom (tower_plan): another step shape (more condition tokens, other modality mixes) or a
+                # smaller device can under-estimate it.  The forward only wrote buffers of its own, so it is repeated ONCE on the next more
+                # conservative plan - the next diet level if there is one, else two chunks - instead of failing the step.
+                if not needs_grad:
+                    raise
+                ctx.saved = None
+                torch.cuda.empty_cache()
+                dietable = not spec.arch["swiglu"]
+                if dietable and diet < 2 and runtime.activation_diet_override() is None:
+                    diet += 1
+                else:
+                    chunk = -(-Bf // 2)
+                ctx.diet = diet
+                runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet, kept_fraction=kept, oom_retry=True)
+                _log.warning("tower pass ran out of memory: retrying with %d frames per pass, activation diet %d (rank-local decision)", min(chunk, Bf), diet)
+                if chunk >= Bf:
+                    out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad, diet=diet, plan=plan)
+                    ctx.chunked = None
+                    return out
         if plan is not None:      # the chunks draw their own plans from their slices of dp_scale: this one only priced the step
             DropPlan.stats[0] -= sum(plan.counts)
             DropPlan.stats[1] -= len(plan.counts) * Bf

@@ -56,6 +56,7 @@ def pad8(n):
 
 
 _SPLITK_WS = {}
+SPLITK_WS_STREAMS = 4   # scratch buffers kept: the most recently used (device, stream) pairs
 SPLITK_SLABS = True   # False: weight-gradient launches get no scratch and fall back to fp32 atomics (kept tested: the C-ABI makes the scratch optional)
 SPLITK_WS_CAP = 320 << 20   # bytes: room for 8+ slabs of the towers' largest layer gradient (6144 x 1408 fp32 = 35 MB); a smaller scratch only
                             # bounds the split count (the library falls back to fewer splits / atomics cleanly)
@@ -66,11 +67,18 @@ def _splitk_scratch(nbytes, device):
     tiles into it and the reduction pass reads them back: launches on ONE stream use it one after the other; launches on different
     streams (or from threads with different current streams) must not share it - hence the stream in the key."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    t = _SPLITK_WS.get(key)
+    t = _SPLITK_WS.pop(key, None)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _SPLITK_WS[key] = t
+    _SPLITK_WS[key] = t                          # (re-inserted last: the dict is the LRU order)
+    while len(_SPLITK_WS) > SPLITK_WS_STREAMS:   # streams created per step would otherwise each pin up to SPLITK_WS_CAP bytes for ever
+        _SPLITK_WS.pop(next(iter(_SPLITK_WS)))
     return t
+
+
+def release_scratch():
+    """Drop the cached split-K scratch buffers (runtime.reset())."""
+    _SPLITK_WS.clear()
 
 
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,

@@ -321,7 +321,16 @@ def set_tower_chunk(frames):
 
 
 _activation_diet = None
-last_tower_plan = None      # dict(frames, frames_per_pass, diet, kept_fraction, ...) of the most recent training-mode tower forward
+last_tower_plan = None      # dict(frames=, frames_per_pass=, diet=, kept_fraction=[, oom_retry=]) of the most recent training-mode tower forward
+
+
+def reset():
+    """Release what the engine caches between steps outside the parameters: split-K scratch buffers, 16-bit / fp8 weight copies, shared
+    gradient arenas of finished backward passes."""
+    ops.release_scratch()
+    clear_weight_cache()
+    from . import functional
+    functional.GradArena._shared.clear()
 
 
 def activation_diet_override():

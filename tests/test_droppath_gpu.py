@@ -186,3 +186,50 @@ def test_activation_diet_recompute(cuda):
         assert (chunk, diet) == (896, 2), (chunk, diet)
         proj = torch.cuda.memory_allocated(cuda) + (12 << 30) + 896 * (52 << 20) + 896 * 0.82 * 40 * 257 * 16 * 1408
         assert proj < 0.82 * torch.cuda.mem_get_info(cuda)[1]
+
+
+def test_tower_forward_oom_retry(cuda, monkeypatch):
+    """An out-of-memory error in the single-pass tower forward (the plan's fitted headroom under-estimated the step) is answered ONCE by the
+    next more conservative plan - the next activation-diet level, or two chunks when the diet is exhausted - instead of failing the step:
+    same output, same gradients, the decision recorded in runtime.last_tower_plan."""
+    from mico_amd import runtime as rt
+    from mico_amd import functional as Fn
+    depth = 2
+    m, sd = build_model("evaclip01_giant", depth, device=cuda)
+    vis = m.vision_encoder.visual
+    g = torch.Generator().manual_seed(12)
+    img = torch.randn(4, 3, 224, 224, generator=g).to(cuda)
+    w = (torch.randn(4, 257, 1408, generator=g) / (4 * 257 * 1408) ** 0.5).to(cuda)
+    dps = _masks(depth, 4, 0.7, 29)
+
+    def run():
+        with rt.precision(torch.float16):
+            m.zero_grad(set_to_none=True)
+            out = vis.forward_groups([img], drop_path_scale=dps)
+            (out * w).sum().backward()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in vis.named_parameters() if p.grad is not None}
+
+    o0, g0 = run()
+    assert rt.last_tower_plan["diet"] == 0 and "oom_retry" not in rt.last_tower_plan
+    real = Fn._tower_forward
+    for forced_diet, want in ((None, dict(diet=1, frames_per_pass=4)), (2, dict(diet=2, frames_per_pass=2))):
+        fails = [1]
+
+        def flaky(*a, **k):
+            if fails[0]:
+                fails[0] -= 1
+                raise torch.cuda.OutOfMemoryError("injected")
+            return real(*a, **k)
+
+        monkeypatch.setattr(Fn, "_tower_forward", flaky)
+        rt.set_activation_diet(forced_diet)
+        try:
+            o1, g1 = run()
+        finally:
+            rt.set_activation_diet(None)
+            monkeypatch.setattr(Fn, "_tower_forward", real)
+        plan = rt.last_tower_plan
+        assert plan.get("oom_retry") and all(plan[k] == v for k, v in want.items()), plan
+        assert rel_err(o1, o0) < 1e-6       # (chunks draw per-chunk plans from the same masks: the same frames are kept)
+        for n in g0:
+            assert rel_err(g1[n], g0[n]) < 2e-3, (n, rel_err(g1[n], g0[n]))

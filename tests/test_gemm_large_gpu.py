@@ -170,3 +170,54 @@ def test_p8_plain_gelu_epilogue(cuda, dtype):
     pair_v, pair_d = torch.empty_like(out), torch.empty_like(out)
     ops.gemm(A, W, pair_v, bias=bias, aux_out=pair_d, act=ops.ACT_GELU_SAVE_DERIV)
     assert torch.equal(out, pair_v)
+
+
+def test_builtin_dma_build_agrees(cuda):
+    """the default library issues the GEMM kernels' LDS-DMA by inline assembly, which hipcc's wait counters cannot see - every
+    `s_waitcnt vmcnt(N)` in front of a barrier is hand-counted.  `make -C mico_amd/csrc noasm` builds the same kernels with the compiler's
+    builtin (its own, conservative waits): both libraries must produce bit-identical results on the orientations / epilogues the towers
+    launch - a miscounted wait shows up as a difference (an LDS race), not as a crash.  Child processes: one library per process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "tools", "probes", "bin", "libmico_noasm.so")
+    if not os.path.exists(alt):
+        pytest.skip("tools/probes/bin/libmico_noasm.so not built (make -C mico_amd/csrc noasm)")
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from mico_amd import ops
+dev = torch.device('cuda:0')
+outs = []
+for dtype in (torch.float16, torch.bfloat16):
+    g = torch.Generator(device='cuda').manual_seed(3)
+    M, D, Hd = 257 * 40 + 5, 1408, 6144
+    x = torch.randn(M, D, device=dev, generator=g).to(dtype)
+    w1 = (0.05 * torch.randn(Hd, D, device=dev, generator=g)).to(dtype)
+    w2 = (0.05 * torch.randn(D, Hd, device=dev, generator=g)).to(dtype)
+    a, h = torch.empty(M, Hd, device=dev, dtype=dtype), torch.empty(M, Hd, device=dev, dtype=dtype)
+    ops.gemm(x, w1, a, aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)                      # forward, GELU pair
+    y = torch.empty(M, D, device=dev, dtype=dtype)
+    ops.gemm(a, w2, y)                                                            # forward, K = 6144
+    dh = torch.empty(M, Hd, device=dev, dtype=dtype)
+    ops.gemm(y, w2, dh, tb=True, M=M, N=Hd, K=D, aux_in=h, act=ops.ACT_MUL_AUX)     # dX with the stored derivative
+    dw = torch.zeros(Hd, D, device=dev)
+    ops.gemm(dh, x, dw, ta=True, tb=True, M=Hd, N=D, K=M, accumulate=True, split_k=0)   # weight gradient (slabs: deterministic)
+    outs += [a.float().cpu(), h.float().cpu(), y.float().cpu(), dh.float().cpu(), dw.cpu()]
+torch.save(outs, sys.argv[1])
+""" % root
+    res = []
+    torch.cuda.empty_cache()
+    with tempfile.TemporaryDirectory() as td:
+        for lib in (None, alt):
+            env = dict(os.environ)
+            env.pop("MICO_HIP_LIB", None)
+            if lib:
+                env["MICO_HIP_LIB"] = lib
+            f = os.path.join(td, "o_%d.pt" % len(res))
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=env)
+            res.append(torch.load(f))
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), i
