@@ -333,6 +333,43 @@ def test_attention_shared_kv(cuda, dtype, drop):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Sq,Sk,hd,B,H", [(257, 257, 88, 40, 16), (200, 257, 72, 3, 5), (257, 256, 96, 2, 3), (130, 200, 88, 3, 4), (260, 129, 80, 2, 2),
+                                          (257, 257, 88, 1, 1)])
+def test_attention_onepass_backward_shapes(cuda, dtype, Sq, Sk, hd, B, H):
+    """attn_bwd_onepass_kernel beyond the towers' own shape: more items than CUs x 2 and fewer than CUs (persistent loop, XCD-contiguous and strided
+    item orders), Sq != Sk (chunks from Sq, key steps / the rank-one key from Sk), every key mode (257 / 256 / < 256 with ragged and dead key
+    blocks), head dims 72 .. 96 - dQ, dK, dV row by row against fp32 autograd, NaN-prefilled outputs (every row must be written)."""
+    from mico_amd import ops
+    torch.manual_seed(Sq * 7 + Sk)
+    D = H * hd
+    q = (0.8 * torch.randn(B, Sq, D, device=cuda)).to(dtype)
+    kv = (0.8 * torch.randn(B, Sk, 2 * D, device=cuda)).to(dtype)
+    k, v = kv[..., :D], kv[..., D:]
+    scale = hd ** -0.5
+    st = dict(q_strides=(Sq * D, D), k_strides=(Sk * 2 * D, 2 * D), v_strides=(Sk * 2 * D, 2 * D), o_strides=(Sq * D, D))
+    kw = dict(B=B, H=H, Sq=Sq, Sk=Sk, hd=hd, scale=scale, **st)
+    o = torch.empty(B, Sq, D, device=cuda, dtype=dtype)
+    lse = torch.empty(B, H, Sq, device=cuda)
+    ops.attn_fwd(q, k, v, o, lse, **kw)
+    do = torch.randn(B, Sq, D, device=cuda).to(dtype)
+    dq = torch.full_like(q, float("nan"))
+    dkv = torch.full_like(kv, float("nan"))
+    delta = torch.empty(B, H, Sq, device=cuda)
+    ops.attn_bwd(q, k, v, o, do, lse, dq, dkv[..., :D], dkv[..., D:], delta, **kw)
+    torch.cuda.synchronize()
+    n = min(B, 4)      # (the reference on a few batch entries: first, last and two in between)
+    sel = sorted(set([0, B - 1] + [B // 3, (2 * B) // 3][: max(0, n - 2)]))
+    qr, kr, vr = (t[sel].float().reshape(len(sel), -1, H, hd).detach().requires_grad_(True) for t in (q, k, v))
+    ref = torch.einsum("bhij,bjhd->bihd", (torch.einsum("bihd,bjhd->bhij", qr, kr) * scale).softmax(-1), vr)
+    ref.backward(do[sel].float().reshape(len(sel), Sq, H, hd))
+    assert torch.isfinite(dq).all() and torch.isfinite(dkv).all()
+    for name, got, want in (("dq", dq[sel], qr.grad.reshape(len(sel), Sq, D)), ("dk", dkv[sel][..., :D], kr.grad.reshape(len(sel), Sk, D)),
+                            ("dv", dkv[sel][..., D:], vr.grad.reshape(len(sel), Sk, D))):
+        err = (got.float() - want).norm(dim=-1) / (want.norm(dim=-1) + 1e-3 * want.norm(dim=-1).mean())
+        assert err.max() < tol(dtype, 8), (name, err.max(), err.argmax())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("drop", [None, (0.1, 77, 5)])
 def test_attention_triplet_backward_in_two_launches(cuda, dtype, drop):
     """mico_attn_params.batch0 / dkv_accumulate: the ITM triplet [own | neg | own] (b = 3 n entries on 2 n K/V sets) differentiated in two
