@@ -2911,12 +2911,16 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
                      p->Sq <= 256 + ResCfg<96>::NXMAX;
     // the towers' self-attention (g/14: 257 tokens, hd 88): one pass, scores computed once (MICO_ATTN_NOONEPASS=1: the two resident kernels, for A/B runs)
     static const bool no_onepass = getenv("MICO_ATTN_NOONEPASS") != nullptr;
-    if (res && !no_onepass && p->hd > 64 && p->Sk <= 257) {
+    if (res && !no_onepass && p->Sk <= 257) {
         static const int n_cu1 = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const int nitems = p->B * p->H;
         const dim3 grid(nitems < n_cu1 ? nitems : n_cu1);
-#define OP_LAUNCH(KMODE) MICO_LAUNCH((attn_bwd_onepass_kernel<T, 96, KMODE>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, *p)
-        DISPATCH_T16(dtype, { if (p->Sk == 257) OP_LAUNCH(2); else if (p->Sk == 256) OP_LAUNCH(1); else OP_LAUNCH(0); });
+#define OP_LAUNCH(HDP, KMODE) MICO_LAUNCH((attn_bwd_onepass_kernel<T, HDP, KMODE>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, *p)
+        // (hd <= 64: the EVA02 towers - L/14 at 257 tokens, B/16 at 197; the dQ waves of head-dim tiles 4 and 5 idle there)
+        DISPATCH_T16(dtype, {
+            if (p->hd <= 64) { if (p->Sk == 257) OP_LAUNCH(64, 2); else if (p->Sk == 256) OP_LAUNCH(64, 1); else OP_LAUNCH(64, 0); }
+            else { if (p->Sk == 257) OP_LAUNCH(96, 2); else if (p->Sk == 256) OP_LAUNCH(96, 1); else OP_LAUNCH(96, 0); }
+        });
 #undef OP_LAUNCH
         MICO_LAUNCH_CHECK();
         return MICO_OK;

@@ -334,7 +334,7 @@ def test_attention_shared_kv(cuda, dtype, drop):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Sq,Sk,hd,B,H", [(257, 257, 88, 40, 16), (200, 257, 72, 3, 5), (257, 256, 96, 2, 3), (130, 200, 88, 3, 4), (260, 129, 80, 2, 2),
-                                          (257, 257, 88, 1, 1)])
+                                          (257, 257, 88, 1, 1), (257, 257, 64, 5, 16), (197, 197, 64, 20, 12), (256, 256, 48, 2, 3)])
 def test_attention_onepass_backward_shapes(cuda, dtype, Sq, Sk, hd, B, H):
     """attn_bwd_onepass_kernel beyond the towers' own shape: more items than CUs x 2 and fewer than CUs (persistent loop, XCD-contiguous and strided
     item orders), Sq != Sk (chunks from Sq, key steps / the rank-one key from Sk), every key mode (257 / 256 / < 256 with ragged and dead key

@@ -51,5 +51,7 @@ if __name__ == "__main__":
     run("vit_g", 320, 16, 257, 257, 88, True)
     run("vit_g_256", 320, 16, 256, 256, 88, True)     # what the 257th token (ragged fifth tile in both directions) costs
     run("vit_g_272", 320, 16, 272, 272, 88, True)
+    run("vit_l14", 128, 16, 257, 257, 64, True)       # the EVA02 towers (hd 64): L/14 ...
+    run("vit_b16", 256, 12, 197, 197, 64, True)       # ... and B/16 (197 tokens: ragged / dead key blocks in the one-pass backward)
     run("bert_cross", 192, 12, 77, 1285, 64, False)
     run("bert_self", 192, 12, 77, 77, 64, True)
