@@ -123,6 +123,7 @@ struct GemmArgs {
     int group_m;                // MID kernel: row-tiles per group of the tile order
     int fast16;                 // P8: the launch qualifies for p8_epilogue_fast16 (16-bit C, no row scale / map / residual / accumulate)
     int tm0;                    // first row tile of this launch (a problem split into a P8 launch over full rounds + a MID launch over the rest)
+    int a_wrap;                 // P8: K-tiles after which the A stream starts over (x W_hi + x W_lo as ONE product over the weights' [hi | lo] rows); 0: never
     int64_t ka_rows, kb_rows;   // physical reduction extents of A / B (differ from K in k-segment mode)
     mico_gemm_epilogue e;
 };
@@ -1428,7 +1429,10 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
         constexpr bool isA = MICO_P8_WALK ? (W == 0 || W == 3) : (W == 1 || W == 2);
         constexpr int half = (W == 1 || W == 3) ? 1 : 0;
         const bool valid = t < T_;
-        const unsigned soff = isA ? (unsigned)(t * BK * 2) : (TB ? (unsigned)((int64_t)t * BK * ldb_b) : (unsigned)(t * BK * 2));   // (k-segment launches stay on the 32-deep kernel)
+        // (k-segment launches stay on the 32-deep kernels, except the one pattern that is a plain product here: the SAME activation against
+        // the weight's hi and lo halves, adjacent along K - the A stream simply starts over after a_wrap K-tiles)
+        const int ta_ = (!TB && g.a_wrap > 0 && t >= g.a_wrap) ? t - g.a_wrap : t;
+        const unsigned soff = isA ? (unsigned)(ta_ * BK * 2) : (TB ? (unsigned)((int64_t)t * BK * ldb_b) : (unsigned)(t * BK * 2));
         LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ld_dst;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -2833,6 +2837,7 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.c_dtype = c_dtype;
     g.tm0 = 0;
+    g.a_wrap = 0;
     g.fast16 = 0;
     if (epi) g.e = *epi;
     else { g.e = mico_gemm_epilogue{}; g.e.alpha = 1.f; }
@@ -2856,6 +2861,7 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
     const bool p8mx = g_mico_gemm_variant != 16 && g.lda * 256 + K < 0x7FFFFF00ll && g.ldb * 256 + K < 0x7FFFFF00ll &&
                       (lean || g.e.act == MICO_ACT_GELU_SAVE_DERIV || g.e.act == MICO_ACT_MUL_AUX);
     g.tm0 = 0;
+    g.a_wrap = 0;
     g.fast16 = p8mx && c_dtype != MICO_F32 && !g.e.row_scale && !g.e.row_map && !g.e.resid && !g.e.accumulate && 256 * ldc * 2 < 0x7FFFFFFFll &&
                (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true);
 #define MX8(ACTV) do { if (p8mx) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_p8mx_kernel<T, ACTV>), grid, block, 0, st, a)); \
@@ -2891,6 +2897,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.c_dtype = c_dtype;
     g.tm0 = 0;
+    g.a_wrap = 0;
     g.fast16 = 0;
     if (epi) g.e = *epi;
     else {
@@ -2942,7 +2949,12 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
                              (g.e.act == MICO_ACT_GELU_SAVE_DERIV || (g.e.resid != nullptr && c_dtype == MICO_F32 && K <= 2048));
     // the 8-phase 256x256x64 kernel: forward / dX orientation, no split, K % 64 == 0 (variant 10: every such problem, 11: those the
     // 256x128 kernel does not take by default, 12: off)
-    const bool p8_ok = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && g.e.nseg == 0 &&
+    // x W_hi + x W_lo (the head-split blocks' weights-split forward: two k-segments, the activation repeated, the weight halves adjacent) is
+    // one product of K = 2 kseg for the 8-phase kernel whose A stream wraps (GemmArgs::a_wrap); MICO_P8_NOWRAP=1: the 32-deep k-segment kernels
+    static const bool no_wrap = getenv("MICO_P8_NOWRAP") != nullptr;
+    const bool wrap_ok = !no_wrap && g.e.nseg == 2 && !ta && !tb && g.e.kseg % 64 == 0 && g.e.a_seg_off[0] == 0 && g.e.a_seg_off[1] == 0 &&
+                         g.e.b_seg_off[0] == 0 && g.e.b_seg_off[1] == g.e.kseg;
+    const bool p8_ok = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || wrap_ok) &&
                        256 * lda * 2 + K * 2 < 0x7FFFFF00ll && (tb ? (K + 64) * ldb * 2 : 256 * ldb * 2 + K * 2) < 0x7FFFFF00ll;
     const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || g_mico_gemm_variant == 13 || g_mico_gemm_variant == 14 || g_mico_gemm_variant == 15 || (g_mico_gemm_variant == 11 && !mid_default) ||
                               (g_mico_gemm_variant == 0 && MICO_P8_DEFAULT));
@@ -3026,6 +3038,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (p8) {
         g_mico_last_gemm_kernel = 8;
+        g.a_wrap = wrap_ok ? g.e.kseg / 64 : 0;
         g.fast16 = c_dtype != MICO_F32 && !g.e.row_scale && !g.e.row_map && !g.e.resid && !g.e.accumulate && !g.e.pos && !g.e.remap_group && g.e.drop_p == 0.f &&
                    (g.e.act == MICO_ACT_NONE ? (!g.e.aux_out && !g.e.aux_in) : true) && 256 * ldc * 2 < 0x7FFFFFFFll &&
                    (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true) && g_mico_gemm_variant != 15;
