@@ -2937,7 +2937,9 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     const bool w4 = w4_built && big && g_mico_gemm_variant >= 2 && (ta || K % 64 == 0) && (tb || K % 64 == 0) && a_ext < 0x7FFFFF00ll && b_ext < 0x7FFFFF00ll;
     if (w4) pc = false;
     // the 256x128 two-workgroups-per-CU kernel: forward / dX orientation, no split (variant 5: every such problem, 6: K <= 2048 only, 7: off)
-    const bool no_split = !(c_dtype == MICO_F32 && g.e.accumulate) && split_k <= 1;
+    // (an fp32-accumulate launch with an explicit split_k = 1 - the condition-token gradients summed over BERT's layers - is one pass too: its
+    // epilogue adds to C; only the automatic choice (split_k <= 0) of an accumulating launch may split)
+    const bool no_split = split_k == 1 || (split_k <= 0 && !(c_dtype == MICO_F32 && g.e.accumulate));
     const bool mid = big && !pc && !w4 && !ta && no_split &&
                      (g_mico_gemm_variant == 5 || (g_mico_gemm_variant == 6 && K <= 2048));
     // the 64-deep unit-ring form of it (variant 8: every such problem, 9: K <= 2048 only)

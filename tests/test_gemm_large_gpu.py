@@ -221,3 +221,19 @@ torch.save(outs, sys.argv[1])
             res.append(torch.load(f))
     for i, (a, b) in enumerate(zip(*res)):
         assert torch.isfinite(a).all() and torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_large_dx_fp32_accumulate_one_pass(cuda, dtype):
+    """dcond += alpha * dkv W (the condition-token gradient summed over BERT's layers: fp32 C, accumulate, explicit split_k = 1, reduction-major
+    B) takes the 8-phase kernel like every other large dX launch."""
+    from mico_amd import ops, _lib
+    torch.manual_seed(9)
+    M, N, K = 64 * 1285 + 3, 768, 1536
+    dy = (0.1 * torch.randn(M, K, device=cuda)).to(dtype)
+    w = (0.05 * torch.randn(K, N, device=cuda)).to(dtype)
+    c = torch.randn(M, N, device=cuda)
+    ref = c.double() + 0.5 * (dy.double() @ w.double())
+    ops.gemm(dy, w, c, tb=True, M=M, N=N, K=K, alpha=0.5, accumulate=True)
+    assert _lib.lib().mico_gemm_last_kernel() == 8
+    assert rel_err(c, ref) < 1e-5 * math.sqrt(K) + 1e-6
