@@ -2284,10 +2284,12 @@ template <int HDP> struct OpCfg {
 // an opaque copy of a lane-dependent value: address arithmetic derived from it is redone where it is used instead of being hoisted out of
 // the item / chunk loops into registers that live (spilled) through them
 __device__ __forceinline__ int launder(int x) { asm volatile("" : "+v"(x)); return x; }
-// byte offset of (key row kl of the step, query tile qt) in a dS step image: the two 32-byte halves of a 64-byte row swap with bit 2 of the
-// row, so that the 8-byte writes of a score tile (16 rows x 32 bytes) and the transposing reads (4 rows x 32 bytes per lane group) both
-// spread over all banks
-__device__ __forceinline__ int ds_off(int kl, int qt) { return kl * 64 + ((qt ^ ((kl >> 2) & 1)) << 5); }
+// byte offset of the 8-byte piece `pc` (4 queries) of (key row kl of the step, query tile qt) in a dS step image: 64-byte rows of four 16-byte
+// granules, the granule index XOR-ed with bits 2..3 of the row.  Rows r, r + 4, r + 8, r + 12 start in the same banks (64-byte stride), so both
+// access patterns - the score tile's 8-byte writes (16 rows x 32 bytes per lane-group pair) and the transposing reads (4 rows x 32 bytes per lane
+// group, four groups with different bits 2..3) - spread over all 64 banks (with a one-bit swap of the row halves SQ_LDS_BANK_CONFLICT was 0.16
+// per LDS cycle: rows r and r + 8 collided)
+__device__ __forceinline__ int ds_off(int kl, int qt, int pc) { return kl * 64 + ((((qt << 1) | (pc >> 1)) ^ ((kl >> 2) & 3)) << 4) + (pc & 1) * 8; }
 
 // KMODE 2: Sk == 257 (the towers), 1: Sk == 256, 0: Sk < 256 (ragged / dead key blocks: masks and run-time loops, no 17th block)
 template <typename T, int HDP, int KMODE>
@@ -2492,7 +2494,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
                 probs(s[rb], dp[rb], lv, dl4);
                 if (!FULL && kb0 + l15 >= p.Sk) { s[rb] = zero4; dp[rb] = zero4; }
                 const s16x4 p4 = pack4<T>(s[rb][0], s[rb][1], s[rb][2], s[rb][3]), d4 = pack4<T>(dp[rb][0], dp[rb][1], dp[rb][2], dp[rb][3]);
-                if (rb == 0 ? live0 : live1) *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt) + g * 8) = d4;
+                if (rb == 0 ? live0 : live1) *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt, g)) = d4;
                 if (qt == 0) { plo[rb] = p4; dlo[rb] = d4; }
                 else {
                     pf[rb] = (s16x8){plo[rb][0], plo[rb][1], plo[rb][2], plo[rb][3], p4[0], p4[1], p4[2], p4[3]};
@@ -2578,7 +2580,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
                     probs(sc[qt][rb], dp[qt][rb], lv[qt], dl4[qt]);
                     p4[qt][rb] = pack4<T>(sc[qt][rb][0], sc[qt][rb][1], sc[qt][rb][2], sc[qt][rb][3]);
                     d4[qt][rb] = pack4<T>(dp[qt][rb][0], dp[qt][rb][1], dp[qt][rb][2], dp[qt][rb][3]);
-                    *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt) + g * 8) = d4[qt][rb];
+                    *(LDS_AS s16x4*)(dsi + ds_off(rb * 16 + l15, qt, g)) = d4[qt][rb];
                 }
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
@@ -2612,7 +2614,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
         LDS_AS const char* dsi = dsb + dsbuf * O::DSB;
         const int rlo = g * 4 + (l15 >> 2);
         const int koff = rlo * C::RS + (((td * 2 + ((l15 >> 1) & 1)) ^ ((rlo & 7) << 1)) << 4) + (l15 & 1) * 8;   // rows rlo + 16 n share the key
-        const int doff0 = ds_off(rlo, BOTH ? 0 : qsel) + (l15 & 3) * 8, doff1 = ds_off(rlo, 1) + (l15 & 3) * 8;
+        const int doff0 = ds_off(rlo, BOTH ? 0 : qsel, l15 & 3), doff1 = ds_off(rlo, 1, l15 & 3);
         f32x4 acc0 = zero4, acc1 = zero4;
         const int d = td * 16 + g * 4;
         // key 256's operands first: they are needed last and have the whole loop to arrive
