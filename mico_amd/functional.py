@@ -348,6 +348,93 @@ class DropPlan:
 _TAIL_EXP = None   # experiment hook (tools/precision_probe.py --tail)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# The POST-norm block of EVA02-CLIP-bigE-14-plus (mico.py:341-344; eva_vit_model.py:411-413):
+#     x = x + drop_path(norm1(attn(x)));  x = x + drop_path(norm2(mlp(x)))
+# Off the ViT-g hot path - built from the hot path's kernels without its frame compaction, activation diet and
+# gradient hand-over: the branch input is a 16-bit cast of the fp32 stream, the branch output stays fp32 for its LayerNorm, every branch is
+# evaluated and scaled per frame (the reference's own drop_path schedule).
+# ----------------------------------------------------------------------------------------------------------------------
+def _postnorm_block_forward(spec, P, b, x, Bf, dps, a, dt, dev, strides3):
+    D, N, H, hd, Hd = spec.D, spec.N, spec.H, spec.hd, spec.hidden
+    M = Bf * N
+
+    def branch_out(br, pre, sc):
+        y = _empty((M, D), torch.float32, dev)
+        mean, rstd = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+        ops.layernorm_fwd(br, P(b + pre + ".weight"), P(b + pre + ".bias"), spec.eps, out32=y, mean=mean, rstd=rstd, dtype=dt)
+        if sc is not None:
+            y = y.view(Bf, N, D) * sc.view(Bf, 1, 1)
+        return x + y.view(M, D), mean, rstd
+
+    # attention branch
+    x16a = _empty((M, D), dt, dev)
+    ops.cast_f32_to_16(x, x16a)
+    qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
+    qkv = _empty((M, 3 * D), dt, dev)
+    _gemm_fwd(x16a, D, [P(b + "attn.qkv.weight")], "qkv", qkv, bias=torch.cat((qb, torch.zeros_like(qb), vb)), ln=False)
+    ao = _empty((M, D), dt, dev)
+    lse = _empty((Bf, H, N), torch.float32, dev)
+    ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], ao, lse, B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
+    br1 = _empty((M, D), torch.float32, dev)
+    _gemm_fwd(ao, D, [P(b + "attn.proj.weight")], "w", br1, bias=P(b + "attn.proj.bias"), ln=False)
+    sc1 = dps[0] if dps is not None else None
+    x, mean1, rstd1 = branch_out(br1, "norm1", sc1)
+    # MLP branch
+    x16b = _empty((M, D), dt, dev)
+    ops.cast_f32_to_16(x, x16b)
+    act, h = _empty((M, Hd), dt, dev), _empty((M, Hd), dt, dev)
+    _gemm_fwd(x16b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV, ln=False)
+    br2 = _empty((M, D), torch.float32, dev)
+    _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", br2, bias=P(b + "mlp.fc2.bias"), ln=False)
+    sc2 = dps[1] if dps is not None else None
+    x, mean2, rstd2 = branch_out(br2, "norm2", sc2)
+    a.update(post=True, x16a=x16a, qkv=qkv, ao=ao, lse=lse, br1=br1, mean1=mean1, rstd1=rstd1, sc1=sc1,
+             x16b=x16b, act=act, h=h, br2=br2, mean2=mean2, rstd2=rstd2, sc2=sc2)
+    return x
+
+
+def _postnorm_block_backward(spec, P, G, b, a, g, Bf, dt, dev, strides3, S):
+    """g: fp32 gradient of the residual stream [M, D] at the block's output, updated in place to the gradient at its input."""
+    D, N, H, hd, Hd = spec.D, spec.N, spec.H, spec.hd, spec.hidden
+    M = Bf * N
+    inv_s = 1.0 / S
+
+    def branch_in(br, mean, rstd, pre, sc):
+        """d(branch output), 16-bit in the gradient scale S: the LayerNorm backward of sc * g"""
+        dy = g if sc is None else (g.view(Bf, N, D) * sc.view(Bf, 1, 1)).view(M, D)
+        d16 = _empty((M, D), dt, dev)
+        ops.layernorm_bwd(dy, br, P(b + pre + ".weight"), mean, rstd, dx16=d16, scale16=S, dgamma=G(b + pre + ".weight"),
+                          dbeta=G(b + pre + ".bias"), dtype=dt)
+        return d16
+
+    # MLP branch
+    d16 = branch_in(a["br2"], a["mean2"], a["rstd2"], "norm2", a["sc2"])
+    w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+    linear_wgrad(d16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
+    dh = a["act"]
+    _gemm_dx(d16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX)
+    linear_wgrad(dh, a["x16b"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
+    _gemm_dx(dh, [w1], "w", g, ln=False, alpha=inv_s, resid=g)
+    del d16, dh
+    # attention branch
+    d16 = branch_in(a["br1"], a["mean1"], a["rstd1"], "norm1", a["sc1"])
+    wp = P(b + "attn.proj.weight")
+    linear_wgrad(d16, a["ao"], G(b + "attn.proj.weight"), inv_s, dbias=G(b + "attn.proj.bias"))
+    dao = _empty((M, D), dt, dev)
+    _gemm_dx(d16, [wp], "w", dao, ln=False)
+    qkv = a["qkv"]
+    dqkv = _empty((M, 3 * D), dt, dev)
+    delta = _empty((Bf, H, N), torch.float32, dev)
+    ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], a["ao"], dao, a["lse"], dqkv, dqkv[:, D:], dqkv[:, 2 * D:], delta,
+                 B=Bf, H=H, Sq=N, Sk=N, hd=hd, scale=hd ** -0.5, **strides3)
+    dbias = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+    linear_wgrad(dqkv, a["x16a"], G(b + "attn.qkv.weight"), inv_s, dbias=dbias)
+    G(b + "attn.q_bias").add_(dbias[:D])
+    G(b + "attn.v_bias").add_(dbias[2 * D:])
+    _gemm_dx(dqkv, [P(b + "attn.qkv.weight")], "qkv", g, ln=False, alpha=inv_s, resid=g)
+
+
 def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
     """One pass of the tower over the frames in `groups`.  save=False keeps nothing for a backward (chunked forward).
     diet (plain-MLP towers): 1 = the MLP intermediates are not kept (the backward recomputes fc1 + GELU / GELU'), 2 = nor the LayerNorm
@@ -360,7 +447,11 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
     depth = arch["depth_built"]
     Bf = sum(g.shape[0] for g in groups)
     M = Bf * N
-    if plan is None:
+    if arch.get("postnorm"):
+        plan, diet = None, 0          # (the post-norm tower evaluates every branch and scales it: no frame compaction, no diet)
+        if dp_scale is not None:
+            dp_scale = dp_scale.detach().to(dev, torch.float32)
+    elif plan is None:
         plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
     if arch["swiglu"]:
         diet = 0      # (the SwiGLU towers keep everything: B/16 and L/14 frames are an order of magnitude smaller)
@@ -400,6 +491,12 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
         if _TAIL_EXP is not None:
             runtime.CFG.split_fp16 = (i >= depth - _TAIL_EXP[0]) if _TAIL_EXP[0] >= 0 else (i < -_TAIL_EXP[0])
             runtime.CFG.split_mode = _TAIL_EXP[1]
+        if arch.get("postnorm"):
+            x = _postnorm_block_forward(spec, P, b, x, Bf, dp_scale[i] if dp_scale is not None else None, a, dt, dev, strides3())
+            if save:
+                acts.append(a)
+            del a
+            continue
         # --- attention branch: x <- x + s1 * proj(attn(LN1 x)) on the kept frames ---
         B1, fmap1, sc1 = branch_io(i, 0)
         a.update(B1=B1, fmap1=fmap1, sc1=sc1, tr1=plan.transition(i, 0) if plan is not None else None)
@@ -553,6 +650,13 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
         b = f"blocks.{i}."
         a = saved["acts"].pop()
         runtime.enter_block(i, pstate, bool(arch["swiglu"]))   # the block's weights in the layout its forward used
+        if a.get("post"):
+            _postnorm_block_backward(spec, P, G, b, a, g, Bf, dt, dev, strides3, S)
+            del a
+            if hook is not None:
+                i0, i1 = block_range[i]
+                hook(grads.span(i0, i1), params[i0:i1])
+            continue
         # ---------------- MLP branch (kept frames only: a dropped branch has no gradient) ----------------
         if a["B2"] > 0:
             M2, fmap2 = a["B2"] * N, a["fmap2"]

@@ -18,6 +18,9 @@ MODEL_CONFIGS = {
                             drop_path_rate=0.0, rope=True, naiveswiglu=True, subln=True),
     "EVA02-CLIP-L-14": dict(embed_dim=768, width=1024, layers=24, head_width=64, mlp_ratio=2.6667, patch_size=14,
                             drop_path_rate=0.0, rope=True, naiveswiglu=True, subln=True),
+    # the post-norm tower (eva_vit_model.py:411-413): x + drop_path(norm1(attn(x))), x + drop_path(norm2(mlp(x)))
+    "EVA02-CLIP-bigE-14-plus": dict(embed_dim=1024, width=1792, layers=64, head_width=112, mlp_ratio=8.571428571428571, patch_size=14,
+                                    drop_path_rate=0.0, rope=False, naiveswiglu=False, subln=False, postnorm=True),
 }
 
 
@@ -93,8 +96,10 @@ class EVAVisionTransformer(nn.Module):
     scale - the only configuration the MiCo JSON configs select)."""
 
     def __init__(self, img_size=224, patch_size=16, num_classes=512, embed_dim=768, depth=12, num_heads=12,
-                 mlp_ratio=4.0, drop_path_rate=0.0, rope=False, naiveswiglu=False, subln=False):
+                 mlp_ratio=4.0, drop_path_rate=0.0, rope=False, naiveswiglu=False, subln=False, postnorm=False):
         super().__init__()
+        assert not (postnorm and (naiveswiglu or subln or rope)), "the post-norm block is built for the plain-MLP tower (EVA02-CLIP-bigE-14-plus)"
+        self.postnorm = bool(postnorm)
         self.image_size = img_size
         self.num_features = self.embed_dim = embed_dim
         self.num_heads = num_heads
@@ -135,7 +140,7 @@ class EVAVisionTransformer(nn.Module):
         if self._spec is None or self._spec.names != names or self._spec.arch["depth_built"] != len(self.blocks):
             arch = dict(width=self.embed_dim, heads=self.num_heads, patch=self.patch_embed.patch_size[0],
                         mlp_hidden=self.mlp_hidden, rope=self.rope is not None, subln=self.subln, swiglu=self.naiveswiglu,
-                        depth_built=len(self.blocks))
+                        depth_built=len(self.blocks), postnorm=self.postnorm)
             rope = (self.rope.freqs_cos.float().contiguous(), self.rope.freqs_sin.float().contiguous()) if self.rope is not None else None
             self._spec = Fn.TowerSpec(arch, names, self.patch_embed.patch_shape[0], rope)
         elif self.rope is not None and self._spec.rope[0].device != self.rope.freqs_cos.device:
@@ -187,7 +192,7 @@ class CustomCLIP(nn.Module):
             img_size=vision_cfg["image_size"], patch_size=vision_cfg["patch_size"], num_classes=embed_dim,
             embed_dim=vision_cfg["width"], depth=vision_cfg["layers"], num_heads=vision_cfg["width"] // vision_cfg["head_width"],
             mlp_ratio=vision_cfg["mlp_ratio"], drop_path_rate=vision_cfg["drop_path_rate"], rope=vision_cfg["rope"],
-            naiveswiglu=vision_cfg["naiveswiglu"], subln=vision_cfg["subln"])
+            naiveswiglu=vision_cfg["naiveswiglu"], subln=vision_cfg["subln"], postnorm=vision_cfg.get("postnorm", False))
         self.text = None
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
 

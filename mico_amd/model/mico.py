@@ -18,6 +18,7 @@ VISION_TYPES = {   # mico.py:323-349
     "evaclip02_base_self": ("EVA02-CLIP-B-16", 768),
     "evaclip02_large": ("EVA02-CLIP-L-14", 1024),
     "evaclip01_giant": ("EVA01-CLIP-g-14", 1408),
+    "evaclip02_bige": ("EVA02-CLIP-bigE-14-plus", 1792),   # the post-norm tower (mico.py:341-344)
 }
 
 
@@ -157,10 +158,6 @@ class MMGeneralModule(nn.Module):
 
     def load_clip_model(self):
         t = self.config.vision_encoder_type
-        if t == "evaclip02_bige":
-            # mico.py:341-344 accepts EVA02-CLIP-bigE-14-plus (64 post-norm blocks, width 1792, xattn); the MI355X tower implements the
-            # pre-norm block of the B/16, L/14 and g/14 towers only (postnorm False on the hot path)
-            raise NotImplementedError("evaclip02_bige (EVA02-CLIP-bigE-14-plus, post-norm) is not supported by the MI355X tower")
         if t not in VISION_TYPES:
             raise NotImplementedError(t)
         name, self.vision_dim = VISION_TYPES[t]

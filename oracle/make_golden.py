@@ -75,6 +75,44 @@ def vit_fixture(vtype, depth, tag):
     return m
 
 
+def vit_bige_fixture(depth=2):
+    """EVA02-CLIP-bigE-14-plus (mico.py:341-344), the post-norm tower: the reference's own EVAVisionTransformer with the arguments
+    model/evaclip/model.py:105-131 derives from model_configs/EVA02-CLIP-bigE-14-plus.json, truncated to `depth` blocks at construction (the
+    full MiCo wrapper would allocate 64 blocks = 4.3 B parameters first); same inputs / weights / digests as vit_fixture."""
+    from functools import partial
+    ns = ref_import.load()
+    torch.manual_seed(0)
+    vis = ns.ref_eva.EVAVisionTransformer(
+        img_size=224, patch_size=14, num_classes=1024, use_mean_pooling=False, init_values=None, patch_dropout=0.0, embed_dim=1792,
+        depth=depth, num_heads=1792 // 112, mlp_ratio=8.571428571428571, qkv_bias=True, drop_path_rate=0.0,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), xattn=True, rope=False, postnorm=True, pt_hw_seq_len=16, intp_freq=False,
+        naiveswiglu=False, subln=False).eval()
+    shapes = {"vision_encoder.visual." + k: tuple(v.shape) for k, v in vis.state_dict().items()}
+    sd = synth_state_dict(shapes, 0)
+    vis.load_state_dict({k[len("vision_encoder.visual."):]: v for k, v in sd.items()}, strict=True)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    taps = []
+    hooks = [blk.register_forward_hook(lambda mod, i, o: taps.append(o.detach())) for blk in vis.blocks]
+    for p in vis.parameters():
+        p.requires_grad_(True)
+    out = vis(x, return_all_features=True)
+    for h in hooks:
+        h.remove()
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    named = dict(vis.named_parameters())
+    fx = dict(
+        out=out.detach().clone(),
+        tap_mean=torch.stack([t.mean() for t in taps]), tap_amax=torch.stack([t.abs().max() for t in taps]),
+        tap_rows=torch.stack([t[:, [0, 1, 100]] for t in taps]),
+        grads={n: grad_digest(p.grad) for n, p in named.items() if p.grad is not None and not n.startswith("head.")},
+        meta=dict(vtype="evaclip02_bige", depth=depth, input_seed=77),
+    )
+    torch.save(fx, os.path.join(OUT, "vit_bige_d2.pt"))
+    print("wrote vit_bige_d2.pt", tuple(out.shape), float(out.abs().max()), len(fx["grads"]), "gradient digests")
+
+
 def bert_fixture(m):
     me = m.multimodal_encoder
     for p in m.parameters():
@@ -570,6 +608,8 @@ def main(which):
     if want("vitl"):     # EVA02-CLIP-L/14 (mico.py:336-340): RoPE + sub-LN + SwiGLU with the 2730-wide hidden layer (not a multiple of 8)
         del_me = vit_fixture("evaclip02_large", 2, "l14_d2")
         del del_me
+    if want("vitbige"):  # EVA02-CLIP-bigE-14-plus (mico.py:341-344): the post-norm block order
+        vit_bige_fixture()
     if want("swin"):
         swin_fixture()
     if want("full"):

@@ -31,6 +31,9 @@ ARCHS = {
                                 swiglu=True, drop_path_rate=0.0, embed_dim=512),
     "evaclip02_large": dict(width=1024, depth=24, heads=16, patch=14, mlp_hidden=2730, rope=True, subln=True,
                             swiglu=True, drop_path_rate=0.0, embed_dim=768),
+    # model/evaclip/model_configs/EVA02-CLIP-bigE-14-plus.json (mico.py:341-344): the POST-norm tower (Block.forward :411-413)
+    "evaclip02_bige": dict(width=1792, depth=64, heads=16, patch=14, mlp_hidden=15360, rope=False, subln=False,
+                           swiglu=False, drop_path_rate=0.0, embed_dim=1024, postnorm=True),
 }
 VIT_EPS = 1e-6  # model/evaclip/model.py:124
 BERT_EPS = 1e-12  # model/bert-base-uncased-crossattn/config.json
@@ -127,7 +130,7 @@ def vit_depth(sd, pre):
 
 def eva_vit_forward(sd, x, arch, pre="vision_encoder.visual.", drop_path_scale=None, taps=None):
     """EVAVisionTransformer.forward_features(return_all_features=True), eval mode:
-    model/evaclip/eva_vit_model.py:611-650; Block.forward :409-416 (gamma None, postnorm False).
+    model/evaclip/eva_vit_model.py:611-650; Block.forward :409-416 (gamma None; both block orders, arch["postnorm"]).
 
     drop_path_scale: optional [depth, 2, B] per-sample multipliers (0 or 1/keep) standing in for the train-mode
     Bernoulli draw of drop_path (:121-138) so stochastic depth can be parity-tested with injected masks.
@@ -138,14 +141,21 @@ def eva_vit_forward(sd, x, arch, pre="vision_encoder.visual.", drop_path_scale=N
     rope = None
     if arch["rope"]:
         rope = rope_tables(arch["width"] // arch["heads"], x.shape[-1] // arch["patch"])
+    post = bool(arch.get("postnorm"))   # Block.forward :411-413: x + drop_path(norm1(attn(x))), x + drop_path(norm2(mlp(x)))
     for i in range(vit_depth(sd, pre)):
         p = pre + f"blocks.{i}."
-        a = eva_attention(sd, p + "attn.", layer_norm(t, sd[p + "norm1.weight"], sd[p + "norm1.bias"], VIT_EPS),
-                          arch, rope)
+        if post:
+            a = layer_norm(eva_attention(sd, p + "attn.", t, arch, rope), sd[p + "norm1.weight"], sd[p + "norm1.bias"], VIT_EPS)
+        else:
+            a = eva_attention(sd, p + "attn.", layer_norm(t, sd[p + "norm1.weight"], sd[p + "norm1.bias"], VIT_EPS),
+                              arch, rope)
         if drop_path_scale is not None:
             a = a * drop_path_scale[i, 0].view(B, 1, 1)
         t = t + a
-        m = eva_mlp(sd, p + "mlp.", layer_norm(t, sd[p + "norm2.weight"], sd[p + "norm2.bias"], VIT_EPS), arch)
+        if post:
+            m = layer_norm(eva_mlp(sd, p + "mlp.", t, arch), sd[p + "norm2.weight"], sd[p + "norm2.bias"], VIT_EPS)
+        else:
+            m = eva_mlp(sd, p + "mlp.", layer_norm(t, sd[p + "norm2.weight"], sd[p + "norm2.bias"], VIT_EPS), arch)
         if drop_path_scale is not None:
             m = m * drop_path_scale[i, 1].view(B, 1, 1)
         t = t + m

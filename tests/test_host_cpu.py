@@ -172,7 +172,7 @@ def test_modify_checkpoint_remap_and_interpolation():
 
 def test_unknown_encoder_type_raises():
     from mico_amd.model import MiCo, default_cfg
-    for t in ("videoswin_base_k600_22k", "clip_vit_base_16", "evaclip02_bige", "swin_small_1k"):   # mico.py:83-90 accepts none of these here
+    for t in ("videoswin_base_k600_22k", "clip_vit_base_16", "swin_small_1k"):   # mico.py:83-90 accepts none of these here
         with pytest.raises(NotImplementedError):
             MiCo(default_cfg(t))
 

@@ -112,6 +112,51 @@ def test_vit_tower_large(cuda, dtype):
     print(f"l14_d2 {dtype} worst grad err {worst:.2e}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("drop_path", [False, True])
+def test_vit_tower_bige_postnorm(cuda, dtype, drop_path):
+    """EVA02-CLIP-bigE-14-plus (mico.py:341-344): the POST-norm block order x + drop_path(norm(branch(x))) (eva_vit_model.py:411-413), width
+    1792, head dim 112, hidden 15360 - forward and every parameter-gradient digest against the reference's own EVAVisionTransformer
+    (tests/golden/vit_bige_d2.pt); with injected stochastic-depth scales against the oracle (pinned to that golden by
+    tests/test_oracle_vs_golden.py::test_vit_tower_bige_postnorm)."""
+    from oracle import mico_oracle as O
+    m, sd = build_model("evaclip02_bige", 2, device=cuda)
+    fx = golden("vit_bige_d2.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    w = torch.randn(fx["out"].shape, generator=g) / fx["out"].numel() ** 0.5
+    vis = m.vision_encoder.visual
+    m.zero_grad(set_to_none=True)
+    dps = None
+    if drop_path:
+        dps = torch.tensor([[[1.25, 0.0], [1.25, 1.25]], [[0.0, 1.6], [1.6, 0.0]]])     # [depth, branch, frame]: 0 or 1 / keep
+    with runtime.precision(dtype):
+        out = vis.forward_groups([x.to(cuda)], drop_path_scale=dps)
+        (out * w.to(cuda)).sum().backward()
+    named = dict(vis.named_parameters())
+    if not drop_path:
+        e = rel_err(out, fx["out"])
+        worst = max(grad_digest_check(d, named[n].grad, None) for n, d in fx["grads"].items())
+    else:
+        sdo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        ref = O.eva_vit_forward(sdo, x, O.ARCHS["evaclip02_bige"], drop_path_scale=dps)
+        (ref * w).sum().backward()
+        e = rel_err(out, ref)
+        worst = 0.0
+        for n, p in named.items():
+            if n.startswith("head."):
+                continue
+            gr = sdo["vision_encoder.visual." + n].grad
+            worst = max(worst, ((p.grad.cpu() - gr).abs().max() / gr.abs().max().clamp_min(1e-20)).item())
+    print(f"bige_d2 {dtype} drop_path={drop_path}: fwd rel err {e:.2e}, worst grad err {worst:.2e}")
+    assert e < FWD_TOL[dtype] and worst < GRAD_TOL[dtype]
+    if not drop_path:   # the no-grad pass (nothing saved) and the facade's vision branch produce the same tokens / a [b, n, 1792] feature
+        with torch.no_grad(), runtime.precision(dtype):
+            assert torch.equal(vis.forward_groups([x.to(cuda)]), out)
+            fv = m.forward_vision_encoder(x.to(cuda).unsqueeze(1))
+        assert fv.shape[0] == 2 and fv.shape[-1] == 1792 and torch.isfinite(fv).all()
+
+
 @pytest.mark.parametrize("pc", PRECISION_CONFIGS)
 def test_bert(setup, cuda, pc):
     """BERT (self-only, cross-attention with a 2-D mask, causal cross-attention + LM head + CE) against the reference's own outputs, in

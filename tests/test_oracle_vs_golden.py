@@ -53,6 +53,25 @@ def test_vit_tower_large():
         assert grad_digest_check(d, sd["vision_encoder.visual." + n].grad, TOL) < 5e-5, n
 
 
+def test_vit_tower_bige_postnorm():
+    """EVA02-CLIP-bigE-14-plus (mico.py:341-344; depth 2): the POST-norm block order (eva_vit_model.py:411-413) against the reference's own
+    EVAVisionTransformer (tests/golden/vit_bige_d2.pt: output, per-block taps, all 32 parameter-gradient digests)."""
+    m, sd = build_model("evaclip02_bige", 2)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    fx = golden("vit_bige_d2.pt")
+    g = torch.Generator().manual_seed(fx["meta"]["input_seed"])
+    x = torch.randn((2, 3, 224, 224), generator=g)
+    taps = []
+    out = O.eva_vit_forward(sd, x, O.ARCHS["evaclip02_bige"], taps=taps)
+    assert rel_err(out, fx["out"]) < TOL
+    assert rel_err(torch.stack([t[:, [0, 1, 100]] for t in taps]), fx["tap_rows"]) < TOL
+    w = torch.randn(out.shape, generator=g) / out.numel() ** 0.5
+    (out * w).sum().backward()
+    assert len(fx["grads"]) == 32
+    for n, d in fx["grads"].items():
+        assert grad_digest_check(d, sd["vision_encoder.visual." + n].grad, TOL) < 5e-5, n
+
+
 def swin_state_dict():
     """the synthetic weights of the fixture-sized Swin tower under the reference's own (prefix-free) SwinTransformer keys"""
     from mico_amd.model.swin import SWIN_CONFIGS, SwinTransformer
