@@ -169,6 +169,12 @@ int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const flo
                        const int* frame_map, int rows_per_frame, float* x_copy,
                        float drop_p, unsigned drop_seed, int drop_site,
                        int valid_cols, int dtype, void* stream);
+/* The fp8 mode's LayerNorm-fed GEMMs (qkv, fc1): as mico_layernorm_fwd (the towers' subset of its arguments), and the 16-bit output is ALSO
+ * written as the block-scaled fp8 A operand of mico_gemm_mx8 - q8 [rows, cols] e4m3 (row stride ldq), scales as mico_quant_mx8 lays them out
+ * ([cols / 128][rows] words of four E8M0 bytes) - bit-identical to mico_quant_mx8(y16), without its pass over y16.  cols % 128 == 0, <= 2048. */
+int mico_layernorm_fwd_mx8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* mean, float* rstd,
+                           int64_t rows, int cols, float eps, const int* frame_map, int rows_per_frame, float* x_copy,
+                           void* q8, int64_t ldq, void* scales, int dtype, void* stream);
 /* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
  * (dx16 = T(dx * scale16)).
  * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced

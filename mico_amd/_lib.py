@@ -54,6 +54,7 @@ PROTOTYPES = {
     "mico_gemm_mx8": [c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, C.POINTER(GemmEpilogue), c_int, c_vp],
     "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
                            c_int, c_vp, c_int, c_vp, c_f, C.c_uint, c_int, c_int, c_int, c_vp],
+    "mico_layernorm_fwd_mx8": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
     "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
                            c_i64, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_f, C.c_uint, c_int, c_int, c_vp],
@@ -104,7 +105,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 108   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 109   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

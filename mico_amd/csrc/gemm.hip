@@ -2778,7 +2778,7 @@ static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-
 static int g_mico_mid_group = 0;       // sweeps: variant / 100 overrides the MID kernel's tile-order group height
 extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant + 100 * g_mico_mid_group; g_mico_gemm_variant = v % 100; g_mico_mid_group = v / 100; return old; }
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 108; }
+extern "C" int mico_version(void) { return 109; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {

@@ -24,7 +24,10 @@ template <> struct RowIO<bf16> {
 
 // LEAN: the towers' block LayerNorms use neither the post-add table, nor dropout, nor an fp32 output, nor the hi|lo split output
 // (bf16 configuration): compiled without them
-template <typename T, typename XT, int NV, bool LEAN = false>
+// MX: the 16-bit output is ALSO written as the block-scaled fp8 operand of mico_gemm_mx8 (e4m3 + one E8M0 scale per 32 columns, the layout and
+// the arithmetic of quant_mx8_kernel - the rounded 16-bit values are what gets quantised, so the result is bit-identical to quantising y16 in
+// a pass of its own): mico_layernorm_fwd_mx8, the fp8 mode's LayerNorm-fed GEMMs (qkv, fc1)
+template <typename T, typename XT, int NV, bool LEAN = false, bool MX = false>
 __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, T* __restrict__ y16,
                                                            float* __restrict__ y32, float* __restrict__ mean_o,
@@ -33,7 +36,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            int post_groups, int split16,
                                                            const int* __restrict__ frame_map, int rpf,
                                                            float* __restrict__ x_copy, float drop_p, unsigned drop_seed,
-                                                           int drop_site, int valid_cols) {
+                                                           int drop_site, int valid_cols, unsigned char* __restrict__ q8 = nullptr,
+                                                           int64_t ldq = 0, unsigned* __restrict__ sc8 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nv = cols >> 2;
@@ -105,6 +109,30 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                     for (int k = 0; k < 4; ++k) o[k] *= drop_mult(drop_seed, drop_site, i0 + k, thr, ik);
                 }
                 if (!LEAN && y32) *(f32x4*)(y32 + row * cols + c * 4) = o;
+                if (MX) {
+                    // cols % 128 == 0: the 8 lanes of a 32-column block and the 32 lanes of a 128-column scale word are all inside or all
+                    // outside the row (c < nv), so the lane exchanges below stay among active lanes
+                    const f32x4 r4 = unpack4<T>(pack4<T>(o[0], o[1], o[2], o[3]));
+                    float amax = fmaxf(fmaxf(fabsf(r4[0]), fabsf(r4[1])), fmaxf(fabsf(r4[2]), fabsf(r4[3])));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                    const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
+                    int e = (int)((bits >> 23) & 0xFF) - 127 + ((bits & 0x7FFFFF) ? 1 : 0);
+                    e = amax > 0.f ? max(-127, min(127, e)) : -127;
+                    const float sinv = __uint_as_float((unsigned)(127 - e) << 23);
+                    unsigned w0 = 0;
+                    if (amax > 0.f && e > -127) {
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r4[0] * sinv, r4[1] * sinv, w0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r4[2] * sinv, r4[3] * sinv, w0, true);
+                    }
+                    *(unsigned*)(q8 + row * ldq + c * 4) = w0;
+                    const unsigned sbyte = (unsigned)(e + 127);
+                    const int base = lane & ~31;
+                    const unsigned word = (__shfl(sbyte, base, 64) & 0xFF) | ((__shfl(sbyte, base + 8, 64) & 0xFF) << 8) |
+                                          ((__shfl(sbyte, base + 16, 64) & 0xFF) << 16) | ((__shfl(sbyte, base + 24, 64) & 0xFF) << 24);
+                    if ((lane & 31) == 0) sc8[(int64_t)(i * 2 + (lane >> 5)) * rows + row] = word;
+                }
                 if (y16) {
                     if (LEAN || !split16) {
                         *(s16x4*)(y16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
@@ -312,6 +340,28 @@ extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma
         if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site, valid_cols);
         else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site, valid_cols);
     });
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_layernorm_fwd_mx8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* mean, float* rstd,
+                                      int64_t rows, int cols, float eps, const int* frame_map, int rows_per_frame, float* x_copy,
+                                      void* q8, int64_t ldq, void* scales, int dtype, void* stream) {
+    MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd_mx8: bad dtype");
+    if (rows <= 0) return MICO_OK;
+    MICO_CHECK(x && gamma && beta && y16 && q8 && scales, "mico_layernorm_fwd_mx8: null pointer");
+    MICO_CHECK(cols % 128 == 0 && cols > 0 && cols <= 2048, "mico_layernorm_fwd_mx8: cols must be a multiple of 128 and <= 2048 (got %d)", cols);
+    MICO_CHECK(ldq >= cols && ldq % 8 == 0, "mico_layernorm_fwd_mx8: ldq must be >= cols and a multiple of 8");
+    MICO_CHECK(x_dtype == MICO_F32 || x_dtype == dtype, "mico_layernorm_fwd_mx8: x_dtype must be fp32 or dtype");
+    if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_fwd_mx8: frame_map needs rows_per_frame > 0");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ln_grid(rows, 1024));
+#define LNMX(XT, NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV, false, true>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, (float*)nullptr, mean, rstd, rows, cols, eps, (const float*)nullptr, 0, 0, 0, frame_map, rows_per_frame, x_copy, 0.f, 0u, 0, cols, (unsigned char*)q8, ldq, (unsigned*)scales)
+    DISPATCH_T16(dtype, {
+        if (x_dtype == MICO_F32) { if (cols <= 1024) LNMX(float, 4); else if (cols <= 1536) LNMX(float, 6); else LNMX(float, 8); }
+        else { if (cols <= 1024) LNMX(T, 4); else if (cols <= 1536) LNMX(T, 6); else LNMX(T, 8); }
+    });
+#undef LNMX
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

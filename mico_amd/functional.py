@@ -219,12 +219,28 @@ def _padv(p, n):
     return out
 
 
-def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None, valid_cols=0):
+class _Operand16:
+    """A 16-bit GEMM operand buffer that carries its block-scaled fp8 copy (fp8 mode, produced by the LayerNorm that wrote it)."""
+    __slots__ = ("t", "mx8")
+
+    def __init__(self, t):
+        self.t, self.mx8 = t, None
+
+
+def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None, valid_cols=0, mx8_for=None):
     """LayerNorm -> 16-bit GEMM operand.  Returns (buf, view, mean, rstd); in the split-precision (fp16 parity) mode buf is
     [rows, 2*cols] = [hi | lo] and view its hi half.  frame_map: compacting gather of whole frames (rows = kept rows)."""
     split = runtime.split_activations() and cols % 64 == 0
     buf = _empty((rows, 2 * cols if split else cols), dt, dev)
     mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+    if mx8_for is not None and not split and not valid_cols and runtime.fp8_enabled() and runtime.CFG.fp8_fused_quant and cols % 128 == 0 \
+            and cols <= 2048 and _mx8_worthwhile(rows, mx8_for):
+        # fp8 mode: the GEMM this LayerNorm feeds takes a block-scaled fp8 operand - written by the LayerNorm itself (== quant_mx8 of the
+        # 16-bit output, without that pass); the operand rides on the buffer object to _gemm_fwd
+        buf = _Operand16(buf)
+        buf.mx8 = ops.layernorm_fwd_mx8(x, g, b, eps, out16=buf.t, mean=mean, rstd=rstd, dtype=dt, frame_map=frame_map,
+                                        rows_per_frame=rows_per_frame, x_copy=x_copy)
+        return buf, buf.t, mean, rstd
     ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt, frame_map=frame_map,
                       rows_per_frame=rows_per_frame, x_copy=x_copy, valid_cols=valid_cols)
     return buf, (buf[:, :cols] if split else buf), mean, rstd
@@ -239,10 +255,14 @@ def _mx8_worthwhile(m, n):
 def _gemm_fwd(a_buf, a_cols, plist, tag, out, k_pad=None, n_pad=None, ln=True, **epi):
     """Forward GEMM out = a W^T: plain in the bf16 configuration; in the fp16 parity configuration the weight is hi|lo split
     (and the activation too when its producer emitted [hi | lo]) and the products are summed by one k-segmented launch."""
+    pre = None
+    if isinstance(a_buf, _Operand16):
+        pre, a_buf = a_buf.mx8, a_buf.t
     if runtime.fp8_enabled() and a_cols % 128 == 0 and "pos" not in epi and not k_pad and not n_pad and _mx8_worthwhile(a_buf.shape[0], out.shape[1]):
-        # configs[4]: block-scaled fp8 MFMA.  The activation is quantised here in a pass of its own (5 TB/s; fusing it into the producing
-        # LayerNorm / GELU epilogue is the next step), the weight's fp8 copy is cached per optimizer step.
-        return ops.gemm_mx8(ops.quant_mx8(a_buf[:, :a_cols]), runtime.gemm_weight_mx8(plist, tag), out, dtype=a_buf.dtype, **epi)
+        # configs[4]: block-scaled fp8 MFMA.  The activation is quantised by the LayerNorm that produced it (round 4: _ln16(mx8_for=...)) or
+        # here in a pass of its own (the GELU / attention outputs: 5 TB/s), the weight's fp8 copy is cached per optimizer step.
+        return ops.gemm_mx8(pre if pre is not None else ops.quant_mx8(a_buf[:, :a_cols]), runtime.gemm_weight_mx8(plist, tag), out,
+                            dtype=a_buf.dtype, **epi)
     w, ks = runtime.gemm_weight(plist, tag, k_pad=k_pad, n_pad=n_pad, ln_fed=ln)
     if ks is not None and a_buf.shape[1] == 2 * a_cols and a_cols == ks[0]:
         ks = (ks[0], [0, a_cols, 0], [0, 0, ks[0]])
@@ -504,7 +524,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
             M1 = B1 * N
             xc1 = _empty((M1, D), torch.float32, dev) if fmap1 is not None else None
             ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev,
-                                            frame_map=fmap1, rows_per_frame=N, x_copy=xc1)
+                                            frame_map=fmap1, rows_per_frame=N, x_copy=xc1, mx8_for=3 * D)
             qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
             qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
             qkv = _empty((M1, 3 * D), dt, dev)
@@ -534,7 +554,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
             M2 = B2 * N
             xc2 = _empty((M2, D), torch.float32, dev) if fmap2 is not None else None
             ln2b, ln2, mean2, rstd2 = _ln16(x, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev,
-                                            frame_map=fmap2, rows_per_frame=N, x_copy=xc2)
+                                            frame_map=fmap2, rows_per_frame=N, x_copy=xc2, mx8_for=None if arch["swiglu"] else spec.hidden)
             x_out = _empty((M, D), torch.float32, dev) if fmap2 is None else x
             epi = dict(resid=x, row_scale=sc2, rows_per_scale=N, row_map=fmap2, rows_per_map=N)
             if arch["swiglu"]:
@@ -707,7 +727,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                     # either case exactly the M2 rows the forward normalised), then fc1 + GELU / GELU' exactly as the forward ran them
                     ln2b = a["ln2b"]
                     if ln2b is None:
-                        ln2b, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev)
+                        ln2b, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, mx8_for=Hd)
                     a["h"], a["act"] = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
                     _gemm_fwd(ln2b, D, [w1], "w", a["act"], bias=P(b + "mlp.fc1.bias"), aux_out=a["h"], act=ops.ACT_GELU_SAVE_DERIV)
                     del ln2b

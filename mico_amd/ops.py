@@ -226,6 +226,19 @@ def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rst
     check(rc, "mico_layernorm_fwd")
 
 
+def layernorm_fwd_mx8(x, gamma, beta, eps, *, out16, mean, rstd, dtype, frame_map=None, rows_per_frame=0, x_copy=None):
+    """layernorm_fwd whose 16-bit output is also quantised to the MX fp8 operand of gemm_mx8 (returns the Mx8; == quant_mx8(out16))."""
+    rows, cols = x.shape[0], x.shape[1]
+    if frame_map is not None:
+        rows = frame_map.shape[0] * rows_per_frame
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((cols // 128, rows), dtype=torch.int32, device=x.device)
+    check(_lib.lib().mico_layernorm_fwd_mx8(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(mean), _p(rstd), rows, cols, eps,
+                                            _p(frame_map), rows_per_frame, _p(x_copy), _p(q), q.stride(0), _p(sc), dt_code(dtype), _st()),
+          "mico_layernorm_fwd_mx8")
+    return Mx8(q, sc)
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
                   grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0, dx16_dst=None, dx16_frame_scale=None,
                   dx16_drop=None):

@@ -39,6 +39,9 @@ class _Cfg:
     share_cross_kv = True
     # one gradient arena per backward pass for all the BERT passes of a step (functional.GradArena.session): no per-parameter sums by autograd
     share_grad_arena = True
+    # fp8 mode: the LayerNorm that feeds qkv / fc1 writes the GEMM's block-scaled fp8 operand itself (mico_layernorm_fwd_mx8) instead of a
+    # quantisation pass over its 16-bit output; MICO_FP8_NO_FUSED_QUANT=1 for A/B runs
+    fp8_fused_quant = os.environ.get("MICO_FP8_NO_FUSED_QUANT") is None
     # fc1 of a tower forward that keeps no GELU' (no backward, or the activation diet recomputes the pair) runs the GELU-only epilogue
     # (half the output bytes); MICO_FC1_PAIR_ALWAYS=1: the pair epilogue everywhere (A/B runs)
     fc1_plain_gelu = os.environ.get("MICO_FC1_PAIR_ALWAYS") is None

@@ -333,6 +333,42 @@ def test_attention_shared_kv(cuda, dtype, drop):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cols,xdt,gather", [(1408, "f32", True), (1408, "f32", False), (1024, "16", False), (1792, "f32", False)])
+def test_layernorm_fwd_mx8_equals_separate_quantisation(cuda, dtype, cols, xdt, gather):
+    """mico_layernorm_fwd_mx8 (fp8 mode: the LayerNorm that feeds qkv / fc1 writes the GEMM's block-scaled fp8 operand itself): 16-bit output,
+    statistics and the gathered fp32 copy equal mico_layernorm_fwd's bit for bit, and the e4m3 bytes + E8M0 scale words equal
+    mico_quant_mx8 of that 16-bit output bit for bit - with the frame gather of the stochastic-depth path and without."""
+    from mico_amd import ops
+    torch.manual_seed(cols)
+    rpf, frames = 257, 7
+    x = (2.0 * torch.randn(frames * rpf, cols, device=cuda) + 0.3)
+    x[5] = 0                                    # an all-equal row: LayerNorm output = beta
+    if xdt == "16":
+        x = x.to(dtype)
+    g = 1.0 + 0.1 * torch.randn(cols, device=cuda)
+    b = 0.05 * torch.randn(cols, device=cuda)
+    b[128:160] = 0
+    g[128:160] = 0                              # a 32-column block of exact zeros: scale byte of an all-zero block
+    fmap = torch.tensor([6, 0, 3, 2], dtype=torch.int32, device=cuda) if gather else None
+    rows = (4 if gather else frames) * rpf
+    kw = dict(frame_map=fmap, rows_per_frame=rpf if gather else 0)
+    outs = []
+    for fused in (False, True):
+        y = torch.full((rows, cols), float("nan"), device=cuda, dtype=dtype)
+        mean, rstd = torch.empty(rows, device=cuda), torch.empty(rows, device=cuda)
+        xc = torch.empty(rows, cols, device=cuda) if (gather and xdt == "f32") else None
+        if fused:
+            mx = ops.layernorm_fwd_mx8(x, g, b, 1e-6, out16=y, mean=mean, rstd=rstd, dtype=dtype, x_copy=xc, **kw)
+        else:
+            ops.layernorm_fwd(x, g, b, 1e-6, out16=y, mean=mean, rstd=rstd, dtype=dtype, x_copy=xc, **kw)
+            mx = ops.quant_mx8(y)
+        torch.cuda.synchronize()
+        outs.append((y, mean, rstd, xc, mx.q, mx.scales))
+    for a_, b_ in zip(*outs):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Sq,Sk,hd,B,H", [(257, 257, 88, 40, 16), (200, 257, 72, 3, 5), (257, 256, 96, 2, 3), (130, 200, 88, 3, 4), (260, 129, 80, 2, 2),
                                           (257, 257, 88, 1, 1), (257, 257, 64, 5, 16), (197, 197, 64, 20, 12), (256, 256, 48, 2, 3)])
 def test_attention_onepass_backward_shapes(cuda, dtype, Sq, Sk, hd, B, H):
