@@ -507,7 +507,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
     for i in range(depth):
         b = f"blocks.{i}."
         a = {}
-        runtime.enter_block(i, pstate, bool(arch["swiglu"]))
+        runtime.enter_block(i, pstate, bool(arch["swiglu"]), depth)
         if _TAIL_EXP is not None:
             runtime.CFG.split_fp16 = (i >= depth - _TAIL_EXP[0]) if _TAIL_EXP[0] >= 0 else (i < -_TAIL_EXP[0])
             runtime.CFG.split_mode = _TAIL_EXP[1]
@@ -669,7 +669,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
     for i in reversed(range(arch["depth_built"])):
         b = f"blocks.{i}."
         a = saved["acts"].pop()
-        runtime.enter_block(i, pstate, bool(arch["swiglu"]))   # the block's weights in the layout its forward used
+        runtime.enter_block(i, pstate, bool(arch["swiglu"]), arch["depth_built"])   # the block's weights in the layout its forward used
         if a.get("post"):
             _postnorm_block_backward(spec, P, G, b, a, g, Bf, dt, dev, strides3, S)
             del a

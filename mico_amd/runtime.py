@@ -35,6 +35,8 @@ class _Cfg:
     # (OCP MX e4m3, one E8M0 scale per 32 reduction elements; mico_gemm_mx8) - weight gradients, attention, LayerNorm, the residual stream
     # and every loss stay as in the 16-bit configuration of compute_dtype.  Off by default (the 16-bit path is the parity path).
     fp8 = False
+    # fp8 mode: (first, last) tower blocks that stay in the 16-bit type (runtime.set_fp8_16bit_blocks)
+    fp8_16bit_blocks = tuple(int(v) for v in os.environ.get("MICO_FP8_16BIT_BLOCKS", "0,0").split(","))
     # training: project the cross-attention K/V of a step's condition tokens once (functional.CrossKVFn) instead of in every BERT pass
     share_cross_kv = True
     # one gradient arena per backward pass for all the BERT passes of a step (functional.GradArena.session): no per-parameter sums by autograd
@@ -95,7 +97,7 @@ def using(state):
         restore(old)
 
 
-def enter_block(i, base, subln_swiglu=False):
+def enter_block(i, base, subln_swiglu=False, depth=None):
     """Precision state of tower block i under the pass-wide state `base` (a snapshot()): with CFG.head_split_blocks = n the first n
     blocks of a plain-fp16 tower run their forward GEMMs as x W_hi + x W_lo (the weights-split mode; EVA02-style towers - RoPE + sub-LN
     + SwiGLU, subln_swiglu=True - take the 3-segment mode with the fp32 gate there: measured on the reference goldens of the depth-2
@@ -106,6 +108,11 @@ def enter_block(i, base, subln_swiglu=False):
     dt, split, mode, fp8, n, hmode = base
     if n and i < n and dt == torch.float16 and not split and not fp8:
         restore((dt, True, "full" if subln_swiglu else hmode, False, n, hmode))
+    elif fp8 and depth is not None and (i < CFG.fp8_16bit_blocks[0] or i >= depth - CFG.fp8_16bit_blocks[1]):
+        # fp8 mode with its first / last blocks kept in the 16-bit type (set_fp8_16bit_blocks): e4m3 rounding made in the first blocks passes
+        # through every later block, and the last blocks' errors reach the output unattenuated - the drift / speed trade-off is measured in
+        # tests/test_full_size_gpu.py::test_config5_video_caption_step
+        restore((dt, split, mode, False, n, hmode))
     else:
         restore(base)
 
@@ -244,6 +251,11 @@ def fp8_mode(on=True):
         yield
     finally:
         CFG.fp8 = old
+
+
+def set_fp8_16bit_blocks(first=0, last=0):
+    """In fp8 mode keep the tower's first / last blocks in the 16-bit type (accuracy against speed; (0, 0) = every block on the fp8 MFMA)."""
+    CFG.fp8_16bit_blocks = (int(first), int(last))
 
 
 def fp8_enabled():
