@@ -693,20 +693,25 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
         load_q(next);   // qf / qx are dead from here on: the next item's query fragments take their registers
         PH(6);
         if (main_live) {
+            // 16-byte stores (as attn_bwd_onepass_kernel's dK / dV rows): v_permlane16_swap trades one head-dim tile's quartet with the
+            // neighbouring lane group for the next tile's, so even groups hold 8 consecutive head dims of tile td and odd groups of tile td + 1 -
+            // half the store instructions (each touches 16 token rows: the address path, not the bytes, is what they cost)
+            static_assert(C::TD % 2 == 0, "tile pairs");
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int i = i0 + rb * 16;
-                if (i < p.Sq) {
-                    const float inv = 1.f / l_run[rb];
-                    T* ob = o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd;
+                const float inv = 1.f / l_run[rb];
+                T* ob = o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd;
 #pragma unroll
-                    for (int td = 0; td < C::TD; ++td) {
-                        const int d = td * 16 + g * 4;
-                        if (d < p.hd)
-                            *(s16x4*)(ob + d) = pack4<T>(oacc[rb][td][0] * inv, oacc[rb][td][1] * inv, oacc[rb][td][2] * inv, oacc[rb][td][3] * inv);
-                    }
-                    if (g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (m_run[rb] + __log2f(l_run[rb])) * 0.6931471805599453f;
+                for (int tp = 0; tp < C::TD; tp += 2) {
+                    const f32x4 ta = oacc[rb][tp] * inv, tb = oacc[rb][tp + 1] * inv;
+                    u32x2 a2 = __builtin_bit_cast(u32x2, pack4<T>(ta[0], ta[1], ta[2], ta[3])), c2 = __builtin_bit_cast(u32x2, pack4<T>(tb[0], tb[1], tb[2], tb[3]));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2[0]), "+v"(c2[0]));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2[1]), "+v"(c2[1]));
+                    const int d = (tp + (g & 1)) * 16 + (g >> 1) * 8;
+                    if (i < p.Sq && d < p.hd) *(u32x4*)(ob + d) = (u32x4){a2[0], a2[1], c2[0], c2[1]};
                 }
+                if (i < p.Sq && g == 0) lse[((int64_t)b * p.H + h) * p.Sq + i] = (m_run[rb] + __log2f(l_run[rb])) * 0.6931471805599453f;
             }
         }
     }
