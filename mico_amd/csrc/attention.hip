@@ -15,6 +15,10 @@ namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
 
+#ifndef MICO_ATTN_PRIO
+#define MICO_ATTN_PRIO 0   // experiment: alternating s_setprio between the two waves of a SIMD in the persistent tower kernels
+#endif
+
 #ifdef MICO_ATTN_PHASES   // timing build (tools/probes/attn_phases.py): per-wave cycle counts of the forward kernel's phases
 __device__ unsigned long long g_attn_phase[4096 * 8];
 #define PH_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -618,6 +622,9 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
     for (; item < item_end; item += item_step) {
         PH(7);
         const int b = item / p.H, h = item - b * p.H;
+#if MICO_ATTN_PRIO
+        if (((item ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (see attn_bwd_onepass_kernel)
+#endif
         const int next = item + item_step < item_end ? item + item_step : item;   // the last item re-fetches itself (static wait counts)
         __syncthreads();   // every wave is done with the previous item's K/V and has written its partials
         PH(0);
@@ -2788,6 +2795,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_onepass_kernel(const T* __res
     // that those registers are live from here to the next item_start only)
     auto chunk = [&](auto last_tag, const int c, const int next_item) {
         constexpr bool LAST = decltype(last_tag)::value;
+#if MICO_ATTN_PRIO
+        // waves w and w + 4 share a SIMD; left alone the first of them wins every issue tie, runs ahead and then idles at the barrier while its
+        // partner finishes alone at single-wave latency: alternate the priority per chunk so that the pair advances together
+        if (((G ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         phase1(st, G & 1);
         PH(2);
         __syncthreads();
