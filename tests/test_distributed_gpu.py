@@ -66,7 +66,9 @@ def _worker(rank, world, port, ret):
             dist.all_gather(both, local[k])
             mean = (both[0] + both[1]) / 2
             err = (p.grad.float() - mean).abs().max() / mean.abs().max().clamp_min(1e-20)
-            assert err < 1e-5, (k, float(err))
+            # (two separate backward passes: the weight-gradient GEMMs add their K-splits with fp32 atomics, and since round 4 all BERT passes of a
+            # step accumulate into ONE arena - the summation order differs from pass to pass: ~1e-6 typical, 1.1e-5 seen once in a full-suite run)
+            assert err < 5e-5, (k, float(err))
         res = {k: float(v) for k, v in out.items()}
         g = m.contra_head_va.weight.grad.detach().float().cpu().clone()
         g2 = m.vision_encoder.visual.blocks[0].mlp.w1.weight.grad.detach().float().cpu().clone()
