@@ -711,8 +711,9 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
                 T* ob = o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + h * p.hd;
 #pragma unroll
                 for (int tp = 0; tp < C::TD; tp += 2) {
-                    const f32x4 ta = oacc[rb][tp] * inv, tb = oacc[rb][tp + 1] * inv;
-                    u32x2 a2 = __builtin_bit_cast(u32x2, pack4<T>(ta[0], ta[1], ta[2], ta[3])), c2 = __builtin_bit_cast(u32x2, pack4<T>(tb[0], tb[1], tb[2], tb[3]));
+                    const f32x4 ta = oacc[rb][tp], tb = oacc[rb][tp + 1];
+                    u32x2 a2 = {pack2_scaled<T>(ta[0], ta[1], inv), pack2_scaled<T>(ta[2], ta[3], inv)};
+                    u32x2 c2 = {pack2_scaled<T>(tb[0], tb[1], inv), pack2_scaled<T>(tb[2], tb[3], inv)};
                     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2[0]), "+v"(c2[0]));
                     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2[1]), "+v"(c2[1]));
                     const int d = (tp + (g & 1)) * 16 + (g >> 1) * 8;

@@ -91,6 +91,22 @@ template <typename T> __device__ __forceinline__ s16x4 pack4(float a, float b, f
     v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
     return __builtin_bit_cast(s16x4, v);
 }
+// (T)(a s) | (T)(b s) << 16.  fp16: v_fma_mix{lo,hi}_f16 forms the fp32 product exactly and rounds it to fp16 ONCE (a v_mul_f32 +
+// v_cvt_pk_f16_f32 pair rounds twice); written out because the compiler picks one form or the other per element as it schedules, which
+// makes the bits of a kernel's output depend on unrelated edits around the conversion.  bf16: one multiply, one conversion.
+template <typename T> __device__ __forceinline__ uint32_t pack2_scaled(float a, float b, float s);
+template <> __device__ __forceinline__ uint32_t pack2_scaled<f16>(float a, float b, float s) {
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r) : "v"(b), "v"(s));
+    return r;
+}
+template <> __device__ __forceinline__ uint32_t pack2_scaled<bf16>(float a, float b, float s) {
+    typedef bf16 v2 __attribute__((ext_vector_type(2)));
+    v2 v;
+    v[0] = (bf16)(a * s); v[1] = (bf16)(b * s);
+    return __builtin_bit_cast(uint32_t, v);
+}
 template <typename T> __device__ __forceinline__ f32x4 unpack4(s16x4 s) {
     typename T16<T>::v4 v = __builtin_bit_cast(typename T16<T>::v4, s);
     f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
