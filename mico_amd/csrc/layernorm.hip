@@ -8,18 +8,30 @@
 
 namespace {
 
+// Non-temporal hints on the row streams (every element is touched once per launch): bit 0 = stores, bit 1 = loads.  Measured with
+// tools/ln_bench.py at 717 frames x 257 x 1408 (tools/probes/README.md "Round 4: LayerNorm"): backward in situ 802 -> 770 us, forward
+// 312 -> 289 us with both; -DMICO_LN_NT=0 rebuilds the plain form.
+#ifndef MICO_LN_NT
+#define MICO_LN_NT 3
+#endif
+template <typename V> __device__ __forceinline__ void st_stream(V* p, V v) {
+    if constexpr ((MICO_LN_NT & 1) != 0) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <typename V> __device__ __forceinline__ V ld_stream(const V* p) {
+    if constexpr ((MICO_LN_NT & 2) != 0) return __builtin_nontemporal_load(p); else return *p;
+}
 constexpr int MAXV = 16;   // float4 per lane -> cols <= 4096 (forward); backward supports cols <= 2048
 constexpr int LN_BLOCK = 256;
 
 template <typename XT> struct RowIO;
 template <> struct RowIO<float> {
-    static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ f32x4 load(const float* p) { return ld_stream((const f32x4*)p); }
 };
 template <> struct RowIO<f16> {
-    static __device__ __forceinline__ f32x4 load(const f16* p) { return unpack4<f16>(*(const s16x4*)p); }
+    static __device__ __forceinline__ f32x4 load(const f16* p) { return unpack4<f16>(ld_stream((const s16x4*)p)); }
 };
 template <> struct RowIO<bf16> {
-    static __device__ __forceinline__ f32x4 load(const bf16* p) { return unpack4<bf16>(*(const s16x4*)p); }
+    static __device__ __forceinline__ f32x4 load(const bf16* p) { return unpack4<bf16>(ld_stream((const s16x4*)p)); }
 };
 
 // LEAN: the towers' block LayerNorms use neither the post-add table, nor dropout, nor an fp32 output, nor the hi|lo split output
@@ -39,7 +51,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            int drop_site, int valid_cols, unsigned char* __restrict__ q8 = nullptr,
                                                            int64_t ldq = 0, unsigned* __restrict__ sc8 = nullptr) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform for the compiler: row bases, statistics and frame lookups go to SGPRs)
     const int nv = cols >> 2;
     // valid_cols < cols: the row is a zero-padded [valid_cols | 0 ...] vector (EVA02-L's 2730-wide SwiGLU hidden in a 2752-wide buffer):
     // statistics over the valid columns only - the zeros add nothing to the sum and exactly (cols - valid) * mean^2 to the centred sum of
@@ -72,7 +84,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
             if (c < nv) {
-                if (x_copy) *(f32x4*)(x_copy + row * cols + c * 4) = v[i];
+                if (x_copy) st_stream((f32x4*)(x_copy + row * cols + c * 4), v[i]);
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 }
                 if (y16) {
                     if (LEAN || !split16) {
-                        *(s16x4*)(y16 + row * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+                        st_stream((s16x4*)(y16 + row * cols + c * 4), pack4<T>(o[0], o[1], o[2], o[3]));
                     } else {   // [rows, 2*cols]: hi | lo halves (split-precision GEMM operand)
                         const s16x4 hi = pack4<T>(o[0], o[1], o[2], o[3]);
                         const f32x4 hf = unpack4<T>(hi);
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            float d16_drop_p, unsigned d16_drop_seed, int d16_drop_site) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform for the compiler: row bases, statistics and frame lookups go to SGPRs)
     const int nv = cols >> 2;
     const float inv = 1.0f / (float)valid_cols;   // (zero-padded rows: gamma is zero-padded, so the padded columns add nothing to either mean)
     f32x4 dg[NV], db[NV];
@@ -207,8 +219,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
             const int c = i * 64 + lane;
             if (c < nv) {
                 f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
-                if (dx_add) o += *(const f32x4*)(dx_add + orow * cols + c * 4);
-                if (dx32) *(f32x4*)(dx32 + orow * cols + c * 4) = o;
+                if (dx_add) o += ld_stream((const f32x4*)(dx_add + orow * cols + c * 4));
+                if (dx32) st_stream((f32x4*)(dx32 + orow * cols + c * 4), o);
                 if (w16) {
                     o *= s16;
                     if (d16_drop_p > 0.f) {   // the dense branch sat behind a dropout in the forward: the same mask multiplies its gradient
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] *= drop_mult(d16_drop_seed, d16_drop_site, i0 + k, thr, ik);
                     }
-                    *(s16x4*)(dx16 + drow * cols + c * 4) = pack4<T>(o[0], o[1], o[2], o[3]);
+                    st_stream((s16x4*)(dx16 + drow * cols + c * 4), pack4<T>(o[0], o[1], o[2], o[3]));
                 }
             }
         }

@@ -27,7 +27,7 @@ def timeit(fn, iters=20):
 
 
 def main():
-    F, N, D = 320, 257, 1408
+    F, N, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 320), 257, 1408   # 717 = one rank of configs[3] after stochastic depth
     M = F * N
     dt = torch.bfloat16
     x = torch.randn(M, D, device=dev)
