@@ -294,6 +294,11 @@ int mico_gelu_bwd_16(const void* x, const void* dy, void* dx, int64_t n, int dty
 /* CLS pooling (mico.py:157-182): pooled[b,:] = mean_f tokens[(b*n+f)*frame_stride + 0..D); backward adds into dtokens. */
 int mico_cls_pool_fwd(const float* tokens, float* pooled, int b, int n, int64_t frame_stride, int D, void* stream);
 int mico_cls_pool_bwd(const float* dpooled, float* dtokens, int b, int n, int64_t frame_stride, int D, void* stream);
+/* pool_video (mico.py:190-191, 217-218, 233-234: torch.cat([x[:, :, 0:1], x[:, :, 1:].mean(2, keepdim=True)], dim=2)): tokens [frames, N, D] fp32
+   -> pooled [frames, 2, D] = the CLS row and the mean of the N - 1 patch rows; the backward writes every element of dtokens (no accumulate).
+   N >= 2, D % 4 == 0; frames == 0 is a no-op. */
+int mico_pool_video_fwd(const float* tokens, float* pooled, int64_t frames, int N, int D, void* stream);
+int mico_pool_video_bwd(const float* dpooled, float* dtokens, int64_t frames, int N, int D, void* stream);
 
 /* SwiGLU gate (eva_vit_model.py:217-220): h = silu(x1) * x2, 16-bit in/out, and its backward. */
 int mico_swiglu_fwd(const void* x1, const void* x2, void* h, int64_t n, int dtype, void* stream);

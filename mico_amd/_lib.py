@@ -89,6 +89,8 @@ PROTOTYPES = {
     "mico_gelu_bwd_16": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_cls_pool_fwd": [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
     "mico_cls_pool_bwd": [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
+    "mico_pool_video_fwd": [c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    "mico_pool_video_bwd": [c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "mico_l2norm_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_l2norm_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_image_preprocess": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_vp],
@@ -105,7 +107,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 109   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 110   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

@@ -737,6 +737,37 @@ __global__ void cls_pool_bwd_kernel(const float* __restrict__ dout, float* __res
         dtok[bf * frame_stride + c] += dout[(bf / n) * D + c] / (float)n;
     }
 }
+// pool_video (model/mico.py:190-191, 217-218, 233-234): tokens [F, N, D] fp32 -> out [F, 2, D]: row 0 = the frame's CLS token, row 1 = the
+// mean of its N - 1 patch tokens (summed in token order, divided once).  One thread per (frame, 4 columns): the N rows of a frame are read with
+// 16-byte loads, consecutive threads on consecutive columns.
+__global__ void pool_video_fwd_kernel(const float* __restrict__ tok, float* __restrict__ out, int64_t F, int N, int D) {
+    const int dv = D >> 2;
+    const int64_t total = F * dv;
+    const float inv = 1.f / (float)(N - 1);
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t f = i / dv;
+        const int c = (int)(i - f * dv) * 4;
+        const float* src = tok + f * N * D + c;
+        *(f32x4*)(out + (f * 2) * D + c) = *(const f32x4*)src;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 1; t < N; ++t) s += *(const f32x4*)(src + (int64_t)t * D);
+        *(f32x4*)(out + (f * 2 + 1) * D + c) = s * inv;
+    }
+}
+// dtok[f, 0, :] = dout[f, 0, :];  dtok[f, t >= 1, :] = dout[f, 1, :] / (N - 1)   (every element of dtok is written: no zero fill needed)
+__global__ void pool_video_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtok, int64_t F, int N, int D) {
+    const int dv = D >> 2;
+    const int64_t total = F * N * dv;
+    const float inv = 1.f / (float)(N - 1);
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int64_t row = i / dv;
+        const int c = (int)(i - row * dv) * 4;
+        const int64_t f = row / N;
+        const int t = (int)(row - f * N);
+        const f32x4 g = *(const f32x4*)(dout + (f * 2 + (t ? 1 : 0)) * D + c);
+        *(f32x4*)(dtok + row * D + c) = t ? g * inv : g;
+    }
+}
 }  // namespace
 
 extern "C" int mico_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
@@ -776,6 +807,23 @@ extern "C" int mico_cls_pool_fwd(const float* tokens, float* pooled, int b, int 
 extern "C" int mico_cls_pool_bwd(const float* dpooled, float* dtokens, int b, int n, int64_t frame_stride, int D, void* stream) {
     MICO_CHECK(dpooled && dtokens && b > 0 && n > 0, "mico_cls_pool_bwd: bad args");
     MICO_LAUNCH(cls_pool_bwd_kernel, dim3(egrid((int64_t)b * n * D)), dim3(EB), 0, ST, dpooled, dtokens, b, n, frame_stride, D);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_pool_video_fwd(const float* tokens, float* pooled, int64_t frames, int N, int D, void* stream) {
+    MICO_CHECK(N >= 2 && D > 0 && D % 4 == 0, "mico_pool_video_fwd: needs N >= 2 tokens per frame and D %% 4 == 0 (got N = %d, D = %d)", N, D);
+    if (frames <= 0) return MICO_OK;
+    MICO_CHECK(tokens && pooled, "mico_pool_video_fwd: null pointer");
+    MICO_LAUNCH(pool_video_fwd_kernel, dim3(egrid(frames * (D / 4))), dim3(EB), 0, ST, tokens, pooled, frames, N, D);
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+extern "C" int mico_pool_video_bwd(const float* dpooled, float* dtokens, int64_t frames, int N, int D, void* stream) {
+    MICO_CHECK(N >= 2 && D > 0 && D % 4 == 0, "mico_pool_video_bwd: needs N >= 2 tokens per frame and D %% 4 == 0 (got N = %d, D = %d)", N, D);
+    if (frames <= 0) return MICO_OK;
+    MICO_CHECK(dpooled && dtokens, "mico_pool_video_bwd: null pointer");
+    MICO_LAUNCH(pool_video_bwd_kernel, dim3(egrid(frames * N * (D / 4))), dim3(EB), 0, ST, dpooled, dtokens, frames, N, D);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -1221,6 +1221,12 @@ __global__ __launch_bounds__(Mid64::THREADS, 2) void gemm_mid_kernel(const GemmA
 // writes, the four passes of a block are unrolled (16 ds_read_b128 in flight), addresses are 32-bit offsets from a per-block scalar base,
 // and none of the generic epilogue's per-pass bookkeeping (64-bit row arithmetic, row_map / row_scale lookups, feature branches) exists.
 // The generic epilogue takes ~3.3 us per 64-row block and wave (tools/probes/gemm_phases.py), most of it exposed latency.
+#ifndef MICO_P8_NTSTORE
+#define MICO_P8_NTSTORE 0   // 1: the fast epilogue's C / aux stores carry the non-temporal hint (A/B: tools/probes/README.md)
+#endif
+template <typename V> __device__ __forceinline__ void p8_store(char* p, V v) {
+    if constexpr (MICO_P8_NTSTORE != 0) __builtin_nontemporal_store(v, (V*)p); else *(V*)p = v;
+}
 template <typename T, int ACT>
 __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x4 (&acc)[8][4], LDS_AS char* wbuf, int64_t m0, int64_t n0, int wm, int wn,
                                                    int lane) {
@@ -1286,8 +1292,8 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
                     for (int h = 0; h < 2; ++h) v[u][h] = gelu_pair4(v[u][h], d[h]);
                     const s16x4 lo = pack4<T>(d[0][0], d[0][1], d[0][2], d[0][3]), hi = pack4<T>(d[1][0], d[1][1], d[1][2], d[1][3]);
                     char* ap = abase + row * ldaux2 + gcol[u] * 2;
-                    if (ok[u][1]) *(s16x8*)ap = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    else *(s16x4*)ap = lo;
+                    if (ok[u][1]) p8_store(ap, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                    else p8_store(ap, lo);
                 } else if constexpr (ACT == MICO_ACT_MUL_AUX) {
                     const s16x8 a8 = aux[ps][u];
                     v[u][0] *= unpack4<T>((s16x4){a8[0], a8[1], a8[2], a8[3]});
@@ -1298,8 +1304,8 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
                 }
                 const s16x4 lo = pack4<T>(v[u][0][0], v[u][0][1], v[u][0][2], v[u][0][3]), hi = pack4<T>(v[u][1][0], v[u][1][1], v[u][1][2], v[u][1][3]);
                 char* cp = cbase + row * ldc2 + gcol[u] * 2;
-                if (ok[u][1]) *(s16x8*)cp = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                else *(s16x4*)cp = lo;
+                if (ok[u][1]) p8_store(cp, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                else p8_store(cp, lo);
             }
         }
     }
@@ -2778,7 +2784,7 @@ static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-
 static int g_mico_mid_group = 0;       // sweeps: variant / 100 overrides the MID kernel's tile-order group height
 extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant + 100 * g_mico_mid_group; g_mico_gemm_variant = v % 100; g_mico_mid_group = v / 100; return old; }
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 109; }
+extern "C" int mico_version(void) { return 110; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {

@@ -1151,6 +1151,30 @@ def cls_pool(tokens):
     return _ClsPool.apply(tokens)
 
 
+class _PoolVideo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens):   # [b, n, N, D] fp32
+        b, n, N, D = tokens.shape
+        tokens = tokens.contiguous()
+        out = _empty((b, n, 2, D), torch.float32, tokens.device)
+        ops.pool_video_fwd(tokens, out, b * n, N, D)
+        ctx.shape = (b, n, N, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, n, N, D = ctx.shape
+        dt = _empty(ctx.shape, torch.float32, dy.device)
+        ops.pool_video_bwd(dy.contiguous(), dt, b * n, N, D)
+        return dt
+
+
+def pool_video(tokens):
+    """torch.cat([x[:, :, 0:1], x[:, :, 1:].mean(2, keepdim=True)], dim=2)  (mico.py:190-191, 217-218, 233-234): per frame the CLS token and the
+    mean of the patch tokens, one kernel each way."""
+    return _PoolVideo.apply(tokens)
+
+
 def mean_pool(tokens):
     """feature.mean(2).mean(1) - the Swin branch of pool_*_for_contra (mico.py:161-163): every frame has the same token count, so the mean of
     the per-frame means is the mean over all n * N token rows, which the CLS-pool kernel computes when each token is its own 'frame'."""

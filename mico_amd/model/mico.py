@@ -219,7 +219,7 @@ class MMGeneralModule(nn.Module):
     def _pack(self, modality, feats):
         b, n, x, c = feats.shape
         if self.config.pool_video:
-            feats = torch.cat([feats[:, :, 0:1], feats[:, :, 1:].mean(2, keepdim=True)], dim=2)
+            feats = Fn.pool_video(feats)
             x = 2
         trans = getattr(self, f"hidden_trans_{modality}_multimodal")
         fe = getattr(self, f"{modality}_frame_embedding")

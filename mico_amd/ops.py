@@ -485,3 +485,11 @@ def cls_pool_fwd(tokens, pooled, b, n, frame_stride, D):
 
 def cls_pool_bwd(dpooled, dtokens, b, n, frame_stride, D):
     check(_lib.lib().mico_cls_pool_bwd(_p(dpooled), _p(dtokens), b, n, frame_stride, D, _st()), "mico_cls_pool_bwd")
+
+
+def pool_video_fwd(tokens, pooled, frames, N, D):
+    check(_lib.lib().mico_pool_video_fwd(_p(tokens), _p(pooled), frames, N, D, _st()), "mico_pool_video_fwd")
+
+
+def pool_video_bwd(dpooled, dtokens, frames, N, D):
+    check(_lib.lib().mico_pool_video_bwd(_p(dpooled), _p(dtokens), frames, N, D, _st()), "mico_pool_video_bwd")

@@ -828,3 +828,22 @@ def test_token_mask_bit_exact(cuda):
     assert torch.equal(t2.cpu(), ref_t) and torch.equal(l2.cpu(), ref_l)
     t3, l3 = tm(ids.to(cuda), 0.6)
     assert t3.is_cuda and ((l3 != -100).sum(1)[(ids[:, 1:] != 0).any(1)] >= 1).all()
+
+
+def test_pool_video_kernel(cuda):
+    """mico_pool_video_fwd / _bwd against torch.cat([x[:, :, 0:1], x[:, :, 1:].mean(2, keepdim=True)], dim=2) (mico.py:190-191) and its autograd
+    gradient, fp32: ViT-g's 257 x 1408 frames, B/16's 197 x 768, the smallest legal frame (2 tokens), and an empty batch."""
+    from mico_amd import functional as Fn
+    for b, n, N, D in ((2, 3, 257, 1408), (1, 8, 197, 768), (3, 1, 2, 8), (0, 4, 257, 1408)):
+        x = torch.randn((b, n, N, D), device=cuda, requires_grad=True)
+        y = Fn.pool_video(x)
+        ref = torch.cat([x[:, :, 0:1], x[:, :, 1:].mean(2, keepdim=True)], dim=2)
+        assert y.shape == ref.shape == (b, n, 2, D)
+        if b == 0:
+            continue
+        assert torch.equal(y[:, :, 0], ref[:, :, 0])
+        assert (y - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 1e-7
+        w = torch.randn_like(ref)
+        gx, = torch.autograd.grad((y * w).sum(), x)
+        gr, = torch.autograd.grad((ref * w).sum(), x)
+        assert (gx - gr).abs().max().item() <= 1e-6 * gr.abs().max().item()
