@@ -31,7 +31,8 @@ int mico_version(void);
 const char* mico_last_error_string(void);
 /* Layout of the parameter structs as THIS library was compiled, for bindings to verify theirs (tests/test_host_cpu.py compares the
  * ctypes mirror field by field): writes up to n ints - sizeof(mico_gemm_epilogue), then the byte offset of each of its fields in
- * declaration order, then -1, then sizeof(mico_attn_params), its field offsets, -1.  Returns the number of ints the full table has. */
+ * declaration order, then -1, then the same for mico_attn_params, mico_ln_fwd_params and mico_ln_bwd_params (each: sizeof, field offsets, -1).
+ * Returns the number of ints the full table has. */
 int mico_struct_layout(int* out, int n);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -161,22 +162,51 @@ int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, c
  *   valid_cols (0 = cols): the rows are zero-padded [valid_cols | 0 ...] vectors - statistics (and, in the backward, the two row means)
  *   are taken over the valid columns only; gamma / beta must be zero-padded so that the padded outputs are 0 (EVA02-CLIP-L's 2730-wide
  *   SwiGLU hidden, eva_vit_model.py:203-224, lives in 2752-wide buffers: GEMM operands need 16-byte rows).
+ *   xhat16 (optional, fp16 [rows, cols] whatever `dtype` is) receives the NORMALISED gathered rows (x - mean) * rstd rounded to fp16 - half the
+ *   bytes of x_copy, and all a backward needs next to rstd: mico_layernorm_bwd takes it as x with x_normalized = 1, and a later forward with
+ *   x = that buffer, x_dtype = MICO_F16, x_normalized = 1 re-creates the output (y = x gamma + beta: the activation diet's LayerNorm recompute;
+ *   no statistics, no copies).  fp16 for both compute types: |xhat| <= sqrt(cols), and bf16 would keep 8 bits of it.
+ *   q8 / ldq / scales (fp8 mode; the LayerNorm-fed GEMMs qkv, fc1): the 16-bit output is ALSO written as the block-scaled fp8 A operand of
+ *   mico_gemm_mx8 - q8 [rows, cols] e4m3 (row stride ldq), scales as mico_quant_mx8 lays them out ([cols / 128][rows] words of four E8M0
+ *   bytes) - bit-identical to mico_quant_mx8(y16), without its pass over y16.  cols % 128 == 0, <= 2048; the towers' subset of the features
+ *   (no y32 / post_add / dropout / split / valid_cols).
+ * Both entry points take ONE parameter struct (ABI 111; they took 24 and 28 positional arguments before - one swapped int was silent).  Zero-
+ * initialise it and set what the call uses; mico_struct_layout() reports the compiled layout of both structs.
  * ------------------------------------------------------------------------------------------------------------- */
-int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
-                       void* y16, float* y32, float* mean, float* rstd,
-                       int64_t rows, int cols, float eps,
-                       const float* post_add, int post_rows_per_group, int post_groups, int y16_split,
-                       const int* frame_map, int rows_per_frame, float* x_copy,
-                       float drop_p, unsigned drop_seed, int drop_site,
-                       int valid_cols, int dtype, void* stream);
-/* The fp8 mode's LayerNorm-fed GEMMs (qkv, fc1): as mico_layernorm_fwd (the towers' subset of its arguments), and the 16-bit output is ALSO
- * written as the block-scaled fp8 A operand of mico_gemm_mx8 - q8 [rows, cols] e4m3 (row stride ldq), scales as mico_quant_mx8 lays them out
- * ([cols / 128][rows] words of four E8M0 bytes) - bit-identical to mico_quant_mx8(y16), without its pass over y16.  cols % 128 == 0, <= 2048. */
-int mico_layernorm_fwd_mx8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* mean, float* rstd,
-                           int64_t rows, int cols, float eps, const int* frame_map, int rows_per_frame, float* x_copy,
-                           void* q8, int64_t ldq, void* scales, int dtype, void* stream);
+typedef struct mico_ln_fwd_params {
+    const void* x;              /* [rows(, gathered through frame_map), cols] */
+    int x_dtype;                /* MICO_F32 | the call's dtype | MICO_F16 with x_normalized */
+    int x_normalized;           /* != 0: x holds (x - mean) * rstd already (an earlier call's xhat16) */
+    const float* gamma;
+    const float* beta;
+    void* y16;                  /* optional 16-bit output ([rows, 2 cols] = [hi | lo] with y16_split) */
+    float* y32;                 /* optional fp32 output */
+    float* mean;                /* optional fp32 [rows] */
+    float* rstd;                /* optional fp32 [rows] */
+    int64_t rows;
+    int cols;
+    float eps;
+    const float* post_add;      /* optional fp32 [post_groups, cols] */
+    int post_rows_per_group, post_groups;
+    int y16_split;
+    const int* frame_map;       /* optional int32 [rows / rows_per_frame] */
+    int rows_per_frame;
+    float* x_copy;              /* optional fp32 [rows, cols]: the gathered input rows */
+    void* xhat16;               /* optional fp16 [rows, cols]: the gathered rows, normalised */
+    float drop_p;
+    unsigned drop_seed;
+    int drop_site;
+    int valid_cols;             /* 0 = cols */
+    void* q8;                   /* optional (fp8 mode): e4m3 [rows, ldq] */
+    int64_t ldq;
+    void* scales;               /* with q8: uint32 [cols / 128][rows] */
+} mico_ln_fwd_params;
+int mico_layernorm_fwd(const mico_ln_fwd_params* p, int dtype, void* stream);
+
 /* dx = LN'(dy_scale * dy) [+ dx_add]; dy fp32 or 16-bit (dy_dtype); outputs dx32 (may alias dx_add) and/or dx16
  * (dx16 = T(dx * scale16)).
+ * x: the forward's input rows (fp32 or 16-bit, with mean / rstd), or - x_normalized != 0, x_dtype MICO_F16 - the forward's xhat16 copy (mean is
+ * then not read and may be NULL).
  * dgamma/dbeta: partial sums are written to ws [2, nblk, cols] (nblk = mico_layernorm_bwd_nblk(rows)), then reduced
  * and ACCUMULATED (+=) into dgamma/dbeta (fp32 [cols]) scaled by grad_scale.
  * frame_map (optional): dx_add and dx32 are indexed with the scattered row
@@ -189,14 +219,37 @@ int mico_layernorm_fwd_mx8(const void* x, int x_dtype, const float* gamma, const
  * dx16_drop_p > 0: dx16 is additionally multiplied by mico_dropout's keep / (1 - p) mask of (dx16_drop_seed, dx16_drop_site, element index
  * in the [rows, cols] dx16) - the gradient side of a hidden-state dropout that sat between this LayerNorm's input and the dense layer
  * (bert.py:295,373), without the separate mico_dropout pass. */
+typedef struct mico_ln_bwd_params {
+    const void* dy;
+    int dy_dtype;
+    float dy_scale;
+    const void* x;
+    int x_dtype;
+    int x_normalized;
+    const float* gamma;
+    const float* mean;
+    const float* rstd;
+    const float* dx_add;
+    float* dx32;
+    void* dx16;
+    float scale16;
+    float* dgamma;
+    float* dbeta;
+    float grad_scale;
+    float* ws;
+    int64_t rows;
+    int cols;
+    const int* frame_map;
+    int rows_per_frame;
+    int valid_cols;
+    const int* dx16_dst;
+    const float* dx16_frame_scale;
+    float dx16_drop_p;
+    unsigned dx16_drop_seed;
+    int dx16_drop_site;
+} mico_ln_bwd_params;
 int mico_layernorm_bwd_nblk(int64_t rows);
-int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype,
-                       const float* gamma, const float* mean, const float* rstd,
-                       const float* dx_add, float* dx32, void* dx16, float scale16,
-                       float* dgamma, float* dbeta, float grad_scale, float* ws,
-                       int64_t rows, int cols, const int* frame_map, int rows_per_frame, int valid_cols,
-                       const int* dx16_dst, const float* dx16_frame_scale,
-                       float dx16_drop_p, unsigned dx16_drop_seed, int dx16_drop_site, int dtype, void* stream);
+int mico_layernorm_bwd(const mico_ln_bwd_params* p, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention (flash style: scores never materialised), forward and backward.

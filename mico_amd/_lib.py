@@ -41,6 +41,26 @@ class AttnParams(C.Structure):
     ]
 
 
+class LnFwdParams(C.Structure):
+    _fields_ = [
+        ("x", c_vp), ("x_dtype", c_int), ("x_normalized", c_int), ("gamma", c_vp), ("beta", c_vp), ("y16", c_vp), ("y32", c_vp),
+        ("mean", c_vp), ("rstd", c_vp), ("rows", c_i64), ("cols", c_int), ("eps", c_f), ("post_add", c_vp),
+        ("post_rows_per_group", c_int), ("post_groups", c_int), ("y16_split", c_int), ("frame_map", c_vp), ("rows_per_frame", c_int),
+        ("x_copy", c_vp), ("xhat16", c_vp), ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("valid_cols", c_int),
+        ("q8", c_vp), ("ldq", c_i64), ("scales", c_vp),
+    ]
+
+
+class LnBwdParams(C.Structure):
+    _fields_ = [
+        ("dy", c_vp), ("dy_dtype", c_int), ("dy_scale", c_f), ("x", c_vp), ("x_dtype", c_int), ("x_normalized", c_int), ("gamma", c_vp),
+        ("mean", c_vp), ("rstd", c_vp), ("dx_add", c_vp), ("dx32", c_vp), ("dx16", c_vp), ("scale16", c_f), ("dgamma", c_vp),
+        ("dbeta", c_vp), ("grad_scale", c_f), ("ws", c_vp), ("rows", c_i64), ("cols", c_int), ("frame_map", c_vp), ("rows_per_frame", c_int),
+        ("valid_cols", c_int), ("dx16_dst", c_vp), ("dx16_frame_scale", c_vp), ("dx16_drop_p", c_f), ("dx16_drop_seed", C.c_uint),
+        ("dx16_drop_site", c_int),
+    ]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mico_hip.h one to one
 PROTOTYPES = {
     "mico_version": [],
@@ -52,12 +72,9 @@ PROTOTYPES = {
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_quant_mx8": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_f, c_int, c_vp],
     "mico_gemm_mx8": [c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, C.POINTER(GemmEpilogue), c_int, c_vp],
-    "mico_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_int,
-                           c_int, c_vp, c_int, c_vp, c_f, C.c_uint, c_int, c_int, c_int, c_vp],
-    "mico_layernorm_fwd_mx8": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp],
+    "mico_layernorm_fwd": [C.POINTER(LnFwdParams), c_int, c_vp],
     "mico_layernorm_bwd_nblk": [c_i64],
-    "mico_layernorm_bwd": [c_vp, c_int, c_f, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_f, c_vp,
-                           c_i64, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_f, C.c_uint, c_int, c_int, c_vp],
+    "mico_layernorm_bwd": [C.POINTER(LnBwdParams), c_int, c_vp],
     "mico_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_attn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(AttnParams), c_int, c_vp],
     "mico_rope": [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
@@ -107,7 +124,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 110   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 111   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):
@@ -122,7 +139,10 @@ def _check_struct_layout(l):
             cur = []
         else:
             cur.append(v)
-    for cls, (size, *offs) in zip((GemmEpilogue, AttnParams), table):
+    classes = (GemmEpilogue, AttnParams, LnFwdParams, LnBwdParams)
+    if len(table) != len(classes):
+        raise MicoHipError(f"mico_struct_layout reports {len(table)} structs, this binding mirrors {len(classes)}")
+    for cls, (size, *offs) in zip(classes, table):
         mine = [getattr(cls, name).offset for name, _ in cls._fields_]
         if C.sizeof(cls) != size or mine != offs:
             raise MicoHipError(f"ctypes {cls.__name__} does not match the compiled struct (size {C.sizeof(cls)} vs {size}, offsets {mine} vs {offs})")

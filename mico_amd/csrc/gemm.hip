@@ -2784,7 +2784,7 @@ static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-
 static int g_mico_mid_group = 0;       // sweeps: variant / 100 overrides the MID kernel's tile-order group height
 extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant + 100 * g_mico_mid_group; g_mico_gemm_variant = v % 100; g_mico_mid_group = v / 100; return old; }
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 110; }
+extern "C" int mico_version(void) { return 111; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {
@@ -2805,6 +2805,26 @@ extern "C" int mico_struct_layout(int* out, int n) {
         OFF(mico_attn_params, v_rs), OFF(mico_attn_params, o_bs), OFF(mico_attn_params, o_rs), OFF(mico_attn_params, scale), OFF(mico_attn_params, mask),
         OFF(mico_attn_params, mask_mode), OFF(mico_attn_params, drop_p), OFF(mico_attn_params, drop_seed), OFF(mico_attn_params, drop_site),
         OFF(mico_attn_params, kv_batch_mod), OFF(mico_attn_params, batch0), OFF(mico_attn_params, dkv_accumulate),
+        -1,
+        (int)sizeof(mico_ln_fwd_params),
+        OFF(mico_ln_fwd_params, x), OFF(mico_ln_fwd_params, x_dtype), OFF(mico_ln_fwd_params, x_normalized), OFF(mico_ln_fwd_params, gamma),
+        OFF(mico_ln_fwd_params, beta), OFF(mico_ln_fwd_params, y16), OFF(mico_ln_fwd_params, y32), OFF(mico_ln_fwd_params, mean),
+        OFF(mico_ln_fwd_params, rstd), OFF(mico_ln_fwd_params, rows), OFF(mico_ln_fwd_params, cols), OFF(mico_ln_fwd_params, eps),
+        OFF(mico_ln_fwd_params, post_add), OFF(mico_ln_fwd_params, post_rows_per_group), OFF(mico_ln_fwd_params, post_groups),
+        OFF(mico_ln_fwd_params, y16_split), OFF(mico_ln_fwd_params, frame_map), OFF(mico_ln_fwd_params, rows_per_frame),
+        OFF(mico_ln_fwd_params, x_copy), OFF(mico_ln_fwd_params, xhat16), OFF(mico_ln_fwd_params, drop_p), OFF(mico_ln_fwd_params, drop_seed),
+        OFF(mico_ln_fwd_params, drop_site), OFF(mico_ln_fwd_params, valid_cols), OFF(mico_ln_fwd_params, q8), OFF(mico_ln_fwd_params, ldq),
+        OFF(mico_ln_fwd_params, scales),
+        -1,
+        (int)sizeof(mico_ln_bwd_params),
+        OFF(mico_ln_bwd_params, dy), OFF(mico_ln_bwd_params, dy_dtype), OFF(mico_ln_bwd_params, dy_scale), OFF(mico_ln_bwd_params, x),
+        OFF(mico_ln_bwd_params, x_dtype), OFF(mico_ln_bwd_params, x_normalized), OFF(mico_ln_bwd_params, gamma), OFF(mico_ln_bwd_params, mean),
+        OFF(mico_ln_bwd_params, rstd), OFF(mico_ln_bwd_params, dx_add), OFF(mico_ln_bwd_params, dx32), OFF(mico_ln_bwd_params, dx16),
+        OFF(mico_ln_bwd_params, scale16), OFF(mico_ln_bwd_params, dgamma), OFF(mico_ln_bwd_params, dbeta), OFF(mico_ln_bwd_params, grad_scale),
+        OFF(mico_ln_bwd_params, ws), OFF(mico_ln_bwd_params, rows), OFF(mico_ln_bwd_params, cols), OFF(mico_ln_bwd_params, frame_map),
+        OFF(mico_ln_bwd_params, rows_per_frame), OFF(mico_ln_bwd_params, valid_cols), OFF(mico_ln_bwd_params, dx16_dst),
+        OFF(mico_ln_bwd_params, dx16_frame_scale), OFF(mico_ln_bwd_params, dx16_drop_p), OFF(mico_ln_bwd_params, dx16_drop_seed),
+        OFF(mico_ln_bwd_params, dx16_drop_site),
         -1,
     };
 #undef OFF

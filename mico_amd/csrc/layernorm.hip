@@ -48,7 +48,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                                                            int post_groups, int split16,
                                                            const int* __restrict__ frame_map, int rpf,
                                                            float* __restrict__ x_copy, float drop_p, unsigned drop_seed,
-                                                           int drop_site, int valid_cols, unsigned char* __restrict__ q8 = nullptr,
+                                                           int drop_site, int valid_cols, f16* __restrict__ xhat16, int x_norm,
+                                                           unsigned char* __restrict__ q8 = nullptr,
                                                            int64_t ldq = 0, unsigned* __restrict__ sc8 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform for the compiler: row bases, statistics and frame lookups go to SGPRs)
@@ -88,20 +89,25 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
-        const float mean = wave_sum(s) * inv;
-        float q = 0.f;
+        // x_norm: the input rows ARE (x - mean) * rstd already (the 16-bit xhat16 copy an earlier forward left for the backward - the
+        // activation diet's LayerNorm recompute): no statistics, y = x gamma + beta
+        float mean = 0.f, rstd = 1.f;
+        if (!x_norm) {
+            mean = wave_sum(s) * inv;
+            float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = i * 64 + lane;
-            if (c < nv) {
-                f32x4 d = v[i] - mean;
-                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 64 + lane;
+                if (c < nv) {
+                    f32x4 d = v[i] - mean;
+                    q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                }
             }
-        }
-        const float rstd = rsqrtf(fmaxf(wave_sum(q) - npad * mean * mean, 0.f) * inv + eps);
-        if (lane == 0) {
-            if (mean_o) mean_o[row] = mean;
-            if (rstd_o) rstd_o[row] = rstd;
+            rstd = rsqrtf(fmaxf(wave_sum(q) - npad * mean * mean, 0.f) * inv + eps);
+            if (lane == 0) {
+                if (mean_o) mean_o[row] = mean;
+                if (rstd_o) rstd_o[row] = rstd;
+            }
         }
         const float* pa = (!LEAN && post_add) ? post_add + (int64_t)((row / post_rpg) % post_groups) * cols : nullptr;
 #pragma unroll
@@ -111,7 +117,9 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
                 // (gamma / beta are re-read per row from L1: held in registers across rows they push the kernel past 128 VGPRs and
                 // it loses more occupancy than the saved L1 traffic buys - measured 207 vs 181 us at the tower shape)
                 f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
-                f32x4 o = (v[i] - mean) * rstd * g + b;
+                const f32x4 nh = (v[i] - mean) * rstd;
+                if (xhat16) st_stream((s16x4*)(xhat16 + row * cols + c * 4), pack4<f16>(nh[0], nh[1], nh[2], nh[3]));
+                f32x4 o = nh * g + b;
                 if (pa) o += *(const f32x4*)(pa + c * 4);
                 if (!LEAN && drop_p > 0.f) {
                     const unsigned thr = drop_threshold(drop_p);
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
                                                            float* __restrict__ ws, int64_t rows, int cols, float dy_scale,
                                                            const int* __restrict__ frame_map, int rpf, int valid_cols,
                                                            const int* __restrict__ dx16_dst, const float* __restrict__ dx16_fscale,
-                                                           float d16_drop_p, unsigned d16_drop_seed, int d16_drop_site) {
+                                                           float d16_drop_p, unsigned d16_drop_seed, int d16_drop_site, int x_norm) {
     __shared__ f32x4 red[2][4][64];   // per (gamma/beta, wave, lane) scratch, reused per column slab
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform for the compiler: row bases, statistics and frame lookups go to SGPRs)
@@ -181,7 +189,9 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
         db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
+        // x_norm: x holds the normalised rows (x - mean) * rstd themselves (the forward's 16-bit xhat16 copy): no mean needed
+        const float rs = rstd[row];
+        const float mu = x_norm ? 0.f : mean[row], xs = x_norm ? 1.f : rs;
         f32x4 xh[NV], g[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__
             const int c = i * 64 + lane;
             if (c < nv) {
                 f32x4 d = RowIO<DT>::load(dy + row * cols + c * 4) * dy_scale;
-                xh[i] = (RowIO<XT>::load(x + row * cols + c * 4) - mu) * rs;
+                xh[i] = (RowIO<XT>::load(x + row * cols + c * 4) - mu) * xs;
                 g[i] = d * *(const f32x4*)(gamma + c * 4);
                 dg[i] += d * xh[i];
                 db[i] += d;
@@ -297,12 +307,22 @@ int ln_grid(int64_t rows, int cap) {
 extern "C" int mico_layernorm_bwd_nblk(int64_t rows);
 
 template <typename T, typename XT>
-void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma, const float* beta, void* y16, float* y32,
-                   float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add, int rpg, int groups, int split16,
-                   const int* fmap, int rpf, float* x_copy, float dp, unsigned dseed, int dsite, int valid) {
-#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite, valid)
-    if (!post_add && dp == 0.f && !y32 && !split16 && cols > 1024 && cols <= 1536) {
-        MICO_LAUNCH((ln_fwd_kernel<T, XT, 6, true>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, y32, mean, rstd, rows, cols, eps, post_add, rpg, groups, split16, fmap, rpf, x_copy, dp, dseed, dsite, valid);
+void ln_fwd_launch(dim3 grid, hipStream_t st, const mico_ln_fwd_params& p, int valid) {
+    const int cols = p.cols;
+    unsigned char* q8 = (unsigned char*)p.q8;
+    unsigned* sc8 = (unsigned*)p.scales;
+#define LN_ARGS (const XT*)p.x, p.gamma, p.beta, (T*)p.y16, p.y32, p.mean, p.rstd, p.rows, cols, p.eps, p.post_add, p.post_rows_per_group, \
+                p.post_groups, p.y16_split, p.frame_map, p.rows_per_frame, p.x_copy, p.drop_p, p.drop_seed, p.drop_site, valid, (f16*)p.xhat16, \
+                p.x_normalized
+    if (q8) {   // fp8 mode: the 16-bit output also as the block-scaled e4m3 operand (cols % 128 == 0, <= 2048: checked by the caller)
+#define LNMX(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV, false, true>), grid, dim3(LN_BLOCK), 0, st, LN_ARGS, q8, p.ldq, sc8)
+        if (cols <= 1024) LNMX(4); else if (cols <= 1536) LNMX(6); else LNMX(8);
+#undef LNMX
+        return;
+    }
+#define LNF(NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV>), grid, dim3(LN_BLOCK), 0, st, LN_ARGS)
+    if (!p.post_add && p.drop_p == 0.f && !p.y32 && !p.y16_split && cols > 1024 && cols <= 1536) {
+        MICO_LAUNCH((ln_fwd_kernel<T, XT, 6, true>), grid, dim3(LN_BLOCK), 0, st, LN_ARGS);
         return;
     }
     if (cols <= 1024) LNF(4);
@@ -311,14 +331,15 @@ void ln_fwd_launch(dim3 grid, hipStream_t st, const void* x, const float* gamma,
     else if (cols <= 3072) LNF(12);
     else LNF(16);
 #undef LNF
+#undef LN_ARGS
 }
 
 template <typename T, typename DT, typename XT>
-void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean,
-                   const float* rstd, const float* dx_add, float* dx32, void* dx16, float scale16, float* ws, int64_t rows,
-                   int cols, float dy_scale, const int* fmap, int rpf, int valid, const int* d16dst, const float* d16scale, float d16p,
-                   unsigned d16seed, int d16site) {
-#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)dy, (const XT*)x, gamma, mean, rstd, dx_add, dx32, (T*)dx16, scale16, ws, rows, cols, dy_scale, fmap, rpf, valid, d16dst, d16scale, d16p, d16seed, d16site)
+void ln_bwd_launch(dim3 grid, hipStream_t st, const mico_ln_bwd_params& p, float* wsp, int valid) {
+    const int cols = p.cols;
+#define LNB(NV) MICO_LAUNCH((ln_bwd_kernel<T, DT, XT, NV>), grid, dim3(LN_BLOCK), 0, st, (const DT*)p.dy, (const XT*)p.x, p.gamma, p.mean, p.rstd, \
+                            p.dx_add, p.dx32, (T*)p.dx16, p.scale16, wsp, p.rows, cols, p.dy_scale, p.frame_map, p.rows_per_frame, valid, p.dx16_dst, \
+                            p.dx16_frame_scale, p.dx16_drop_p, p.dx16_drop_seed, p.dx16_drop_site, p.x_normalized)
     if (cols <= 1024) LNB(4);
     else if (cols <= 1536) LNB(6);
     else if (cols <= 2048) LNB(8);
@@ -331,84 +352,76 @@ void ln_bwd_launch(dim3 grid, hipStream_t st, const void* dy, const void* x, con
 
 extern "C" int mico_layernorm_bwd_nblk(int64_t rows) { return ln_grid(rows, 2048); }
 
-extern "C" int mico_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* y32,
-                                  float* mean, float* rstd, int64_t rows, int cols, float eps, const float* post_add,
-                                  int post_rows_per_group, int post_groups, int y16_split, const int* frame_map,
-                                  int rows_per_frame, float* x_copy, float drop_p, unsigned drop_seed, int drop_site,
-                                  int valid_cols, int dtype, void* stream) {
+extern "C" int mico_layernorm_fwd(const mico_ln_fwd_params* pp, int dtype, void* stream) {
+    MICO_CHECK(pp != nullptr, "mico_layernorm_fwd: null parameter struct");
+    const mico_ln_fwd_params& p = *pp;
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd: bad dtype");
-    if (valid_cols <= 0) valid_cols = cols;
+    const int cols = p.cols;
+    const int valid_cols = p.valid_cols <= 0 ? cols : p.valid_cols;
     MICO_CHECK(valid_cols <= cols, "mico_layernorm_fwd: valid_cols > cols");
-    if (rows <= 0) return MICO_OK;   // an empty batch is a no-op (its tensors have no storage to point to)
-    MICO_CHECK(x && gamma && beta && (y16 || y32), "mico_layernorm_fwd: null pointer");
+    if (p.rows <= 0) return MICO_OK;   // an empty batch is a no-op (its tensors have no storage to point to)
+    MICO_CHECK(p.x && p.gamma && p.beta && (p.y16 || p.y32), "mico_layernorm_fwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= MAXV * 256, "mico_layernorm_fwd: cols must be a multiple of 4 and <= %d (got %d)", MAXV * 256, cols);
-    MICO_CHECK(x_dtype == MICO_F32 || x_dtype == dtype, "mico_layernorm_fwd: x_dtype must be fp32 or dtype");
-    if (post_add) MICO_CHECK(post_rows_per_group > 0 && post_groups > 0, "mico_layernorm_fwd: bad post_add grouping");
-    if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_fwd: frame_map needs rows_per_frame > 0");
-    if (rows <= 0) return MICO_OK;
+    if (p.x_normalized) {
+        MICO_CHECK(p.x_dtype == MICO_F16, "mico_layernorm_fwd: a normalised input (x_normalized) is the fp16 xhat16 copy of an earlier forward");
+        MICO_CHECK(!p.mean && !p.rstd && !p.x_copy && !p.xhat16, "mico_layernorm_fwd: x_normalized produces no statistics and no input copies");
+    } else {
+        MICO_CHECK(p.x_dtype == MICO_F32 || p.x_dtype == dtype, "mico_layernorm_fwd: x_dtype must be fp32 or dtype");
+    }
+    if (p.post_add) MICO_CHECK(p.post_rows_per_group > 0 && p.post_groups > 0, "mico_layernorm_fwd: bad post_add grouping");
+    if (p.frame_map) MICO_CHECK(p.rows_per_frame > 0, "mico_layernorm_fwd: frame_map needs rows_per_frame > 0");
+    if (p.q8) {
+        MICO_CHECK(p.y16 && p.scales, "mico_layernorm_fwd: the fp8 operand (q8) needs y16 and scales");
+        MICO_CHECK(cols % 128 == 0 && cols <= 2048, "mico_layernorm_fwd: the fp8 operand needs cols %% 128 == 0 and <= 2048 (got %d)", cols);
+        MICO_CHECK(p.ldq >= cols && p.ldq % 8 == 0, "mico_layernorm_fwd: ldq must be >= cols and a multiple of 8");
+        MICO_CHECK(!p.y32 && !p.post_add && p.drop_p == 0.f && !p.y16_split && valid_cols == cols, "mico_layernorm_fwd: the fp8 operand form takes the towers' subset of the features");
+    }
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ln_grid(rows, 1024));
+    const dim3 grid(ln_grid(p.rows, 1024));
     DISPATCH_T16(dtype, {
-        if (x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site, valid_cols);
-        else ln_fwd_launch<T, T>(grid, st, x, gamma, beta, y16, y32, mean, rstd, rows, cols, eps, post_add, post_rows_per_group, post_groups, y16_split, frame_map, rows_per_frame, x_copy, drop_p, drop_seed, drop_site, valid_cols);
+        if (p.x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, p, valid_cols);
+        else if (p.x_dtype == dtype) ln_fwd_launch<T, T>(grid, st, p, valid_cols);
+        else ln_fwd_launch<T, f16>(grid, st, p, valid_cols);     // (the fp16 xhat16 rows under bf16 compute)
     });
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }
 
-extern "C" int mico_layernorm_fwd_mx8(const void* x, int x_dtype, const float* gamma, const float* beta, void* y16, float* mean, float* rstd,
-                                      int64_t rows, int cols, float eps, const int* frame_map, int rows_per_frame, float* x_copy,
-                                      void* q8, int64_t ldq, void* scales, int dtype, void* stream) {
-    MICO_CHECK(dtype_ok(dtype), "mico_layernorm_fwd_mx8: bad dtype");
-    if (rows <= 0) return MICO_OK;
-    MICO_CHECK(x && gamma && beta && y16 && q8 && scales, "mico_layernorm_fwd_mx8: null pointer");
-    MICO_CHECK(cols % 128 == 0 && cols > 0 && cols <= 2048, "mico_layernorm_fwd_mx8: cols must be a multiple of 128 and <= 2048 (got %d)", cols);
-    MICO_CHECK(ldq >= cols && ldq % 8 == 0, "mico_layernorm_fwd_mx8: ldq must be >= cols and a multiple of 8");
-    MICO_CHECK(x_dtype == MICO_F32 || x_dtype == dtype, "mico_layernorm_fwd_mx8: x_dtype must be fp32 or dtype");
-    if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_fwd_mx8: frame_map needs rows_per_frame > 0");
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ln_grid(rows, 1024));
-#define LNMX(XT, NV) MICO_LAUNCH((ln_fwd_kernel<T, XT, NV, false, true>), grid, dim3(LN_BLOCK), 0, st, (const XT*)x, gamma, beta, (T*)y16, (float*)nullptr, mean, rstd, rows, cols, eps, (const float*)nullptr, 0, 0, 0, frame_map, rows_per_frame, x_copy, 0.f, 0u, 0, cols, (unsigned char*)q8, ldq, (unsigned*)scales)
-    DISPATCH_T16(dtype, {
-        if (x_dtype == MICO_F32) { if (cols <= 1024) LNMX(float, 4); else if (cols <= 1536) LNMX(float, 6); else LNMX(float, 8); }
-        else { if (cols <= 1024) LNMX(T, 4); else if (cols <= 1536) LNMX(T, 6); else LNMX(T, 8); }
-    });
-#undef LNMX
-    MICO_LAUNCH_CHECK();
-    return MICO_OK;
-}
-
-extern "C" int mico_layernorm_bwd(const void* dy, int dy_dtype, float dy_scale, const void* x, int x_dtype, const float* gamma,
-                                  const float* mean, const float* rstd, const float* dx_add, float* dx32, void* dx16,
-                                  float scale16, float* dgamma, float* dbeta, float grad_scale, float* ws, int64_t rows,
-                                  int cols, const int* frame_map, int rows_per_frame, int valid_cols,
-                                  const int* dx16_dst, const float* dx16_frame_scale, float dx16_drop_p, unsigned dx16_drop_seed,
-                                  int dx16_drop_site, int dtype, void* stream) {
+extern "C" int mico_layernorm_bwd(const mico_ln_bwd_params* pp, int dtype, void* stream) {
+    MICO_CHECK(pp != nullptr, "mico_layernorm_bwd: null parameter struct");
+    const mico_ln_bwd_params& p = *pp;
     MICO_CHECK(dtype_ok(dtype), "mico_layernorm_bwd: bad dtype");
-    MICO_CHECK(dx16_drop_p >= 0.f && dx16_drop_p < 1.f && (dx16_drop_p == 0.f || dx16), "mico_layernorm_bwd: dx16_drop_p must be in [0, 1) and needs dx16");
-    if (dx16_dst) MICO_CHECK(dx16 && rows_per_frame > 0, "mico_layernorm_bwd: dx16_dst needs dx16 and rows_per_frame > 0");
-    if (valid_cols <= 0) valid_cols = cols;
+    MICO_CHECK(p.dx16_drop_p >= 0.f && p.dx16_drop_p < 1.f && (p.dx16_drop_p == 0.f || p.dx16), "mico_layernorm_bwd: dx16_drop_p must be in [0, 1) and needs dx16");
+    if (p.dx16_dst) MICO_CHECK(p.dx16 && p.rows_per_frame > 0, "mico_layernorm_bwd: dx16_dst needs dx16 and rows_per_frame > 0");
+    const int cols = p.cols;
+    const int valid_cols = p.valid_cols <= 0 ? cols : p.valid_cols;
     MICO_CHECK(valid_cols <= cols, "mico_layernorm_bwd: valid_cols > cols");
-    if (rows <= 0) return MICO_OK;
-    if (frame_map) MICO_CHECK(rows_per_frame > 0, "mico_layernorm_bwd: frame_map needs rows_per_frame > 0");
-    MICO_CHECK(dy && x && gamma && mean && rstd, "mico_layernorm_bwd: null pointer");
+    if (p.rows <= 0) return MICO_OK;
+    if (p.frame_map) MICO_CHECK(p.rows_per_frame > 0, "mico_layernorm_bwd: frame_map needs rows_per_frame > 0");
+    MICO_CHECK(p.dy && p.x && p.gamma && p.rstd && (p.mean || p.x_normalized), "mico_layernorm_bwd: null pointer");
     MICO_CHECK(cols % 4 == 0 && cols > 0 && cols <= 3072, "mico_layernorm_bwd: cols must be a multiple of 4 and <= 3072 (got %d)", cols);
-    MICO_CHECK((dy_dtype == MICO_F32 || dy_dtype == dtype) && (x_dtype == MICO_F32 || x_dtype == dtype), "mico_layernorm_bwd: bad in dtype");
-    MICO_CHECK(!(dgamma || dbeta) || ws, "mico_layernorm_bwd: dgamma/dbeta need a workspace");
-    if (rows <= 0) return MICO_OK;
+    MICO_CHECK(p.dy_dtype == MICO_F32 || p.dy_dtype == dtype, "mico_layernorm_bwd: bad dy dtype");
+    if (p.x_normalized) MICO_CHECK(p.x_dtype == MICO_F16, "mico_layernorm_bwd: a normalised x (x_normalized) is the fp16 xhat16 copy of the forward");
+    else MICO_CHECK(p.x_dtype == MICO_F32 || p.x_dtype == dtype, "mico_layernorm_bwd: bad x dtype");
+    MICO_CHECK(!(p.dgamma || p.dbeta) || p.ws, "mico_layernorm_bwd: dgamma/dbeta need a workspace");
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = ln_grid(rows, 2048);
+    const int nblk = ln_grid(p.rows, 2048);
     const dim3 grid(nblk);
-    float* wsp = (dgamma || dbeta) ? ws : nullptr;
+    float* wsp = (p.dgamma || p.dbeta) ? p.ws : nullptr;
     DISPATCH_T16(dtype, {
-        if (dy_dtype == MICO_F32 && x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
-        else if (dy_dtype == MICO_F32) ln_bwd_launch<T, float, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
-        else if (x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
-        else ln_bwd_launch<T, T, T>(grid, st, dy, x, gamma, mean, rstd, dx_add, dx32, dx16, scale16, wsp, rows, cols, dy_scale, frame_map, rows_per_frame, valid_cols, dx16_dst, dx16_frame_scale, dx16_drop_p, dx16_drop_seed, dx16_drop_site);
+        if (p.dy_dtype == MICO_F32) {
+            if (p.x_dtype == MICO_F32) ln_bwd_launch<T, float, float>(grid, st, p, wsp, valid_cols);
+            else if (p.x_dtype == dtype) ln_bwd_launch<T, float, T>(grid, st, p, wsp, valid_cols);
+            else ln_bwd_launch<T, float, f16>(grid, st, p, wsp, valid_cols);
+        } else {
+            if (p.x_dtype == MICO_F32) ln_bwd_launch<T, T, float>(grid, st, p, wsp, valid_cols);
+            else if (p.x_dtype == dtype) ln_bwd_launch<T, T, T>(grid, st, p, wsp, valid_cols);
+            else ln_bwd_launch<T, T, f16>(grid, st, p, wsp, valid_cols);     // (the fp16 xhat16 rows under bf16 compute)
+        }
     });
     MICO_LAUNCH_CHECK();
     if (wsp) {
-        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 31) / 32, nblk >= 64 ? 16 : 1), dim3(256), 0, st, wsp, nblk, cols, dgamma, dbeta, grad_scale);
+        MICO_LAUNCH(ln_bwd_reduce_kernel, dim3((cols + 31) / 32, nblk >= 64 ? 16 : 1), dim3(256), 0, st, wsp, nblk, cols, p.dgamma, p.dbeta, p.grad_scale);
         MICO_LAUNCH_CHECK();
     }
     return MICO_OK;

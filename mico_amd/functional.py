@@ -120,7 +120,7 @@ class _ArenaSession:
     def __init__(self, arena, private=()):
         self.arena, self.touched = arena, set()
         self.flat = arena.flat
-        self.private, self.own = frozenset(private), {}
+        self.private, self.own, self.own_fused = frozenset(private), {}, {}
 
     def get(self, i):
         if i in self.private:
@@ -131,10 +131,24 @@ class _ArenaSession:
         return self.arena.get(i)
 
     def fused(self, idxs, shape):
+        if any(i in self.private for i in idxs):   # a private group: ONE buffer of this node's own, the members' views adjacent in it
+            assert all(i in self.private for i in idxs), "a fused group is private as a whole"
+            key = tuple(idxs)
+            if key not in self.own_fused:
+                sizes = [math.prod(self.arena.shapes[i]) for i in idxs]
+                buf = torch.zeros(sum(sizes), dtype=torch.float32, device=self.arena.flat.device)
+                o = 0
+                for i, n in zip(idxs, sizes):
+                    assert i not in self.own
+                    self.own[i] = buf[o:o + n].view(self.arena.shapes[i])
+                    o += n
+                self.own_fused[key] = buf
+            return self.own_fused[key].view(shape)
         self.touched.update(idxs)
         return self.arena.fused(idxs, shape)
 
     def span(self, i0, i1):
+        assert not any(i in self.private for i in range(i0, i1))
         self.touched.update(range(i0, i1))
         return self.arena.span(i0, i1)
 
@@ -227,22 +241,25 @@ class _Operand16:
         self.t, self.mx8 = t, None
 
 
-def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None, valid_cols=0, mx8_for=None):
+def _ln16(x, g, b, eps, rows, cols, dt, dev, frame_map=None, rows_per_frame=0, x_copy=None, valid_cols=0, mx8_for=None, xhat=None,
+          x_normalized=False):
     """LayerNorm -> 16-bit GEMM operand.  Returns (buf, view, mean, rstd); in the split-precision (fp16 parity) mode buf is
-    [rows, 2*cols] = [hi | lo] and view its hi half.  frame_map: compacting gather of whole frames (rows = kept rows)."""
+    [rows, 2*cols] = [hi | lo] and view its hi half.  frame_map: compacting gather of whole frames (rows = kept rows).
+    xhat: fp16 [rows, cols] buffer that receives the normalised rows (what the backward keeps instead of an fp32 copy, TowerDiet.xh16);
+    x_normalized: x IS such a buffer - the output is re-created from it (no statistics: mean / rstd come back as None)."""
     split = runtime.split_activations() and cols % 64 == 0
     buf = _empty((rows, 2 * cols if split else cols), dt, dev)
-    mean, rstd = _empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev)
+    mean, rstd = (None, None) if x_normalized else (_empty((rows,), torch.float32, dev), _empty((rows,), torch.float32, dev))
     if mx8_for is not None and not split and not valid_cols and runtime.fp8_enabled() and runtime.CFG.fp8_fused_quant and cols % 128 == 0 \
             and cols <= 2048 and _mx8_worthwhile(rows, mx8_for):
         # fp8 mode: the GEMM this LayerNorm feeds takes a block-scaled fp8 operand - written by the LayerNorm itself (== quant_mx8 of the
         # 16-bit output, without that pass); the operand rides on the buffer object to _gemm_fwd
         buf = _Operand16(buf)
         buf.mx8 = ops.layernorm_fwd_mx8(x, g, b, eps, out16=buf.t, mean=mean, rstd=rstd, dtype=dt, frame_map=frame_map,
-                                        rows_per_frame=rows_per_frame, x_copy=x_copy)
+                                        rows_per_frame=rows_per_frame, x_copy=x_copy, xhat16=xhat, x_normalized=x_normalized)
         return buf, buf.t, mean, rstd
     ops.layernorm_fwd(x, g, b, eps, out16=buf, mean=mean, rstd=rstd, split16=split, dtype=dt, frame_map=frame_map,
-                      rows_per_frame=rows_per_frame, x_copy=x_copy, valid_cols=valid_cols)
+                      rows_per_frame=rows_per_frame, x_copy=x_copy, valid_cols=valid_cols, xhat16=xhat, x_normalized=x_normalized)
     return buf, (buf[:, :cols] if split else buf), mean, rstd
 
 
@@ -285,6 +302,35 @@ def _qkv_params(P, b, arch):
     if arch["subln"]:
         return [P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")]
     return [P(b + "attn.qkv.weight")]
+
+
+class TowerDiet:
+    """What one tower pass keeps per block for its hand-written backward (runtime.set_activation_diet, tower_plan).
+    keep_mlp[i]: block i keeps its two MLP intermediates (GELU output, GELU': 4 hidden bytes per token) - otherwise the backward re-runs fc1
+    with the GELU-pair epilogue;  keep_ln[i]: it keeps its two LayerNorm outputs (4 D) - otherwise they are re-created from the saved
+    LayerNorm input rows;  xh16: those input rows are kept as fp16 NORMALISED rows (x - mean) * rstd (mico_ln_fwd_params::xhat16, 2 x 2 D
+    bytes per token and block) instead of fp32 copies (2 x 4 D): all the LayerNorm backward needs next to rstd, and y = xhat gamma + beta
+    re-creates the output.  The forward's values do not depend on any of this; with xh16 the backward sees the normalised rows rounded to fp16
+    (relative 2^-12: its LayerNorm outputs can differ from the forward's in the last bit - far inside the gradient tolerances, but not the
+    bit-for-bit recompute of the fp32 copies, which is why a step that fits without it does not use it).
+    level: the legacy uniform levels 0 (keep all) / 1 (no MLP intermediates) / 2 (nor LayerNorm outputs) with fp32 rows, 3 = xh16 rows with
+    nothing else kept except the MLP intermediates of the LAST mlp_blocks blocks (the first ones the backward frees)."""
+    __slots__ = ("xh16", "keep_mlp", "keep_ln", "level", "mlp_blocks")
+
+    def __init__(self, depth, level=0, mlp_blocks=0):
+        level = int(level)
+        assert 0 <= level <= 3
+        self.level, self.xh16 = level, level == 3
+        self.mlp_blocks = depth if level == 0 else (min(depth, max(0, int(mlp_blocks))) if level == 3 else 0)
+        self.keep_mlp = [level == 0 or (level == 3 and i >= depth - self.mlp_blocks) for i in range(depth)]
+        self.keep_ln = [level <= 1] * depth
+
+    @classmethod
+    def of(cls, diet, depth):
+        return diet if isinstance(diet, cls) else cls(depth, diet or 0)
+
+    def describe(self):
+        return self.level if self.level < 3 else f"3 (fp16 normalised rows; MLP intermediates kept in the last {self.mlp_blocks} of {len(self.keep_mlp)} blocks)"
 
 
 class DropPlan:
@@ -475,6 +521,8 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
         plan = DropPlan(dp_scale, Bf, dev) if dp_scale is not None else None
     if arch["swiglu"]:
         diet = 0      # (the SwiGLU towers keep everything: B/16 and L/14 frames are an order of magnitude smaller)
+    diet = TowerDiet.of(diet, depth)
+    xh16 = diet.xh16 and save
     x = _empty((M, D), torch.float32, dev)
     # ---- patch embedding: im2row + GEMM(+bias +pos, patch rows -> token rows) ; CLS rows ----
     pe_w, pe_b, pos = P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed")
@@ -522,9 +570,10 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
         a.update(B1=B1, fmap1=fmap1, sc1=sc1, tr1=plan.transition(i, 0) if plan is not None else None)
         if B1 > 0:
             M1 = B1 * N
-            xc1 = _empty((M1, D), torch.float32, dev) if fmap1 is not None else None
+            xc1 = _empty((M1, D), torch.float32, dev) if (fmap1 is not None and save and not xh16) else None
+            xh1 = _empty((M1, D), torch.float16, dev) if xh16 else None
             ln1b, ln1, mean1, rstd1 = _ln16(x, P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev,
-                                            frame_map=fmap1, rows_per_frame=N, x_copy=xc1, mx8_for=3 * D)
+                                            frame_map=fmap1, rows_per_frame=N, x_copy=xc1, xhat=xh1, mx8_for=3 * D)
             qb, vb = P(b + "attn.q_bias").detach(), P(b + "attn.v_bias").detach()
             qkv_bias = torch.cat((qb, torch.zeros_like(qb), vb))
             qkv = _empty((M1, 3 * D), dt, dev)
@@ -542,20 +591,23 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
                 a.update(aln=aln, mean_a=mean_a, rstd_a=rstd_a)
             # every frame kept: out of place, the input buffer itself is the saved LN input; otherwise the epilogue
             # scatters the kept frames onto the stream in place and the LN's compact copy (xc1) is what is saved
-            x_mid = _empty((M, D), torch.float32, dev) if fmap1 is None else x
+            # (with the fp16 normalised rows kept instead, nothing reads the stream again: in place either way)
+            x_mid = _empty((M, D), torch.float32, dev) if (fmap1 is None and save and not xh16) else x
             _gemm_fwd(proj_in, D, [P(b + "attn.proj.weight")], "w", x_mid, bias=P(b + "attn.proj.bias"), resid=x, row_scale=sc1,
                       rows_per_scale=N, row_map=fmap1, rows_per_map=N, ln=bool(arch["subln"]))
-            a.update(x1=x if fmap1 is None else xc1, mean1=mean1, rstd1=rstd1, ln1=None if diet >= 2 else ln1, qkv=qkv, ao=ao, lse=lse)
+            a.update(x1=xh1 if xh16 else (x if fmap1 is None else xc1), xn=xh16, mean1=mean1, rstd1=rstd1, ln1=ln1 if diet.keep_ln[i] else None,
+                     qkv=qkv, ao=ao, lse=lse)
             x = x_mid
         # --- MLP branch ---
         B2, fmap2, sc2 = branch_io(i, 1)
         a.update(B2=B2, fmap2=fmap2, sc2=sc2, tr2=plan.transition(i, 1) if plan is not None else None)
         if B2 > 0:
             M2 = B2 * N
-            xc2 = _empty((M2, D), torch.float32, dev) if fmap2 is not None else None
+            xc2 = _empty((M2, D), torch.float32, dev) if (fmap2 is not None and save and not xh16) else None
+            xh2 = _empty((M2, D), torch.float16, dev) if xh16 else None
             ln2b, ln2, mean2, rstd2 = _ln16(x, P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev,
-                                            frame_map=fmap2, rows_per_frame=N, x_copy=xc2, mx8_for=None if arch["swiglu"] else spec.hidden)
-            x_out = _empty((M, D), torch.float32, dev) if fmap2 is None else x
+                                            frame_map=fmap2, rows_per_frame=N, x_copy=xc2, xhat=xh2, mx8_for=None if arch["swiglu"] else spec.hidden)
+            x_out = _empty((M, D), torch.float32, dev) if (fmap2 is None and save and not xh16) else x
             epi = dict(resid=x, row_scale=sc2, rows_per_scale=N, row_map=fmap2, rows_per_map=N)
             if arch["swiglu"]:
                 Hp = spec.hidden_pad                     # == Hd unless the hidden width needs padding (see TowerSpec)
@@ -584,18 +636,18 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
                 a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
             else:
                 act = _empty((M2, Hd), dt, dev)
-                if (save and diet == 0) or runtime.fp8_enabled() or not runtime.CFG.fc1_plain_gelu:   # (the 8-phase fp8 kernel has the pair epilogue only)
+                if (save and diet.keep_mlp[i]) or runtime.fp8_enabled() or not runtime.CFG.fc1_plain_gelu:   # (the 8-phase fp8 kernel has the pair epilogue only)
                     h = _empty((M2, Hd), dt, dev)
                     _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
-                    if diet == 0:
+                    if diet.keep_mlp[i]:
                         a.update(h=h, act=act)
                     del h
                 else:   # nobody will read GELU' (no backward, or the activation diet recomputes the pair): half the output bytes of the launch
                     _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), act=ops.ACT_GELU)
                 _gemm_fwd(act, Hd, [P(b + "mlp.fc2.weight")], "w", x_out, bias=P(b + "mlp.fc2.bias"), ln=False, **epi)
                 del act
-            a.update(x2=x if fmap2 is None else xc2, mean2=mean2, rstd2=rstd2, ln2=None if diet >= 2 else ln2,
-                     ln2b=ln2b if diet == 1 else None)
+            a.update(x2=xh2 if xh16 else (x if fmap2 is None else xc2), xn=xh16, mean2=mean2, rstd2=rstd2, ln2=ln2 if diet.keep_ln[i] else None,
+                     ln2b=ln2b if (diet.keep_ln[i] and not diet.keep_mlp[i]) else None)
             x = x_out
         if save:
             acts.append(a)
@@ -723,14 +775,17 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
                 if "act" not in a:
-                    # activation diet: the LayerNorm output (level 2: from the saved fp32 rows - compact kept rows or the whole stream, in
-                    # either case exactly the M2 rows the forward normalised), then fc1 + GELU / GELU' exactly as the forward ran them
+                    # activation diet: the LayerNorm output (from the saved rows - fp32: compact kept rows or the whole stream, in either case
+                    # exactly the M2 rows the forward normalised; or their fp16 normalised form), then fc1 + GELU / GELU' as the forward ran them
                     ln2b = a["ln2b"]
                     if ln2b is None:
-                        ln2b, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, mx8_for=Hd)
+                        ln2b, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, mx8_for=Hd,
+                                                     x_normalized=a["xn"])
                     a["h"], a["act"] = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
                     _gemm_fwd(ln2b, D, [w1], "w", a["act"], bias=P(b + "mlp.fc1.bias"), aux_out=a["h"], act=ops.ACT_GELU_SAVE_DERIV)
                     del ln2b
+                elif a["ln2"] is None:      # the MLP intermediates were kept, the LayerNorm output (fc1's weight gradient reads it) was not
+                    _, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, x_normalized=a["xn"])
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
                 _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
@@ -740,7 +795,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             ho, pre = handover(a["tr2"], a["B1"], a["sc1"], a["sc2"] is not None)
             ops.layernorm_bwd(dln2, a["x2"], P(b + "norm2.weight"), a["mean2"], a["rstd2"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm2.weight"), dbeta=G(b + "norm2.bias"), dtype=dt, frame_map=fmap2,
-                              rows_per_frame=N, **ho)
+                              rows_per_frame=N, x_normalized=a.get("xn", False), **ho)
             del dln2, g16
         else:
             pre = None
@@ -761,8 +816,8 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                                   dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
                                   grad_scale=inv_s, dtype=dt)
                 dao = dao2
-            if a["ln1"] is None:      # activation diet level 2
-                _, a["ln1"], _, _ = _ln16(a["x1"], P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev)
+            if a["ln1"] is None:      # activation diet: the LayerNorm output was not kept
+                _, a["ln1"], _, _ = _ln16(a["x1"], P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev, x_normalized=a["xn"])
             qkv = a["qkv"]
             dqkv = _empty((M1, 3 * D), dt, dev)
             delta = _empty((B1, H, N), torch.float32, dev)
@@ -788,7 +843,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             ho, pre = handover(a["tr1"], nxt["B2"], nxt["sc2"], a["sc1"] is not None) if nxt is not None else ({}, None)
             ops.layernorm_bwd(dln1, a["x1"], P(b + "norm1.weight"), a["mean1"], a["rstd1"], dy_scale=inv_s, dx_add=g,
                               dx32=g, dgamma=G(b + "norm1.weight"), dbeta=G(b + "norm1.bias"), dtype=dt, frame_map=fmap1,
-                              rows_per_frame=N, **ho)
+                              rows_per_frame=N, x_normalized=a.get("xn", False), **ho)
             del dqkv, dao, dln1, g16
         else:
             pre = None
@@ -838,31 +893,42 @@ def _slice_groups(groups, c0, c1):
 _SOFT_FRAC = float(os.environ.get("MICO_HBM_SOFT_FRAC", "0.82"))
 
 
-def tower_plan(spec, n_frames, device, kept=1.0):
-    """-> (frames per tower pass, activation diet level).  Saved activations cost depth * N * (20 D + 4 hidden) bytes per kept frame (542 MB
-    for ViT-g/14: two fp32 stream copies, LN outputs, qkv, attention output, the two MLP intermediates).  When the step's frames do not fit
-    in the memory budget there are two ways to pay with recomputation, priced in tower-forward units:
-      * the activation diet - level 1 drops the MLP intermediates (4 hidden of the bytes; the backward re-runs fc1 + GELU: +0.33 of a tower
-        forward), level 2 the LayerNorm outputs as well (4 D; two more LayerNorm passes per block: +0.02);
+def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
+    """-> (frames per tower pass, TowerDiet).  Saved activations of the pre-norm plain-MLP tower cost, per kept token and block: two LayerNorm
+    input copies (fp32: 8 D bytes; as fp16 normalised rows, TowerDiet.xh16: 4 D), the two LayerNorm outputs 4 D, qkv 6 D, the attention output
+    2 D, the two MLP intermediates 4 hidden - depth * N * (20 D + 4 hidden) = 542 MB per frame for ViT-g/14 when everything is kept.  When the
+    step's frames do not fit in the memory budget there are two ways to pay with recomputation, priced in tower-forward units:
+      * the activation diet - level 1 drops the MLP intermediates (the backward re-runs fc1 + GELU: +0.33 of a tower forward), level 2 the
+        LayerNorm outputs as well (two more LayerNorm passes per block: +0.02); level 3 (round 5) additionally keeps the LayerNorm input rows as
+        fp16 normalised rows (no recomputation at all: 4 D fewer bytes than level 2) and spends what that frees on the MLP intermediates of as
+        many blocks as fit - the LAST ones, which the backward frees first (each saves its share of the 0.33);
       * chunks - the tower runs in n equal chunks, forward without saving except for the last one, and in the backward the other chunks are
         recomputed with saving and differentiated: +(n - 1) / n.
-    The cheapest combination that fits is taken: BASELINE configs[3] (14 frames per sample, 896 per GPU at b = 64, ~0.8 kept by stochastic
-    depth) runs in ONE pass at level 2 (166 GB of activations) where it used to take three chunks (+0.67).
-    kept: fraction of the (block, branch, frame) triples the step's stochastic-depth draw keeps (only those are evaluated and saved)."""
+    The cheapest combination that fits is taken; levels 0-2 recompute the forward's own values bit for bit and win ties.  One rank of BASELINE
+    configs[3] (14 frames per sample, 896 per GPU at b = 64, ~0.8 kept by stochastic depth) runs in ONE pass at level 3 with the MLP
+    intermediates of ~10 of the 40 blocks kept (round 3: level 2, 166 GB of activations; round 2: three chunks, +0.67).
+    kept: fraction of the (block, branch, frame) triples the step's stochastic-depth draw keeps (only those are evaluated and saved);
+    block_tokens (optional, per block): kept MLP-branch tokens of each block (DropPlan counts x N) - prices the per-block MLP choice exactly.
+    The post-norm tower (bigE) and the SwiGLU towers keep everything (no diet): only chunks are priced for them, at their own bytes per frame."""
     if torch.device(device).type != "cuda":
         from ._lib import MicoHipError
         raise MicoHipError("the ViT tower runs on an MI355X device only (parameters are on %s): mico_amd has no CPU path" % device)
     depth, N, D, Hd = spec.arch["depth_built"], spec.N, spec.D, spec.hidden
-    dietable = not spec.arch["swiglu"]
+    postnorm = bool(spec.arch.get("postnorm"))
+    dietable = not spec.arch["swiglu"] and not postnorm
+    # (the post-norm block saves fp32 br1 / br2 (8 D), x16a / x16b / ao (6 D), qkv (6 D), act + h (4 hidden): the same 20 D + 4 hidden per token)
     per_frame = {0: depth * N * (20 * D + 4 * Hd)}
     if dietable:
         per_frame[1] = depth * N * 20 * D
         per_frame[2] = depth * N * 16 * D
-    extra = {0: 0.0, 1: 0.33, 2: 0.35}
+        per_frame[3] = depth * N * 12 * D
+    extra = {0: 0.0, 1: 0.33, 2: 0.35, 3: 0.35}
     forced_chunk, forced_diet = runtime.tower_chunk_override(), runtime.activation_diet_override()
-    levels = [forced_diet if forced_diet in per_frame else 0] if forced_diet is not None else sorted(per_frame)
+    forced_level = forced_diet[0] if forced_diet is not None else None
+    levels = [forced_level if forced_level in per_frame else 0] if forced_diet is not None else sorted(per_frame)
     if forced_chunk:
-        return forced_chunk, levels[0]
+        lv = levels[0] if forced_diet is not None else 0
+        return forced_chunk, TowerDiet(depth, lv, forced_diet[1] if (forced_diet is not None and lv == 3) else 0)
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)    # cached blocks are reusable
     # what the rest of the step needs next to the tower's saved activations - the backward's temporaries, BERT with its cross-attention K/V
@@ -879,6 +945,11 @@ def tower_plan(spec, n_frames, device, kept=1.0):
     hard = int(0.90 * max(free - headroom, free // 4))
     soft = min(hard, int(_SOFT_FRAC * total) - torch.cuda.memory_allocated(device) - headroom)
     kept = min(1.0, max(0.05, kept + 0.02))      # (a little slack: the draw differs from chunk to chunk)
+    if block_tokens is None or len(block_tokens) != depth:
+        block_tokens = [kept * n_frames * N] * depth
+    else:
+        block_tokens = [t * (kept / max(kept - 0.02, 1e-6)) for t in block_tokens]      # (the same slack)
+    mlp_tokens_total = float(sum(block_tokens)) or 1.0
 
     def cheapest(budget):
         best = None
@@ -887,13 +958,29 @@ def tower_plan(spec, n_frames, device, kept=1.0):
             most = max(1, int(max(budget, 0) // pf))
             n_chunks = -(-n_frames // most)
             cost = extra[lv] + (n_chunks - 1) / n_chunks
+            mlp_blocks = 0
+            if lv == 3 and forced_diet is not None:
+                mlp_blocks = forced_diet[1]
+            elif lv == 3 and n_chunks == 1:
+                # one pass at level 3: what is left of the budget keeps MLP intermediates, last block first; a kept block saves its share
+                # (by kept tokens) of the fc1 recompute
+                left = budget - pf * n_frames
+                saved_tokens = 0.0
+                for i in reversed(range(depth)):
+                    need = block_tokens[i] * 4 * Hd
+                    if need > left:
+                        break
+                    left -= need
+                    saved_tokens += block_tokens[i]
+                    mlp_blocks += 1
+                cost = 0.02 + 0.33 * (1.0 - saved_tokens / mlp_tokens_total)
             if best is None or cost < best[0] - 1e-9:
-                best = (cost, -(-n_frames // n_chunks), lv)      # equal chunks: the one whose activations are kept is then as large as the others
+                best = (cost, -(-n_frames // n_chunks), lv, mlp_blocks)      # equal chunks: the one whose activations are kept is then as large as the others
         return best
 
     bs, bh = cheapest(soft), cheapest(hard)
     best = bs if bs[0] <= bh[0] + 0.05 else bh
-    return best[1], best[2]
+    return best[1], TowerDiet(depth, best[2], best[3])
 
 
 def tower_chunk_frames(spec, n_frames, device):
@@ -914,17 +1001,24 @@ class EvaTowerFn(torch.autograd.Function):
     def _forward(ctx, spec, groups, dp_scale, *params):
         Bf = sum(g.shape[0] for g in groups)
         needs_grad = any(ctx.needs_input_grad)    # False under torch.no_grad(): nothing is kept for a backward then
-        plan, chunk, diet = None, Bf, 0
+        depth = spec.arch["depth_built"]
+        plan, chunk, diet = None, Bf, TowerDiet(depth, 0)
         if needs_grad:
             plan = DropPlan(dp_scale, Bf, params[0].device) if dp_scale is not None else None
             kept = plan.kept_fraction() if plan is not None else 1.0
-            chunk, diet = tower_plan(spec, Bf, params[0].device, kept)
-            runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet, kept_fraction=kept)
-            if (Bf, min(chunk, Bf), diet) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
-                EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet)
-                _log.info("tower plan: %d frames, %d per pass, activation diet %d (kept fraction %.3f)", Bf, min(chunk, Bf), diet, kept)
+            btok = [plan.counts[2 * i + 1] * spec.N for i in range(depth)] if (plan is not None and len(plan.counts) == 2 * depth) else None
+            chunk, diet = tower_plan(spec, Bf, params[0].device, kept, btok)
+
+            def record(**more):
+                runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet.level, mlp_blocks_kept=diet.mlp_blocks,
+                                               rows_fp16_normalised=diet.xh16, kept_fraction=kept, **more)
+            record()
+            if (Bf, min(chunk, Bf), diet.level, diet.mlp_blocks) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
+                EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet.level, diet.mlp_blocks)
+                _log.info("tower plan: %d frames, %d per pass, activation diet %s (kept fraction %.3f)", Bf, min(chunk, Bf), diet.describe(), kept)
         ctx.spec, ctx.params, ctx.diet = spec, params, diet
         if chunk >= Bf:
+            retry = False
             try:
                 out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad, diet=diet, plan=plan)
                 ctx.chunked = None
@@ -932,19 +1026,28 @@ class EvaTowerFn(torch.autograd.Function):
             except torch.cuda.OutOfMemoryError:
                 # The plan is priced from a fitted headroom (tower_plan): another step shape (more condition tokens, other modality mixes) or a
                 # smaller device can under-estimate it.  The forward only wrote buffers of its own, so it is repeated ONCE on the next more
-                # conservative plan - the next diet level if there is one, else two chunks - instead of failing the step.
+                # conservative plan instead of failing the step.  Only the DECISION is taken here: while this handler is active the
+                # exception's traceback keeps the failed _tower_forward frame - its `acts`, `x`, every buffer of the failed attempt - alive,
+                # so empty_cache() would free nothing and the retry would allocate on top of them; the retry runs below, after
+                # the handler has exited and the traceback is gone.
                 if not needs_grad:
                     raise
+                retry = True
+            if retry:
                 ctx.saved = None
+                import gc
+                gc.collect()
                 torch.cuda.empty_cache()
-                dietable = not spec.arch["swiglu"]
-                if dietable and diet < 2 and runtime.activation_diet_override() is None:
-                    diet += 1
+                dietable = not spec.arch["swiglu"] and not spec.arch.get("postnorm")
+                if dietable and runtime.activation_diet_override() is None and (diet.level < 3 or diet.mlp_blocks > 0):
+                    # next more conservative diet: no MLP intermediates at level 3, else the next level
+                    diet = TowerDiet(depth, 3, 0) if diet.level == 3 else TowerDiet(depth, diet.level + 1, 0)
                 else:
                     chunk = -(-Bf // 2)
                 ctx.diet = diet
-                runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet, kept_fraction=kept, oom_retry=True)
-                _log.warning("tower pass ran out of memory: retrying with %d frames per pass, activation diet %d (rank-local decision)", min(chunk, Bf), diet)
+                record(oom_retry=True)
+                _log.warning("tower pass ran out of memory: retrying with %d frames per pass, activation diet %s (rank-local decision)",
+                             min(chunk, Bf), diet.describe())
                 if chunk >= Bf:
                     out, ctx.saved = _tower_forward(spec, groups, dp_scale, params, save=needs_grad, diet=diet, plan=plan)
                     ctx.chunked = None
@@ -1153,20 +1256,24 @@ def cls_pool(tokens):
 
 class _PoolVideo(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tokens):   # [b, n, N, D] fp32
+    def forward(ctx, tokens):   # [b, n, N, D]; the kernels are fp32-only and take raw pointers: any other dtype is converted here
         b, n, N, D = tokens.shape
-        tokens = tokens.contiguous()
+        if not tokens.is_cuda:
+            from ._lib import MicoHipError
+            raise MicoHipError("pool_video runs on an MI355X device only (tokens are on %s): mico_amd has no CPU path" % tokens.device)
+        ctx.in_dtype = tokens.dtype
+        tokens = tokens.float().contiguous()
         out = _empty((b, n, 2, D), torch.float32, tokens.device)
         ops.pool_video_fwd(tokens, out, b * n, N, D)
         ctx.shape = (b, n, N, D)
-        return out
+        return out.to(ctx.in_dtype)
 
     @staticmethod
     def backward(ctx, dy):
         b, n, N, D = ctx.shape
         dt = _empty(ctx.shape, torch.float32, dy.device)
-        ops.pool_video_bwd(dy.contiguous(), dt, b * n, N, D)
-        return dt
+        ops.pool_video_bwd(dy.float().contiguous(), dt, b * n, N, D)
+        return dt.to(ctx.in_dtype)
 
 
 def pool_video(tokens):
@@ -1470,7 +1577,15 @@ class BertFn(torch.autograd.Function):
         Sg = runtime.grad_scale()
         inv_s = 1.0 / Sg
         scale = 1.0 / math.sqrt(hd)
-        grads = GradArena.session(params, spec.grad_groups, private=(spec.idx["embeddings.word_embeddings.weight"],))   # (tied to the LM head's decoder)
+        # private = parameters with gradient producers OUTSIDE the BertFn nodes of this backward pass: the word embeddings (tied to the LM
+        # head's decoder) and - in a pass that projects its own condition tokens while the step may also hold a CrossKVFn node for the same
+        # key / value projections (share_cross_kv: e.g. "cap%tv%ta_ret%tva", where cap%ta has no retrieval twin) - the cross-attention
+        # key / value weights and biases.  Two defined gradients for one parameter make the engine replace its accumulator by an
+        # out-of-place sum; in-place additions to an arena view handed out earlier would then be lost.
+        private = [spec.idx["embeddings.word_embeddings.weight"]]
+        if cond16 is not None and runtime.CFG.share_cross_kv:
+            private += [i for grp in spec.grad_groups for i in grp if ".crossattention.self." in spec.names[i]]
+        grads = GradArena.session(params, spec.grad_groups, private=private)
 
         def G(name):
             return grads.get(spec.idx[name])
@@ -1526,7 +1641,7 @@ class BertFn(torch.autograd.Function):
                 delta = _empty((b, H, S), torch.float32, dev)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 kv = a["kv"]
-                if shared and has_neg and S <= ops.ATTN_SMALLQ_MAX and hd == 64:
+                if shared and has_neg and ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(li * 8 + SITE_CROSS_P), batch0=2 * n_own):
                     # two launches over the triplet: entries [0, 2 n) own exactly the [own | neg] K/V sets, entries [2 n, 3 n) read the own sets again
                     # and ADD their dK / dV (mico_attn_params.batch0 keeps the dropout counters of the one-launch forward)
                     dkv = dkv_pair[li]

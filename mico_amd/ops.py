@@ -212,50 +212,63 @@ def gemm_mx8(A, B, out, *, dtype, M=None, **epi):
 
 def layernorm_fwd(x, gamma, beta, eps, *, out16=None, out32=None, mean=None, rstd=None, post_add=None,
                   post_rows_per_group=0, post_groups=0, split16=False, dtype=torch.float16, frame_map=None,
-                  rows_per_frame=0, x_copy=None, drop=None, valid_cols=0):
+                  rows_per_frame=0, x_copy=None, xhat16=None, x_normalized=False, drop=None, valid_cols=0, mx8=None):
     """split16: out16 is [rows, 2*cols] and receives [hi | lo] (split-precision GEMM operand).  frame_map (int32 [frames]):
-    compacting gather of whole frames out of x; the number of rows is then len(frame_map) * rows_per_frame."""
+    compacting gather of whole frames out of x; the number of rows is then len(frame_map) * rows_per_frame.
+    xhat16 (fp16 [rows, cols]): receives the normalised gathered rows - the half-size replacement of x_copy for the backward;
+    x_normalized: x IS such a buffer (y = x gamma + beta, no statistics).  mx8: an Mx8 whose q / scales receive the fp8 operand."""
     rows, cols = x.shape[0], x.shape[1]
     if frame_map is not None:
         rows = frame_map.shape[0] * rows_per_frame
-    rc = _lib.lib().mico_layernorm_fwd(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(out32), _p(mean),
-                                       _p(rstd), rows, cols, eps, _p(post_add), post_rows_per_group, post_groups,
-                                       int(split16), _p(frame_map), rows_per_frame, _p(x_copy),
-                                       float(drop[0]) if drop else 0.0, (int(drop[1]) & 0xFFFFFFFF) if drop else 0,
-                                       int(drop[2]) if drop else 0, int(valid_cols), dt_code(dtype), _st())
-    check(rc, "mico_layernorm_fwd")
+    if xhat16 is not None:
+        assert xhat16.dtype == torch.float16 and xhat16.is_contiguous() and tuple(xhat16.shape) == (rows, cols)
+    if x_normalized:
+        assert x.dtype == torch.float16 and x.is_contiguous()
+    p = _lib.LnFwdParams(x=_p(x), x_dtype=dt_code(x.dtype), x_normalized=int(bool(x_normalized)), gamma=_p(gamma), beta=_p(beta), y16=_p(out16),
+                         y32=_p(out32), mean=_p(mean), rstd=_p(rstd), rows=rows, cols=cols, eps=eps, post_add=_p(post_add),
+                         post_rows_per_group=post_rows_per_group, post_groups=post_groups, y16_split=int(split16), frame_map=_p(frame_map),
+                         rows_per_frame=rows_per_frame, x_copy=_p(x_copy), xhat16=_p(xhat16), drop_p=float(drop[0]) if drop else 0.0,
+                         drop_seed=(int(drop[1]) & 0xFFFFFFFF) if drop else 0, drop_site=int(drop[2]) if drop else 0, valid_cols=int(valid_cols),
+                         q8=_p(mx8.q) if mx8 is not None else None, ldq=mx8.q.stride(0) if mx8 is not None else 0,
+                         scales=_p(mx8.scales) if mx8 is not None else None)
+    check(_lib.lib().mico_layernorm_fwd(C.byref(p), dt_code(dtype), _st()), "mico_layernorm_fwd")
 
 
-def layernorm_fwd_mx8(x, gamma, beta, eps, *, out16, mean, rstd, dtype, frame_map=None, rows_per_frame=0, x_copy=None):
+def layernorm_fwd_mx8(x, gamma, beta, eps, *, out16, mean, rstd, dtype, frame_map=None, rows_per_frame=0, x_copy=None, xhat16=None,
+                      x_normalized=False):
     """layernorm_fwd whose 16-bit output is also quantised to the MX fp8 operand of gemm_mx8 (returns the Mx8; == quant_mx8(out16))."""
     rows, cols = x.shape[0], x.shape[1]
     if frame_map is not None:
         rows = frame_map.shape[0] * rows_per_frame
     q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
     sc = torch.empty((cols // 128, rows), dtype=torch.int32, device=x.device)
-    check(_lib.lib().mico_layernorm_fwd_mx8(_p(x), dt_code(x.dtype), _p(gamma), _p(beta), _p(out16), _p(mean), _p(rstd), rows, cols, eps,
-                                            _p(frame_map), rows_per_frame, _p(x_copy), _p(q), q.stride(0), _p(sc), dt_code(dtype), _st()),
-          "mico_layernorm_fwd_mx8")
-    return Mx8(q, sc)
+    mx = Mx8(q, sc)
+    layernorm_fwd(x, gamma, beta, eps, out16=out16, mean=mean, rstd=rstd, dtype=dtype, frame_map=frame_map, rows_per_frame=rows_per_frame,
+                  x_copy=x_copy, xhat16=xhat16, x_normalized=x_normalized, mx8=mx)
+    return mx
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dy_scale=1.0, dx_add=None, dx32=None, dx16=None, scale16=1.0, dgamma=None, dbeta=None,
                   grad_scale=1.0, dtype=torch.float16, frame_map=None, rows_per_frame=0, valid_cols=0, dx16_dst=None, dx16_frame_scale=None,
-                  dx16_drop=None):
+                  dx16_drop=None, x_normalized=False):
     """frame_map: dx_add / dx32 are the full stream, addressed through the frame scatter; dy / x / mean / rstd are compact.
     dx16_dst / dx16_frame_scale: dx16 is laid out for the next consumer's frame set (mico_layernorm_bwd in include/mico_hip.h).
-    dx16_drop: (p, seed, site) - dx16 also carries that dropout's mask (the gradient side of a hidden-state dropout)."""
+    dx16_drop: (p, seed, site) - dx16 also carries that dropout's mask (the gradient side of a hidden-state dropout).
+    x_normalized: x is the forward's fp16 xhat16 copy (mean may be None)."""
     dp, dseed, dsite = (float(dx16_drop[0]), int(dx16_drop[1]) & 0xFFFFFFFF, int(dx16_drop[2])) if dx16_drop is not None else (0.0, 0, 0)
     rows, cols = x.shape[0], x.shape[1]
     ws = None
     if dgamma is not None or dbeta is not None:
         nblk = _lib.lib().mico_layernorm_bwd_nblk(rows)
         ws = torch.empty(2 * nblk * cols, dtype=torch.float32, device=x.device)
-    rc = _lib.lib().mico_layernorm_bwd(_p(dy), dt_code(dy.dtype), dy_scale, _p(x), dt_code(x.dtype), _p(gamma), _p(mean), _p(rstd),
-                                       _p(dx_add), _p(dx32), _p(dx16), scale16, _p(dgamma), _p(dbeta), grad_scale,
-                                       _p(ws), rows, cols, _p(frame_map), rows_per_frame, int(valid_cols), _p(dx16_dst), _p(dx16_frame_scale),
-                                       dp, dseed, dsite, dt_code(dtype), _st())
-    check(rc, "mico_layernorm_bwd")
+    if x_normalized:
+        assert x.dtype == torch.float16 and x.is_contiguous()
+    p = _lib.LnBwdParams(dy=_p(dy), dy_dtype=dt_code(dy.dtype), dy_scale=dy_scale, x=_p(x), x_dtype=dt_code(x.dtype),
+                         x_normalized=int(bool(x_normalized)), gamma=_p(gamma), mean=_p(mean), rstd=_p(rstd), dx_add=_p(dx_add), dx32=_p(dx32),
+                         dx16=_p(dx16), scale16=scale16, dgamma=_p(dgamma), dbeta=_p(dbeta), grad_scale=grad_scale, ws=_p(ws), rows=rows,
+                         cols=cols, frame_map=_p(frame_map), rows_per_frame=rows_per_frame, valid_cols=int(valid_cols), dx16_dst=_p(dx16_dst),
+                         dx16_frame_scale=_p(dx16_frame_scale), dx16_drop_p=dp, dx16_drop_seed=dseed, dx16_drop_site=dsite)
+    check(_lib.lib().mico_layernorm_bwd(C.byref(p), dt_code(dtype), _st()), "mico_layernorm_bwd")
 
 
 def dropout_(x, drop):
@@ -267,6 +280,17 @@ def dropout_(x, drop):
 
 
 ATTN_SMALLQ_MAX = 80   # query rows of the one-pass short-query backward (SqCfg::QMAX in csrc/attention.hip; hd 64 only)
+
+
+def attn_bwd_smallq_ok(B, H, Sq, Sk, hd, drop=None, batch0=0):
+    """True when mico_attn_bwd takes its one-pass short-query kernel for this launch - the only kernel that implements
+    mico_attn_params.dkv_accumulate.  The library's own condition (csrc/attention.hip, mico_attn_bwd), restated so that a caller that wants
+    the two-launch ITM triplet backward can fall back to the one-launch form instead of running into the library's check."""
+    import os
+    if os.environ.get("MICO_ATTN_NOSMALLQ") is not None or hd != 64 or Sq > ATTN_SMALLQ_MAX:
+        return False
+    p = float(drop[0]) if drop else 0.0
+    return p <= 0.0 or (B + batch0) * H * Sq * Sk <= 0xFFFFFFFF
 
 
 def _attn_params(B, H, Sq, Sk, hd, q, k, v, o, scale, mask, q_strides, k_strides, v_strides, o_strides, drop=None, kv_batch_mod=0, batch0=0,

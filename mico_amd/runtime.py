@@ -336,7 +336,7 @@ def set_tower_chunk(frames):
 
 
 _activation_diet = None
-last_tower_plan = None      # dict(frames=, frames_per_pass=, diet=, kept_fraction=[, oom_retry=]) of the most recent training-mode tower forward
+last_tower_plan = None      # dict(frames=, frames_per_pass=, diet=, mlp_blocks_kept=, rows_fp16_normalised=, kept_fraction=[, oom_retry=]) of the most recent training-mode tower forward
 
 
 def reset():
@@ -353,12 +353,14 @@ def activation_diet_override():
     return _activation_diet
 
 
-def set_activation_diet(level):
+def set_activation_diet(level, mlp_blocks=0):
     """0: keep everything the backward reads; 1: drop the two MLP intermediates (GELU output and GELU', 4 * hidden of the 20 D + 4 hidden
     bytes per token and block) and recompute them in the backward with one fc1 GEMM; 2: also drop the LayerNorm outputs (recomputed from
-    the saved fp32 rows).  None: automatic (functional.tower_plan)."""
+    the saved fp32 rows); 3: as 2 with the LayerNorm input rows kept as fp16 normalised rows instead of fp32 copies, and the MLP
+    intermediates of the LAST `mlp_blocks` blocks kept (functional.TowerDiet).  None: automatic (functional.tower_plan).
+    activation_diet_override() -> None | (level, mlp_blocks)."""
     global _activation_diet
-    _activation_diet = None if level is None else int(level)
+    _activation_diet = None if level is None else (int(level), int(mlp_blocks))
 
 
 _grad_slice_hook = None

@@ -134,7 +134,9 @@ def test_activation_diet_recompute(cuda):
     """runtime.set_activation_diet: level 1 drops the MLP intermediates (fc1 + GELU / GELU' re-run in the backward), level 2 the LayerNorm
     outputs too (recomputed from the saved fp32 rows).  Plain-MLP tower (g/14 architecture), with and without stochastic depth (compact
     kept-frame rows vs the whole stream as the saved LayerNorm input), also through chunks: the recomputed tensors are the forward's own
-    values, so outputs are identical and gradients agree to the summation order of the fp32 atomics."""
+    values, so outputs are identical and gradients agree to the summation order of the fp32 atomics.  Level 3 (round 5): the LayerNorm input
+    rows kept as fp16 normalised rows instead of fp32 copies, with the MLP intermediates of none / the last / all blocks kept (the mixed
+    per-block plan tower_plan produces for one rank of configs[3]) - same outputs, gradients within the same bound."""
     from mico_amd import runtime as rt
     from mico_amd import functional as Fn
     depth = 2
@@ -147,45 +149,59 @@ def test_activation_diet_recompute(cuda):
     w = (torch.randn(5, 257, 1408, generator=g) / (5 * 257 * 1408) ** 0.5).to(cuda)
     res = {}
     try:
-        for diet, chunk in ((0, None), (1, None), (2, None), (2, 2)):
-            rt.set_activation_diet(diet)
+        cases = ((0, None, 0), (1, None, 0), (2, None, 0), (2, 2, 0), (3, None, 0), (3, None, 1), (3, None, 2), (3, 2, 1))
+        for diet, chunk, mlpb in cases:
+            rt.set_activation_diet(diet, mlpb)
             rt.set_tower_chunk(chunk)
             for use_dp in (False, True):
                 with rt.precision(torch.float16):
                     m.zero_grad(set_to_none=True)
                     out = vis.forward_groups([img, aud], drop_path_scale=dps if use_dp else None)
-                    assert rt.last_tower_plan["diet"] == diet
+                    assert rt.last_tower_plan["diet"] == diet and rt.last_tower_plan["rows_fp16_normalised"] == (diet == 3)
+                    assert rt.last_tower_plan["mlp_blocks_kept"] == (depth if diet == 0 else mlpb)
                     (out * w).sum().backward()
-                res[(diet, chunk, use_dp)] = (out.detach().clone(), {n: p.grad.clone() for n, p in vis.named_parameters() if p.grad is not None})
+                res[(diet, chunk, mlpb, use_dp)] = (out.detach().clone(), {n: p.grad.clone() for n, p in vis.named_parameters() if p.grad is not None})
     finally:
         rt.set_activation_diet(None)
         rt.set_tower_chunk(None)
+    worst = 0.0
     for use_dp in (False, True):
-        o0, g0 = res[(0, None, use_dp)]
-        for key in ((1, None), (2, None), (2, 2)):
+        o0, g0 = res[(0, None, 0, use_dp)]
+        for key in cases[1:]:
             o1, g1 = res[key + (use_dp,)]
             assert torch.equal(o0, o1), (key, use_dp)
             assert set(g0) == set(g1)
             for n in g0:
                 assert rel_err(g1[n], g0[n]) < 2e-3, (key, use_dp, n, rel_err(g1[n], g0[n]))
+                if key[0] == 3:
+                    worst = max(worst, rel_err(g1[n], g0[n]))
+    print("level 3 (fp16 normalised rows) against level 0: worst gradient difference", worst)
     # the plan: the cheapest combination that fits - everything fits here, so nothing is dropped
     spec, _ = vis._tower_spec()
-    assert Fn.tower_plan(spec, 5, cuda) == (5, 0)
+    chunk0, diet0 = Fn.tower_plan(spec, 5, cuda)
+    assert (chunk0, diet0.level, diet0.xh16, all(diet0.keep_mlp), all(diet0.keep_ln)) == (5, 0, False, True, True)
     # and a step that cannot keep everything: one rank of BASELINE configs[3] on the full-depth architecture (896 frames, ~0.8 kept) - priced
     # from the free memory of this box, it must come out as a single pass on the diet or as chunks, never as "keep everything in one pass"
     import copy
     big = copy.copy(spec)
     big.arch = dict(spec.arch, depth_built=40)
     chunk, diet = Fn.tower_plan(big, 896, cuda, kept=0.8)
-    assert diet > 0 or chunk < 896          # 896 x 0.82 x 542 MB = 398 GB of level-0 activations exceed the 288 GB of an MI355X
-    assert chunk * 0.82 * 40 * 257 * {0: 20 * 1408 + 4 * 6144, 1: 20 * 1408, 2: 16 * 1408}[diet] < torch.cuda.mem_get_info(cuda)[1]
-    print("configs[3] rank share on this box:", chunk, "frames per pass, diet", diet)
+    assert diet.level > 0 or chunk < 896          # 896 x 0.82 x 542 MB = 398 GB of level-0 activations exceed the 288 GB of an MI355X
+    per_tok = {0: 20 * 1408 + 4 * 6144, 1: 20 * 1408, 2: 16 * 1408, 3: 12 * 1408}[diet.level]
+    acts = chunk * 0.82 * 257 * (40 * per_tok + (diet.mlp_blocks * 4 * 6144 if diet.level == 3 else 0))
+    assert acts < torch.cuda.mem_get_info(cuda)[1]
+    print("configs[3] rank share on this box:", chunk, "frames per pass, diet", diet.describe())
     # the soft budget (functional._SOFT_FRAC of the device memory for the step's projected peak): on a clean 288 GiB device level 1 would
-    # "fit" at a 266 GiB peak - the plan must take level 2 in ONE pass instead (231 GiB measured), leaving room for RCCL and a second reducer
+    # "fit" at a 266 GiB peak - the plan must stay in ONE pass under the soft budget: level 3 (fp16 normalised rows) with the MLP intermediates
+    # of SOME blocks kept from what the smaller rows free (round 4: level 2, 231 GiB measured), leaving room for RCCL and a second reducer
     if torch.cuda.mem_get_info(cuda)[0] > 250 << 30:
-        assert (chunk, diet) == (896, 2), (chunk, diet)
-        proj = torch.cuda.memory_allocated(cuda) + (12 << 30) + 896 * (52 << 20) + 896 * 0.82 * 40 * 257 * 16 * 1408
+        assert (chunk, diet.level) == (896, 3) and 4 <= diet.mlp_blocks <= 20, (chunk, diet.describe())
+        proj = torch.cuda.memory_allocated(cuda) + (12 << 30) + 896 * (52 << 20) + acts
         assert proj < 0.82 * torch.cuda.mem_get_info(cuda)[1]
+        # with the per-block kept tokens of a real draw (later blocks keep fewer frames) the last blocks are cheaper than the average
+        toks = [int(896 * 257 * (1.0 - 0.4 * i / 39)) for i in range(40)]
+        chunk_b, diet_b = Fn.tower_plan(big, 896, cuda, kept=sum(toks) / (40 * 896 * 257), block_tokens=toks)
+        assert (chunk_b, diet_b.level) == (896, 3) and diet_b.mlp_blocks >= diet.mlp_blocks
 
 
 def test_tower_forward_oom_retry(cuda, monkeypatch):
@@ -212,13 +228,18 @@ def test_tower_forward_oom_retry(cuda, monkeypatch):
     o0, g0 = run()
     assert rt.last_tower_plan["diet"] == 0 and "oom_retry" not in rt.last_tower_plan
     real = Fn._tower_forward
-    for forced_diet, want in ((None, dict(diet=1, frames_per_pass=4)), (2, dict(diet=2, frames_per_pass=2))):
+    base = torch.cuda.memory_allocated()
+    for forced_diet, want in ((None, dict(diet=1, frames_per_pass=4)), (2, dict(diet=2, frames_per_pass=2)), (3, dict(diet=3, frames_per_pass=2))):
         fails = [1]
+        mem = {}
 
         def flaky(*a, **k):
             if fails[0]:
                 fails[0] -= 1
+                attempt = real(*a, **k)      # the error comes LATE: every buffer of the failed attempt is alive in this frame when it leaves it
+                mem["at_raise"] = torch.cuda.memory_allocated()
                 raise torch.cuda.OutOfMemoryError("injected")
+            mem["at_retry"] = torch.cuda.memory_allocated()
             return real(*a, **k)
 
         monkeypatch.setattr(Fn, "_tower_forward", flaky)
@@ -230,6 +251,8 @@ def test_tower_forward_oom_retry(cuda, monkeypatch):
             monkeypatch.setattr(Fn, "_tower_forward", real)
         plan = rt.last_tower_plan
         assert plan.get("oom_retry") and all(plan[k] == v for k, v in want.items()), plan
+        # the retry must not run on top of the failed attempt's activations (the handler's traceback kept them alive)
+        assert mem["at_retry"] - base < 0.25 * (mem["at_raise"] - base), (base, mem)
         assert rel_err(o1, o0) < 1e-6       # (chunks draw per-chunk plans from the same masks: the same frames are kept)
         for n in g0:
             assert rel_err(g1[n], g0[n]) < 2e-3, (n, rel_err(g1[n], g0[n]))

@@ -50,14 +50,15 @@ def test_ctypes_structs_match_the_compiled_layout():
             cur = []
         else:
             cur.append(v)
-    assert len(table) == 2
-    for cls, (size, *offs) in zip((_lib.GemmEpilogue, _lib.AttnParams), table):
+    assert len(table) == 4
+    for cls, (size, *offs) in zip((_lib.GemmEpilogue, _lib.AttnParams, _lib.LnFwdParams, _lib.LnBwdParams), table):
         assert ctypes.sizeof(cls) == size, (cls.__name__, ctypes.sizeof(cls), size)
         mine = [getattr(cls, name).offset for name, _ in cls._fields_]
         assert mine == offs, (cls.__name__, mine, offs)
     # and the header's field lists are what the table was built from (a field added to the header but not to the table would hide here)
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mico_hip.h")).read(), flags=re.S)
-    for struct, cls in (("mico_gemm_epilogue", _lib.GemmEpilogue), ("mico_attn_params", _lib.AttnParams)):
+    for struct, cls in (("mico_gemm_epilogue", _lib.GemmEpilogue), ("mico_attn_params", _lib.AttnParams),
+                        ("mico_ln_fwd_params", _lib.LnFwdParams), ("mico_ln_bwd_params", _lib.LnBwdParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
         names = []
         for decl in body.split(";"):
@@ -286,3 +287,60 @@ def test_shared_grad_arena_sessions():
             for a, b in zip(ref, got):
                 assert (a is None) == (b is None) and (a is None or torch.allclose(a, b, rtol=1e-6, atol=1e-6))
     assert len(GradArena._shared) <= 1
+
+
+def test_grad_arena_private_fused_group_with_outside_producer():
+    """a parameter pair written as ONE fused view by the arena nodes (BERT's cross-attention key | value gradients) that ALSO
+    receives a gradient from a producer outside those nodes (CrossKVFn) - in every order of arrival at the parameter's accumulator.  As part of
+    the shared arena the second defined gradient makes the engine replace the accumulator and later in-place additions are lost; as a private
+    group (a fused buffer per node) autograd sums everything.  Checked against plain autograd."""
+    import torch
+    from mico_amd.functional import GradArena
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, private, *params):
+            k, v = params
+            ctx.save_for_backward(x)
+            ctx.params, ctx.private = params, private
+            return x @ torch.cat((k.detach(), v.detach()), 0).t()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            grads = GradArena.session(ctx.params, groups=[[0, 1]], private=(0, 1) if ctx.private else ())
+            grads.fused([0, 1], (8, 4)).add_(g.t() @ x)        # the fused weight-gradient GEMM accumulates into the adjacent views
+            return (None, None) + grads.result()
+
+    class Outside(torch.autograd.Function):                    # the CrossKVFn-like producer: defined gradients of its own for k and v
+        @staticmethod
+        def forward(ctx, x, k, v):
+            ctx.save_for_backward(x)
+            return x @ k.detach().t() + x @ v.detach().t()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            return None, g.t() @ x, g.t() @ x
+
+    torch.manual_seed(0)
+    xs = [torch.randn(5, 4) for _ in range(4)]
+    k0, v0 = torch.randn(4, 4), torch.randn(4, 4)
+
+    def run(order, private, plain=False):
+        k, v = torch.nn.Parameter(k0.clone()), torch.nn.Parameter(v0.clone())
+        terms = []
+        for kind, x in zip(order, xs):
+            if kind == "n":
+                y = x @ torch.cat((k, v), 0).t() if plain else Node.apply(x, private, k, v)
+            else:
+                y = x @ k.t() + x @ v.t() if plain else Outside.apply(x, k, v)
+            terms.append((y ** 2).sum())
+        sum(terms).backward()
+        return k.grad.clone(), v.grad.clone()
+
+    for order in ("nnon", "onnn", "nnno", "nonn"):
+        ref = run(order, True, plain=True)
+        got = run(order, True)
+        for a, b in zip(ref, got):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), order

@@ -207,6 +207,53 @@ def test_layernorm(cuda, dtype, cols, xdt):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("gather", [False, True])
+def test_layernorm_normalised_rows(cuda, dtype, gather):
+    """mico_ln_fwd_params::xhat16 / x_normalized (ABI 111, the activation diet's level 3): the forward leaves the gathered rows as fp16
+    NORMALISED rows (x - mean) * rstd - half the bytes of the fp32 x_copy - without changing any of its other outputs; a later forward over
+    that buffer re-creates the 16-bit output (last-bit differences only: the rows were rounded once more), and the backward over it equals
+    the backward over the fp32 rows to the fp16 rounding of xhat.  fp16 rows under both compute types."""
+    from mico_amd import ops
+    torch.manual_seed(5)
+    N, D, frames = 7, 1408, 40
+    x = torch.randn(frames * N, D, device=cuda) * 3 + 0.5
+    x[:, 5] *= 30.0                                               # an outlier channel, as ViT residual streams have
+    gmm = 1 + 0.1 * torch.randn(D, device=cuda)
+    bta = 0.1 * torch.randn(D, device=cuda)
+    fmap = torch.tensor([f for f in range(frames) if f % 3 != 1], device=cuda, dtype=torch.int32) if gather else None
+    rows = (fmap.numel() if gather else frames) * N
+    kw = dict(frame_map=fmap, rows_per_frame=N) if gather else {}
+    y0, y1 = (torch.empty(rows, D, device=cuda, dtype=dtype) for _ in range(2))
+    m0, r0, m1, r1 = (torch.empty(rows, device=cuda) for _ in range(4))
+    xc = torch.empty(rows, D, device=cuda)
+    xh = torch.empty(rows, D, device=cuda, dtype=torch.float16)
+    ops.layernorm_fwd(x, gmm, bta, 1e-6, out16=y0, mean=m0, rstd=r0, dtype=dtype, x_copy=xc, **kw)
+    ops.layernorm_fwd(x, gmm, bta, 1e-6, out16=y1, mean=m1, rstd=r1, dtype=dtype, xhat16=xh, **kw)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)        # the other outputs do not notice
+    ref_hat = (xc - m0[:, None]) * r0[:, None]
+    assert ((xh.float() - ref_hat).abs() <= 2.0 ** -11 * ref_hat.abs() + 1e-7).all()       # one fp16 rounding
+    # forward again from the normalised rows: no statistics, y = xhat gamma + beta
+    y2 = torch.empty(rows, D, device=cuda, dtype=dtype)
+    ops.layernorm_fwd(xh, gmm, bta, 1e-6, out16=y2, dtype=dtype, x_normalized=True)
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    d = (y2.float() - y0.float()).abs()
+    assert (d <= 1.5 * ulp * y0.float().abs() + 2.0 ** -11 * (gmm.abs()[None] * ref_hat.abs()) + 1e-6).all(), d.max().item()
+    assert (y2 == y0).float().mean() > (0.6 if dtype == torch.float16 else 0.9)
+    # backward over the normalised rows against the backward over the fp32 copy (same dy, statistics, frame scatter)
+    dy = torch.randn(rows, D, device=cuda).to(dtype)
+    g_a = torch.randn(frames * N, D, device=cuda)
+    g_b = g_a.clone()
+    dga, dba, dgb, dbb = (torch.zeros(D, device=cuda) for _ in range(4))
+    ops.layernorm_bwd(dy, xc, gmm, m0, r0, dy_scale=0.25, dx_add=g_a, dx32=g_a, dgamma=dga, dbeta=dba, dtype=dtype, **kw)
+    ops.layernorm_bwd(dy, xh, gmm, None, r0, dy_scale=0.25, dx_add=g_b, dx32=g_b, dgamma=dgb, dbeta=dbb, dtype=dtype, x_normalized=True, **kw)
+    assert rel_err(g_b, g_a) < 1e-3 and rel_err(dgb, dga) < 1e-3 and torch.equal(dbb, dba)
+    # refusals: a normalised input is fp16 and produces no statistics / copies
+    from mico_amd._lib import MicoHipError
+    with pytest.raises(MicoHipError):
+        ops.layernorm_fwd(xh, gmm, bta, 1e-6, out16=y2, mean=m1, dtype=dtype, x_normalized=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("x_all", [False, True])
 def test_layernorm_bwd_handover(cuda, dtype, x_all):
     """mico_layernorm_bwd's dx16_dst / dx16_frame_scale + mico_gather_rows_cast's dst_map: the LayerNorm backward of a branch that kept

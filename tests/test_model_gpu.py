@@ -338,6 +338,44 @@ def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
     assert any("crossattention.self.key.weight" in n for n in res[True][1])
 
 
+def test_cap_subtask_without_retrieval_twin_keeps_cross_kv_gradients(setup, cuda):
+    """task "cap%tv%tva_ret%tva" - cap%tv has no retrieval twin, so its BERT pass projects its own condition tokens and produces
+    cross-attention key / value weight gradients itself, while ret%tva / cap%tva go through functional.CrossKVFn, a second producer of the same
+    gradients.  With those parameters as part of the shared gradient arena the engine's out-of-place sum dropped later in-place additions; they
+    are private in such a pass now.  Against the step with share_grad_arena off (per-node arenas, autograd sums everything): same gradients."""
+    vtype, tag, m, sd = setup
+    fx = golden(f"loss_{tag}.pt")
+    r = fx["W1"]
+    b = fx["meta"]["b"]
+    batch0 = to_dev(synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234), cuda)
+    res = {}
+    for task in ("cap%tv%tva_ret%tva", "ret%tva_cap%tva%tv"):
+        for share in (False, True):
+            batch = dict(batch0)
+            batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
+            batch["_injected"]["cap"] = r["inj"]["cap"]
+            old = runtime.CFG.share_grad_arena
+            runtime.CFG.share_grad_arena = share
+            try:
+                with runtime.precision(torch.float16):
+                    m.zero_grad(set_to_none=True)
+                    out = m(batch, task, compute_loss=True)
+                    sum(out.values()).backward()
+            finally:
+                runtime.CFG.share_grad_arena = old
+            res[share] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        assert set(res[True]) == set(res[False])
+        worst = ("", 0.0)
+        for n, g0 in res[False].items():
+            if n.endswith("self.key.bias"):
+                continue
+            e = rel_err(res[True][n], g0) if g0.abs().max() > 0 else float(res[True][n].abs().max())
+            if e > worst[1]:
+                worst = (n, e)
+        print(tag, task, "shared arena vs per-node arenas: worst gradient difference", worst)
+        assert worst[1] < 2e-3, (task, worst)      # (summation order of fp32 atomics / split-K slabs only)
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly on CPU tensors - it never routes through PyTorch/oracle math."""
     from mico_amd._lib import MicoHipError
