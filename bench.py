@@ -45,7 +45,9 @@ sys.path.insert(0, ROOT)
 
 # algorithmic forward GF / sample for step-B at config-3 shapes: 2 * MAC of every
 # GEMM incl. attention, LM head only where a loss consumes it; fwd+bwd = 3 x fwd
-ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74, "vitg_omni14_txt77": 24.04, "vitg_vid8_cap": 13.08}
+ALG_TFLOP_PER_SAMPLE = {"vitg_img1_aud4_txt77_stepB": 8.74, "vitg_omni14_txt77": 24.04, "vitg_vid8_cap": 13.08, "vitb16_img1_txt77_stepA": 0.1453}
+# forward GF of ONE tower block on one frame and the block count: what stochastic depth removes from the executed work
+TOWER_BLOCK_GF = {"evaclip01_giant": (40, 13.341), "evaclip02_base": (12, 2.908)}
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
 
 PRECISIONS = {   # --dtype -> (torch dtype, split_fp16, split_mode, description)
@@ -73,13 +75,15 @@ def parse():
     ap.add_argument("--layers", type=int, default=None, help="truncate the ViT (debug only; invalidates the metric)")
     ap.add_argument("--dtype", default="fp16", choices=sorted(PRECISIONS))
     ap.add_argument("--task", default=None)
-    ap.add_argument("--workload", default="omni", choices=["img_aud_txt", "omni", "vid_cap_fp8"],
+    ap.add_argument("--workload", default="omni", choices=["img_aud_txt", "omni", "vid_cap_fp8", "b16_img_txt"],
                     help="omni (default) = one rank's share of BASELINE configs[3], the configuration the metric is quoted on: image + video "
                          "(9 vision frames) + depth + audio (4) + text, 14 tower frames/sample, b = 64/GPU; img_aud_txt = BASELINE configs[2] "
                          "(image + audio + text, 5 frames/sample); vid_cap_fp8 = one rank of configs[4]: 8 video frames + BERT generative head "
-                         "(CAP), b = 32, --dtype fp8")
+                         "(CAP), b = 32, --dtype fp8; b16_img_txt = BASELINE configs[1]: ViT-B/16 (EVA02-CLIP-B/16) image + text contrastive "
+                         "step (step-A: encoders + heads + ITC), b = 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--diet", type=int, default=None, help="force the tower's saved-activation level (0 / 1 / 2; default: mico_amd.functional.tower_plan decides)")
+    ap.add_argument("--diet", type=int, default=None, help="force the tower's saved-activation level (0 / 1 / 2 / 3; default: mico_amd.functional.tower_plan decides)")
+    ap.add_argument("--diet-mlp-blocks", type=int, default=0, help="with --diet 3: the last n tower blocks keep their MLP intermediates")
     ap.add_argument("--no-comm", action="store_true", help="N = 1: skip the extra steps on a one-rank RCCL group (the `comm` object)")
     ap.add_argument("--no-extras", action="store_true", help="skip parity / parity_config / secondary (only the headline measurement)")
     ap.add_argument("--all-precisions", action="store_true", help="also time fp16-plain and fp8 on the same step (`other_precisions`)")
@@ -193,6 +197,9 @@ WORKLOADS = {
     "img_aud_txt": dict(shape=dict(vision=1, audio=4, S=77), task="ret%tva_cap%tva", key="vitg_img1_aud4_txt77_stepB", frames=5),
     "omni": dict(shape=dict(vision=9, depth=1, audio=4, S=77), task="ret%tva%tvd_cap%tva", key="vitg_omni14_txt77", frames=14),
     "vid_cap_fp8": dict(shape=dict(vision=8, S=77), task="cap%tv", key="vitg_vid8_cap", frames=8, batch=32, dtype="fp8"),
+    # BASELINE configs[1]: step-A of SURVEY.md section 8d (all encoders + heads + packed all-gather + ITC, backward) - the task prefix "itc" is
+    # this repo's name for MiCo.forward's contrastive-only objective (ret without the ITM passes)
+    "b16_img_txt": dict(shape=dict(vision=1, S=77), task="itc%tv", key="vitb16_img1_txt77_stepA", frames=1, batch=256, vision="evaclip02_base"),
 }
 
 
@@ -317,6 +324,8 @@ WORKLOAD_TEXT = {
             "b={b}/GPU, task {task} (ITC+ITM for tva and tvd, CAP)",
     "vid_cap_fp8": "BASELINE.json configs[4] per-rank share: ViT-g/14 video (8 x 224^2 frames) + BERT cross-attention generative head (CAP), "
                    "b={b}/GPU, task {task}, fp8 MFMA",
+    "b16_img_txt": "BASELINE.json configs[1]: ViT-B/16 (EVA02-CLIP-B/16: RoPE + sub-LN + SwiGLU) image(1)+text(77) contrastive fwd+bwd, b={b}/GPU, "
+                   "task {task} (step-A: encoders + heads + ITC)",
 }
 
 
@@ -337,7 +346,8 @@ def executed_tflop_per_sample(wname, task, kept, share_kv, eval_mode):
     nominal = ALG_TFLOP_PER_SAMPLE.get(wl["key"])
     if nominal is None:
         return None, None
-    executed = nominal - wl["frames"] * 40 * 13.341 * 3 / 1e3 * (1.0 - kept)
+    nblk, blk_gf = TOWER_BLOCK_GF[wl.get("vision", "evaclip01_giant")]
+    executed = nominal - wl["frames"] * nblk * blk_gf * 3 / 1e3 * (1.0 - kept)
     if share_kv and not eval_mode and task == wl["task"]:
         if wname == "img_aud_txt":        # tva: 4 sets -> 2, E = 5 x 257
             executed -= 12 * 2 * 1285 * 2 * 768 * 1536 * 3 / 1e12
@@ -354,6 +364,8 @@ def main():
         args.dtype = wl["dtype"]
     if "batch" in wl and "--batch" not in " ".join(sys.argv):
         args.batch = wl["batch"]
+    if "vision" in wl and "--vision" not in " ".join(sys.argv):
+        args.vision = wl["vision"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -381,7 +393,7 @@ def main():
     from mico_amd.distributed import GradBucketReducer, packed_all_gather
 
     set_precision(args.dtype)
-    runtime.set_activation_diet(args.diet)
+    runtime.set_activation_diet(args.diet, args.diet_mlp_blocks)
     torch.manual_seed(rank)     # host RNG: stochastic-depth draws differ per rank (weights/inputs come from counter hashes)
     from mico_amd.functional import DropPlan
     DropPlan.skip_dropped = not args.dense_droppath
@@ -404,7 +416,7 @@ def main():
                           lr=1e-6, betas=(0.9, 0.98))
     finish_ms = []
 
-    def step(the_batch, task):
+    def step(the_batch, task, model=model):
         model.zero_grad(set_to_none=True)
         losses = model(dict(the_batch), task, compute_loss=True)
         total = sum(losses.values())
@@ -419,7 +431,7 @@ def main():
             optimizer.step()
         return losses
 
-    def timed_steps(n, the_batch, task):
+    def timed_steps(n, the_batch, task, model=model):
         """EXACTLY n steps bracketed by barrier + synchronize on both sides; max over ranks."""
         torch.cuda.synchronize()
         if world > 1:
@@ -427,7 +439,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
-            losses = step(the_batch, task)
+            losses = step(the_batch, task, model)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -439,26 +451,26 @@ def main():
             el = t.item()
         return el, losses
 
-    def measure(wname, task, nb, steps, warmup, seed, detail=False):
+    def measure(wname, task, nb, steps, warmup, seed, detail=False, model=model):
         """One workload, timed: `warmup` untimed steps, then exactly `steps` timed ones with the per-launch GEMM timer on.  Returns the
         figures of a bench line for it (value, ms per step, executed TFLOP, MFMA fraction of the step, GEMM roofline, peak memory,
         the tower plan it ran under)."""
         w = WORKLOADS[wname]
         batch = {k: v.to(dev) for k, v in synth_inputs(dict(b=nb, **w["shape"]), seed=seed + rank).items()}
         for _ in range(warmup):
-            step(batch, task)
+            step(batch, task, model)
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         timer = None if args.no_gemm_timer else ops.KernelTimer()
         ops.GEMM_TIMER = timer
         DropPlan.stats[:] = [0, 0]
         finish_ms.clear()
-        el, losses = timed_steps(steps, batch, task)
+        el, losses = timed_steps(steps, batch, task, model)
         ops.GEMM_TIMER = None
         kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
         value = nb * world * steps / el
         nominal, executed = executed_tflop_per_sample(wname, task, kept, runtime.CFG.share_cross_kv, args.eval_mode)
-        full = args.layers is None and args.vision == "evaclip01_giant" and task == w["task"]
+        full = args.layers is None and model.config.vision_encoder_type == w.get("vision", "evaclip01_giant") and task == w["task"]
         step_tflops = executed * value / world if (full and executed) else None
         roofline = None
         if timer is not None and timer.records:
@@ -575,7 +587,7 @@ def main():
     roofline = head.pop("roofline")
     if roofline is not None:
         dom = roofline.pop("_dom")
-        for tname in ("r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json"):
+        for tname in ("r05_gemm_hbm_traffic.json", "r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
@@ -638,6 +650,44 @@ def main():
             del sbatch
         except Exception as e:   # the headline line must survive a failure of the secondary measurement
             res["secondary"] = {"error": repr(e)}
+        # ---- BASELINE configs[1] (ViT-B/16 image + text contrastive step, b = 256): its own model, timed with its own GEMM roofline ----
+        if args.workload != "b16_img_txt":
+            try:
+                torch.cuda.empty_cache()
+                wb = WORKLOADS["b16_img_txt"]
+                mb = MiCo(default_cfg(wb["vision"]))
+                mb.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in mb.state_dict().items()}, seed=0), strict=False)
+                mb.to(dev)
+                mb.eval() if args.eval_mode else mb.train()
+                secb, bb = measure("b16_img_txt", wb["task"], wb["batch"], max(10, args.steps // 2), 3, seed=2468, model=mb)
+                rb = secb.get("roofline")
+                if rb is not None:
+                    rb.pop("_dom", None)
+                    rb.pop("variants", None)
+                secb["precision"] = PRECISIONS[args.dtype][3] + " (EVA02-style towers: their head-split blocks run the 3-segment mode, DESIGN.md section 4)"
+                secb["workload"] = WORKLOAD_TEXT["b16_img_txt"].format(b=wb["batch"], task=wb["task"])
+                res.setdefault("secondary", {})["configs1_b16_img_txt"] = secb
+                del bb, mb
+            except Exception as e:
+                res.setdefault("secondary", {})["configs1_b16_img_txt"] = {"error": repr(e)}
+        # ---- what skipping the dropped stochastic-depth branches is worth: the same step on the reference's schedule (every branch
+        # evaluated, dropped ones multiplied by 0) - identical values and gradients, more work, its own tower plan ----
+        if not args.eval_mode and not args.dense_droppath:
+            try:
+                torch.cuda.empty_cache()
+                DropPlan.skip_dropped = False
+                kd = max(3, args.steps // 5)
+                dm, db_ = measure(args.workload, args.task, b, kd, 1, seed=1234)
+                del db_
+                res["droppath_ab"] = dict(skipped_branches=dict(value=head["value"], ms_per_step=head["ms_per_step"], kept_branch_fraction=head["kept_branch_fraction"]),
+                                          dense_reference_schedule=dict(value=dm["value"], ms_per_step=dm["ms_per_step"], steps=kd, warmup=1,
+                                                                        peak_mem_gb=dm["peak_mem_gb"], tower_plan=dm["tower_plan"]),
+                                          unit="samples/s", speedup=head["value"] / dm["value"],
+                                          note="same step, same precision, same process; `dense` = bench.py --dense-droppath")
+            except Exception as e:
+                res["droppath_ab"] = {"error": repr(e)}
+            finally:
+                DropPlan.skip_dropped = True
         # ---- the same (headline) step in the configuration with margin under the 1e-3 gate, timed next to it ----
         torch.cuda.empty_cache()
         pc = "fp16-split-w" if args.dtype != "fp16-split-w" else "fp16"

@@ -119,12 +119,10 @@ typedef struct mico_gemm_epilogue {
  * producer/consumer, 3 = 256x256 one wave per SIMD (experiment builds), 4 = MX-fp8, 5 = 256x256 8-wave persistent, 6 / 7 = 256x128 four-wave kernels, two
  * workgroups per CU (32-deep stages / 64-deep unit ring) (profiling aid: lets a caller attribute its per-launch timings to the kernel rocprofv3 reports) */
 int mico_gemm_last_kernel(void);
-/* kernel routing switch for A/B measurements (process-wide; returns the previous value): 0 = default routing, 1 = never the
- * one-wave-per-SIMD kernel, 2 / 3 = the one-wave-per-SIMD experiment kernel (builds with -DMICO_GEMM_W4 only) takes every large problem it
- * supports, 4 = never the persistent form of the 8-wave kernel, 5 / 6 and 8 / 9 = the 256x128 two-workgroups-per-CU kernels (32-deep stages /
- * 64-deep unit ring) take every large forward / dX problem / only those with K <= 2048, 7 = never (the default routes the GELU-pair forward
- * and the short-K residual-scatter forward to the unit-ring kernel) */
-int mico_gemm_set_variant(int variant);
+/* (The product library routes by the problem alone and keeps no process-global routing state.  The experiment switch of earlier rounds,
+ * mico_gemm_set_variant(v) - force the 32-deep 8-wave kernel (12), the 256x128 two-workgroups-per-CU kernels (5 / 6, 8 / 9), the 8-phase kernel
+ * (10; 15 = with its generic epilogue) ... onto every large problem they support, for same-process A/B measurements - is exported by the probe
+ * build only: `make -C mico_amd/csrc variants` -> tools/probes/bin/libmico_variants.so, loaded through MICO_HIP_LIB.) */
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,
               void* C, int64_t ldc, int c_dtype,

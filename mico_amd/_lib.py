@@ -67,7 +67,6 @@ PROTOTYPES = {
     "mico_last_error_string": [],
     "mico_struct_layout": [C.POINTER(c_int), c_int],
     "mico_gemm_last_kernel": [],
-    "mico_gemm_set_variant": [c_int],
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_quant_mx8": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_f, c_int, c_vp],
@@ -168,9 +167,22 @@ def lib():
                            "(`make -C mico_amd/csrc`)")
     _check_struct_layout(l)
     _lib = l
-    if os.environ.get("MICO_GEMM_VARIANT"):      # A/B runs of whole test files / benches without touching their code
-        l.mico_gemm_set_variant(int(os.environ["MICO_GEMM_VARIANT"]))
+    if os.environ.get("MICO_GEMM_VARIANT"):      # A/B runs of whole test files / benches without touching their code (probe build only)
+        set_gemm_variant(int(os.environ["MICO_GEMM_VARIANT"]), l)
     return l
+
+
+def set_gemm_variant(v, l=None):
+    """mico_gemm_set_variant of the probe build (`make -C mico_amd/csrc variants`, MICO_HIP_LIB=tools/probes/bin/libmico_variants.so): the product
+    library has no routing switch.  Returns the previous value."""
+    l = l or lib()
+    try:
+        fn = l.mico_gemm_set_variant
+    except AttributeError:
+        raise MicoHipError(f"{LIB_PATH} has no kernel-routing switch (the product library routes by the problem alone): build the probe library "
+                           "with `make -C mico_amd/csrc variants` and point MICO_HIP_LIB at tools/probes/bin/libmico_variants.so") from None
+    fn.argtypes, fn.restype = [c_int], c_int
+    return fn(int(v))
 
 
 def check(rc, what):

@@ -2779,10 +2779,20 @@ int mico_set_err(int code, const char* fmt, ...) {
     return code;
 }
 
-thread_local int g_mico_last_gemm_kernel = 0;
-static int g_mico_gemm_variant = 0;   // 0 = default routing; 1 = never the one-wave-per-SIMD kernel; 2 = it takes every large problem
+thread_local int g_mico_last_gemm_kernel = 0;   // per calling thread: mico_gemm_last_kernel() is safe next to other threads' launches
+// Kernel routing of mico_gemm.  The product library routes by the problem alone (variant 0, a compile-time constant: mico_gemm keeps no
+// process-global routing state and the kernels only other variants reach are not instantiated).  The experiment switch - force the 32-deep
+// 8-wave kernel / the 256x128 kernels / the 8-phase kernel with its generic epilogue ... for same-process A/B runs and for the test that
+// runs EVERY large-tile kernel on a chip-filling problem - exists in the probe build only: `make -C mico_amd/csrc variants`
+// (-DMICO_GEMM_VARIANTS=1 -> tools/probes/bin/libmico_variants.so, which also exports mico_gemm_set_variant).
+#ifdef MICO_GEMM_VARIANTS
+static int g_mico_gemm_variant = 0;   // 0 = default routing; see the routing block of mico_gemm for the values
 static int g_mico_mid_group = 0;       // sweeps: variant / 100 overrides the MID kernel's tile-order group height
 extern "C" int mico_gemm_set_variant(int v) { const int old = g_mico_gemm_variant + 100 * g_mico_mid_group; g_mico_gemm_variant = v % 100; g_mico_mid_group = v / 100; return old; }
+#else
+static constexpr int g_mico_gemm_variant = 0;
+static constexpr int g_mico_mid_group = 0;
+#endif
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
 extern "C" int mico_version(void) { return 111; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
@@ -3102,7 +3112,9 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         } else DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st)));
     }
     else if (mid64) { g_mico_last_gemm_kernel = 7; DISPATCH_T16(dtype, (launch_mid<T>(tb, g, st))); }
+#ifdef MICO_GEMM_VARIANTS
     else if (mid) { g_mico_last_gemm_kernel = 6; DISPATCH_T16(dtype, (launch<T, Mid>(ta, tb, g, st))); }
+#endif
     else if (big) {
         // persistent form when every CU gets several tiles and nothing is split (variant 4 forces it off, for A/B runs)
         bool done = false;

@@ -891,6 +891,10 @@ def _slice_groups(groups, c0, c1):
 
 
 _SOFT_FRAC = float(os.environ.get("MICO_HBM_SOFT_FRAC", "0.82"))
+# Level 3 fills what its smaller rows free with MLP intermediates - up to the soft budget minus this margin: the budget's activation estimate is
+# exact for them (4 hidden bytes per kept MLP token) while the levels' own bytes are priced with slack (kept + 0.02), so a plan filled to the
+# brim peaks ~10 GiB above the same budget's level-2 plan (measured on one rank of configs[3]: 237 against 227 GiB with 14 blocks kept)
+_MLP_KEEP_MARGIN = int(float(os.environ.get("MICO_MLP_KEEP_MARGIN_GIB", "6")) * (1 << 30))
 
 
 def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
@@ -964,7 +968,7 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
             elif lv == 3 and n_chunks == 1:
                 # one pass at level 3: what is left of the budget keeps MLP intermediates, last block first; a kept block saves its share
                 # (by kept tokens) of the fc1 recompute
-                left = budget - pf * n_frames
+                left = budget - pf * n_frames - _MLP_KEEP_MARGIN
                 saved_tokens = 0.0
                 for i in reversed(range(depth)):
                     need = block_tokens[i] * 4 * Hd
@@ -979,7 +983,12 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
         return best
 
     bs, bh = cheapest(soft), cheapest(hard)
-    best = bs if bs[0] <= bh[0] + 0.05 else bh
+    if bs[1] >= n_frames or bs[0] <= bh[0] + 0.05:
+        best = bs       # (one pass under the soft budget: how many blocks keep their MLP intermediates is the soft budget's decision too)
+    else:
+        # only chunked recomputation keeps the step under the soft budget and the hard one avoids it: take the hard budget's level and chunking,
+        # but none of its optional extras (MLP intermediates kept at level 3)
+        best = (bh[0], bh[1], bh[2], forced_diet[1] if (forced_diet is not None and bh[2] == 3) else 0)
     return best[1], TowerDiet(depth, best[2], best[3])
 
 

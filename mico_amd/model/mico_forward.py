@@ -95,7 +95,9 @@ def _condition_feats(self, enc, cond):
     return torch.cat([enc["condition_feats_" + m] for m in cond], dim=1)
 
 
-def _forward_ret(self, batch, enc, subtasks):
+def _forward_ret(self, batch, enc, subtasks, itm=True):
+    """ITC + ITM of vast.py:395-457.  itm=False: the contrastive objective alone (step-A of SURVEY.md section 8d, BASELINE configs[1]) - the
+    ITM hard-negative passes are not run and no "loss_itm" is returned (task prefix "itc%...", an addition of this repo)."""
     inj = batch.get("_injected", {})
     world = batch.get("_world")
     ids, am = _tokens(self, batch)
@@ -117,6 +119,8 @@ def _forward_ret(self, batch, enc, subtasks):
         sim_c2t = Fn.matmul_nt(fc, feat_t_all) / self.contra_temp                       # vast.py:405-408
         sim_t2c = Fn.matmul_nt(feat_t, fc_all) / self.contra_temp
         loss_itc.append((Fn.cross_entropy(sim_c2t, targets, 0.1) + Fn.cross_entropy(sim_t2c, targets, 0.1)) / 2)
+        if not itm:
+            continue
         # ---- ITM hard negatives (vast.py:421-457) ----
         cond = _condition_feats(self, enc, st[1:])
         if st in inj:
@@ -148,6 +152,8 @@ def _forward_ret(self, batch, enc, subtasks):
         gt = torch.zeros(bs * 3, dtype=torch.long, device=ids.device)
         gt[:bs] = 1
         loss_itm.append(self.itm_ratio * Fn.cross_entropy(logits, gt))
+    if not itm:
+        return {"loss_itc": sum(loss_itc) / len(loss_itc)}
     return {"loss_itc": sum(loss_itc) / len(loss_itc), "loss_itm": sum(loss_itm) / len(loss_itm)}
 
 
@@ -198,6 +204,9 @@ def forward(self, batch, task, compute_loss=True):
                 for st in subtasks:
                     out[f"feat_cond_{st}"] = _feat_cond(self, enc, st[1:])
                     out[f"condition_feats_{st}"] = _condition_feats(self, enc, st[1:])
+        elif t.startswith("itc"):      # contrastive objective only (no ITM passes): step-A of SURVEY.md section 8d
+            assert compute_loss, "itc%... is a training objective"
+            out.update(_forward_ret(self, batch, enc, subtasks, itm=False))
         elif t.startswith("cap"):
             if compute_loss:
                 out.update(_forward_cap(self, batch, enc, subtasks))

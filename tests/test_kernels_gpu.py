@@ -102,56 +102,17 @@ def test_gemm_chip_filling_kernels(cuda, dtype, variant):
     256x256x64 kernel (10; its k-segment launch falls back to the 32-deep kernel) - plain forward / dX,
     the towers' residual-scatter epilogue (its own instantiation, ACT_RESID: frame map, per-frame scale, fp32 stream updated in place), the
     MLP's GELU pair, and a split-precision (2 k-segment) forward."""
-    from mico_amd import ops, _lib
-    torch.manual_seed(5)
-    frames, rows_per = 131, 257
-    M, N, K = frames * rows_per - 100, 1368, 1408
-    A = (0.5 * torch.randn(M, K, device=cuda)).to(dtype)
-    W = (0.05 * torch.randn(N, K, device=cuda)).to(dtype)
-    bias = torch.randn(N, device=cuda)
-    acc = A.float() @ W.float().t()
-    old = _lib.lib().mico_gemm_set_variant(variant)
-    try:
-        y = torch.empty(M, N, device=cuda, dtype=dtype)
-        ops.gemm(A, W, y, bias=bias)
-        assert _lib.lib().mico_gemm_last_kernel() == {12: 1, 5: 6, 8: 7, 10: 8}[variant]
-        assert rel_err(y, acc + bias) < tol(dtype)
-        # dX orientation: the weight read reduction-major
-        Wt = W.t().contiguous()
-        y2 = torch.empty(M, N, device=cuda, dtype=dtype)
-        ops.gemm(A, Wt, y2, tb=True, M=M, N=N, K=K)
-        assert rel_err(y2, acc) < tol(dtype)
-        # residual scatter: the compact rows of the kept frames go to frames fmap[f] of the fp32 stream, scaled per frame, in place
-        nf = (M + rows_per - 1) // rows_per
-        fmap = (torch.arange(nf, device=cuda, dtype=torch.int32) * 3 // 2).contiguous()          # skips every third frame
-        stream = torch.randn((int(fmap[-1]) + 1) * rows_per, N, device=cuda)
-        rs = torch.rand(int(fmap[-1]) + 1, device=cuda) + 0.5
-        ref = stream.clone()
-        rows = (fmap.long().repeat_interleave(rows_per) * rows_per + torch.arange(rows_per, device=cuda).repeat(nf))[:M]
-        ref[rows] += (acc + bias) * rs[fmap.long()].repeat_interleave(rows_per)[:M, None]
-        ops.gemm(A, W, stream, bias=bias, resid=stream, row_scale=rs, rows_per_scale=rows_per, row_map=fmap, rows_per_map=rows_per)
-        assert rel_err(stream, ref) < 1e-5 * math.sqrt(K)
-        # the MLP pair
-        gd = torch.empty(M, N, device=cuda, dtype=dtype)
-        a2 = torch.empty(M, N, device=cuda, dtype=dtype)
-        ops.gemm(A, W, a2, bias=bias, aux_out=gd, act=ops.ACT_GELU_SAVE_DERIV)
-        pre = acc + bias
-        gp32 = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
-        assert rel_err(a2, F.gelu(pre)) < tol(dtype) and rel_err(gd, gp32) < tol(dtype)
-        dh = torch.empty(M, N, device=cuda, dtype=dtype)
-        ops.gemm(A, Wt, dh, tb=True, M=M, N=N, K=K, aux_in=gd, act=ops.ACT_MUL_AUX, alpha=0.5)
-        assert rel_err(dh, 0.5 * acc * gd.float()) < tol(dtype)
-        # two k-segments (x W_hi + x W_lo of the split-weights precision mode): A read twice, B = [hi | lo]
-        if dtype == torch.float16:
-            Wf = 0.05 * torch.randn(N, K, device=cuda)
-            hi = Wf.to(dtype)
-            lo = (Wf - hi.float()).to(dtype)
-            Wcat = torch.cat((hi, lo), dim=1).contiguous()
-            y3 = torch.empty(M, N, device=cuda, dtype=torch.float32)
-            ops.gemm(A, Wcat, y3, ksegs=(K, [0, 0], [0, K]))
-            assert rel_err(y3, A.float() @ Wf.t()) < 2e-5 * math.sqrt(K)
-    finally:
-        _lib.lib().mico_gemm_set_variant(old)
+    # (the product library routes by the problem alone and has no switch to force a kernel: the case runs in a process of its own on the probe
+    # build that has it - tests/gemm_variant_case.py, `make -C mico_amd/csrc variants`)
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "probes", "bin", "libmico_variants.so")
+    assert os.path.exists(lib), "probe build missing: make -C mico_amd/csrc variants (python -c 'import __graft_entry__ as g; g.build()' builds it)"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gemm_variant_case.py"), str(variant), "f16" if dtype == torch.float16 else "bf16"],
+                       env=dict(os.environ, MICO_HIP_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-3000:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -246,7 +207,10 @@ def test_layernorm_normalised_rows(cuda, dtype, gather):
     dga, dba, dgb, dbb = (torch.zeros(D, device=cuda) for _ in range(4))
     ops.layernorm_bwd(dy, xc, gmm, m0, r0, dy_scale=0.25, dx_add=g_a, dx32=g_a, dgamma=dga, dbeta=dba, dtype=dtype, **kw)
     ops.layernorm_bwd(dy, xh, gmm, None, r0, dy_scale=0.25, dx_add=g_b, dx32=g_b, dgamma=dgb, dbeta=dbb, dtype=dtype, x_normalized=True, **kw)
-    assert rel_err(g_b, g_a) < 1e-3 and rel_err(dgb, dga) < 1e-3 and torch.equal(dbb, dba)
+    # dx: the rounding enters through two row means only; dgamma = sum over rows of dy * xhat is a sum of random signs, so the fp16 rounding of
+    # xhat (relative 2^-12 rms per element) shows at ~1e-3 of its largest entry (tools/probes/ln_xhat_diag.py: the kernels agree with fp32
+    # torch evaluations of both forms to 2e-7; the difference between the forms is the rounding itself)
+    assert rel_err(g_b, g_a) < 1e-4 and rel_err(dgb, dga) < 5e-3 and torch.equal(dbb, dba)
     # refusals: a normalised input is fp16 and produces no statistics / copies
     from mico_amd._lib import MicoHipError
     with pytest.raises(MicoHipError):

@@ -39,7 +39,7 @@ def main():
         y = torch.empty(n, n, device=dev, dtype=dt)
         for v in variants * 2:
             if v is not None:
-                ops._lib.lib().mico_gemm_set_variant(v)
+                ops._lib.set_gemm_variant(v)
             for _ in range(3):
                 ops.gemm(x, w, y)
             torch.cuda.synchronize()
@@ -84,7 +84,7 @@ def main():
             if (a.only and cname not in a.only.split(",")) or (a.mx8 and cname in ("dx", "dw")):
                 continue
             if var is not None:
-                ops._lib.lib().mico_gemm_set_variant(var)
+                ops._lib.set_gemm_variant(var)
                 cname = f"{cname}@{var}"
             for _ in range(3):
                 fn()

@@ -25,7 +25,7 @@ def run(ta, tb, M, N, K, dtype, reps=4, lda=None, ldb=None):
 import sys
 vs = [int(x) for x in sys.argv[1:]] or [3]
 for v in vs:
-    _lib.lib().mico_gemm_set_variant(v)
+    _lib.set_gemm_variant(v)
     print("variant", v)
     for dt in (torch.bfloat16,):
         run(False, True, 8232, 2048, 1408, dt, reps=4)
@@ -41,5 +41,5 @@ def run_sk(dtype):
         d = (dw - ref).abs()
         print(f"  split-K TT {dtype} split_k={sk}: rel err {(d.max() / ref.abs().max()).item():.2e} (tol {2e-5 * rows ** 0.5:.2e}) bad {(d > 1e-2 * ref.abs().max()).sum().item()}")
 for v in vs:
-    _lib.lib().mico_gemm_set_variant(v)
+    _lib.set_gemm_variant(v)
     print("variant", v); run_sk(torch.bfloat16)

@@ -15,7 +15,7 @@ from mico_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 M = int(os.environ.get("PHASES_M", "82240"))
 if os.environ.get("PHASES_VARIANT"):
-    _lib.lib().mico_gemm_set_variant(int(os.environ["PHASES_VARIANT"]))
+    _lib.set_gemm_variant(int(os.environ["PHASES_VARIANT"]))
 for name, K, N in (("qkv", 1408, 4224), ("fc1", 1408, 6144), ("fc2", 6144, 1408)):
     x = torch.randn(M, K, device=dev).bfloat16()
     w = (0.02 * torch.randn(N, K, device=dev)).bfloat16()

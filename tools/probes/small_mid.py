@@ -4,7 +4,7 @@ from mico_amd import ops, _lib
 dev = torch.device("cuda:0")
 dt = torch.float16
 def run(M, N, K, variant, tb=False, iters=20):
-    _lib.lib().mico_gemm_set_variant(variant)
+    _lib.set_gemm_variant(variant)
     x = torch.randn(M, K, device=dev).to(dt)
     w = (0.02 * torch.randn((K, N) if tb else (N, K), device=dev)).to(dt)
     y = torch.empty(M, N, device=dev, dtype=dt)
