@@ -239,7 +239,7 @@ def test_tower_forward_oom_retry(cuda, monkeypatch):
                 attempt = real(*a, **k)      # the error comes LATE: every buffer of the failed attempt is alive in this frame when it leaves it
                 mem["at_raise"] = torch.cuda.memory_allocated()
                 raise torch.cuda.OutOfMemoryError("injected")
-            mem["at_retry"] = torch.cuda.memory_allocated()
+            mem.setdefault("at_retry", torch.cuda.memory_allocated())      # (the first call after the failure: chunks and the backward's recompute follow)
             return real(*a, **k)
 
         monkeypatch.setattr(Fn, "_tower_forward", flaky)
@@ -252,7 +252,7 @@ def test_tower_forward_oom_retry(cuda, monkeypatch):
         plan = rt.last_tower_plan
         assert plan.get("oom_retry") and all(plan[k] == v for k, v in want.items()), plan
         # the retry must not run on top of the failed attempt's activations (the handler's traceback kept them alive)
-        assert mem["at_raise"] - mem["before"] > 50 << 20, mem                    # (the failed attempt held its saved activations)
+        assert mem["at_raise"] - mem["before"] > 20 << 20, mem                    # (the failed attempt held its saved activations)
         assert mem["at_retry"] - mem["before"] < 0.25 * (mem["at_raise"] - mem["before"]), mem
         assert rel_err(o1, o0) < 1e-6       # (chunks draw per-chunk plans from the same masks: the same frames are kept)
         for n in g0:

@@ -20,8 +20,19 @@ python tools/prof_summary.py $f 45 > $O/${TAG}_kernel_stats.txt; cp $f $O/${TAG}
 $B --steps 10 --warmup 3 --gemm-detail > $O/bench_detail.json 2> $O/${TAG}_gemm_detail.txt
 python bench.py > $O/${TAG}_bench_line.json 2> $O/bench_line.err
 if [ "${PROFILE_VIDCAP:-0}" = 1 ]; then
-  python bench.py --workload vid_cap_fp8 --no-cpu-baseline --no-comm > $O/${TAG}_bench_line_fp8_vidcap.json 2> $O/bench_fp8.err
-  python bench.py --workload vid_cap_fp8 --dtype bf16 --no-cpu-baseline --no-comm > $O/${TAG}_bench_line_bf16_vidcap.json 2> $O/bench_bf16.err
+  # BASELINE configs[4] shapes: the fp8 mode and the same step in bf16 on the same box (two alternating pairs), + the fp8 step's kernel table
+  for i in 1 2; do
+    python bench.py --workload vid_cap_fp8 --no-cpu-baseline --no-comm > $O/${TAG}_bench_line_fp8_vidcap$i.json 2> $O/bench_fp8.err
+    python bench.py --workload vid_cap_fp8 --dtype bf16 --no-cpu-baseline --no-comm > $O/${TAG}_bench_line_bf16_vidcap$i.json 2> $O/bench_bf16.err
+  done
+  mv $O/${TAG}_bench_line_fp8_vidcap2.json $O/${TAG}_bench_line_fp8_vidcap.json; mv $O/${TAG}_bench_line_bf16_vidcap2.json $O/${TAG}_bench_line_bf16_vidcap.json
+  (cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fp8 -- python $R/bench.py --workload vid_cap_fp8 --no-cpu-baseline --no-extras --no-comm --steps 3 --warmup 2 > $O/stats_fp8.log 2>&1)
+  f8=$(find $O/stats_fp8 -name "*kernel_stats.csv" | head -1)
+  python tools/prof_summary.py $f8 30 > $O/${TAG}_kernel_stats_fp8_vidcap.txt
+fi
+if [ "${PROFILE_CALIB:-0}" = 1 ]; then
+  # the vendor library (hipBLASLt behind torch.matmul) on the towers' layer shapes next to mico_gemm, same process, same box
+  python tools/probes/hipblaslt_ref.py --m 184269 > $O/${TAG}_hipblaslt_calibration.txt 2>&1
 fi
 find $O -name "*.csv" -size +3M -delete; find $O -name "*.db" -delete
 head -30 $O/${TAG}_kernel_stats.txt; cat $O/${TAG}_bench_line.json
