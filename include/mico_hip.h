@@ -470,6 +470,37 @@ int mico_win_attn_bwd(const void* qkv, const void* dout, const float* lse, const
                       int batch, int res, int heads, int shift, float scale, float dbias_scale, int dtype, void* stream);
 int mico_patch_merge(const float* in, float* out, int batch, int res, int channels, int backward, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel alignment step over RCCL / xGMI (ABI 112; SURVEY section 8b: mico_comm_*).  For a binding that does not go
+ * through torch.distributed; mico_amd/distributed.py keeps torch.distributed as its default transport and takes these with MICO_COMM=1
+ * (mico_amd/comm.py).  One communicator per process and GPU.  RCCL is resolved at run time (the librccl.so.1 already resident in the
+ * process, else the ROCm one): libmico_hip.so has no link-time dependency on it and a single-GPU user never loads it.
+ * Every call is asynchronous on `stream`; buffers are device memory owned by the caller; counts are host integers.
+ *   mico_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId); the caller distributes them (a broadcast of its own, a file, MPI ...).
+ *   mico_comm_init: collective over all ranks, on the calling thread's current HIP device.  mico_comm_destroy(NULL) is a no-op.
+ *   mico_comm_allgather: recv [nranks][bytes_per_rank] <- every rank's send [bytes_per_rank].
+ *   mico_comm_allgather_packed: replaces the 3 + #subtasks all-gathers of data/utils/distributed.py:50-66 as called at vast.py:395-404 with ONE:
+ *     nparts (<= 8) per-rank tensors of `rows` rows and row_bytes[i] bytes per row are packed row by row into pack_scratch
+ *     [rows, sum(row_bytes)] (one small kernel) and gathered into recv [nranks * rows, sum(row_bytes)]; part i of row r of rank q is at
+ *     recv + ((q * rows + r) * sum + off_i).  The parts are autograd constants exactly like concat_all_gather's outputs.
+ *   mico_comm_alltoallv: the row exchange of the index-then-fetch that replaces all_gather_with_grad(condition_feats)[neg_idx]
+ *     (data/utils/distributed.py:12-47, vast.py:421-433): send holds send_bytes[p] bytes for every peer p back to back, recv receives
+ *     recv_bytes[p] from every peer p back to back (counts known on the host after the index all-gather); the gradient route is the same
+ *     call with the two count arrays swapped.
+ *   mico_comm_allreduce_f32 (in place; average != 0: divided by nranks) / mico_comm_reduce_scatter_f32: gradient averaging - the towers'
+ *     arena slices in place from inside the backward, flat buckets as reduce-scatter (+ mico_comm_allgather).
+ * ------------------------------------------------------------------------------------------------------------- */
+#define MICO_COMM_ID_BYTES 128
+int mico_comm_unique_id(void* id_out);
+int mico_comm_init(void** comm_out, int rank, int nranks, const void* id);
+int mico_comm_destroy(void* comm);
+int mico_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int mico_comm_allgather_packed(void* comm, const void* const* parts, const int64_t* row_bytes, int nparts, int64_t rows,
+                               void* pack_scratch, void* recv, void* stream);
+int mico_comm_alltoallv(void* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes, void* stream);
+int mico_comm_allreduce_f32(void* comm, float* buf, int64_t count, int average, void* stream);
+int mico_comm_reduce_scatter_f32(void* comm, const float* send, float* recv, int64_t count_per_rank, int average, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

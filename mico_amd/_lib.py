@@ -113,6 +113,14 @@ PROTOTYPES = {
     "mico_fbank_windows": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_f, c_f, c_vp, c_vp],
     "mico_adamw_step": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp],
     "mico_grads_finite": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp],
+    "mico_comm_unique_id": [c_vp],
+    "mico_comm_init": [C.POINTER(c_vp), c_int, c_int, c_vp],
+    "mico_comm_destroy": [c_vp],
+    "mico_comm_allgather": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "mico_comm_allgather_packed": [c_vp, C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_i64, c_vp, c_vp, c_vp],
+    "mico_comm_alltoallv": [c_vp, c_vp, C.POINTER(c_i64), c_vp, C.POINTER(c_i64), c_vp],
+    "mico_comm_allreduce_f32": [c_vp, c_vp, c_i64, c_int, c_vp],
+    "mico_comm_reduce_scatter_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }
 _RESTYPES = {"mico_last_error_string": C.c_char_p}
 
@@ -123,7 +131,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 111   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 112   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

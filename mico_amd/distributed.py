@@ -81,6 +81,9 @@ def packed_all_gather(tensors):
     like concat_all_gather)."""
     if not is_dist():
         return [t.detach() for t in tensors]
+    from . import comm
+    if comm.enabled() and tensors[0].is_cuda:      # MICO_COMM=1: pack kernel + one ncclAllGather on the compute stream (mico_comm_allgather_packed)
+        return comm.get().allgather_packed(tensors)
     b = tensors[0].shape[0]
     flat = [t.detach().contiguous().view(b, -1).view(torch.uint8) for t in tensors]
     widths = [f.shape[1] for f in flat]
@@ -102,6 +105,9 @@ def packed_all_gather(tensors):
 def _exchange(send, send_counts, recv_counts):
     """Variable-size row exchange: send[sum(send_counts), ...] split by destination rank -> received rows by source rank."""
     W = dist.get_world_size()
+    from . import comm
+    if comm.enabled() and send.is_cuda:            # MICO_COMM=1: grouped ncclSend / ncclRecv on the compute stream (mico_comm_alltoallv)
+        return comm.get().alltoallv_rows(send, send_counts, recv_counts)
     recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if _nccl():
         dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts)

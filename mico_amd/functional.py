@@ -317,12 +317,20 @@ class TowerDiet:
     nothing else kept except the MLP intermediates of the LAST mlp_blocks blocks (the first ones the backward frees)."""
     __slots__ = ("xh16", "keep_mlp", "keep_ln", "level", "mlp_blocks")
 
-    def __init__(self, depth, level=0, mlp_blocks=0):
+    def __init__(self, depth, level=0, mlp_blocks=0, keep=None):
+        """mlp_blocks: at level 3, the LAST n blocks keep their MLP intermediates; keep (level 3): an explicit set of block indices instead
+        (tower_plan picks them by what their recompute costs per byte)."""
         level = int(level)
         assert 0 <= level <= 3
         self.level, self.xh16 = level, level == 3
-        self.mlp_blocks = depth if level == 0 else (min(depth, max(0, int(mlp_blocks))) if level == 3 else 0)
-        self.keep_mlp = [level == 0 or (level == 3 and i >= depth - self.mlp_blocks) for i in range(depth)]
+        if level == 3 and keep is not None:
+            kset = {int(i) for i in keep if 0 <= int(i) < depth}
+        elif level == 3:
+            kset = set(range(depth - min(depth, max(0, int(mlp_blocks))), depth))
+        else:
+            kset = set(range(depth)) if level == 0 else set()
+        self.keep_mlp = [i in kset for i in range(depth)]
+        self.mlp_blocks = len(kset)
         self.keep_ln = [level <= 1] * depth
 
     @classmethod
@@ -330,7 +338,22 @@ class TowerDiet:
         return diet if isinstance(diet, cls) else cls(depth, diet or 0)
 
     def describe(self):
-        return self.level if self.level < 3 else f"3 (fp16 normalised rows; MLP intermediates kept in the last {self.mlp_blocks} of {len(self.keep_mlp)} blocks)"
+        if self.level < 3:
+            return self.level
+        kept = [i for i, k in enumerate(self.keep_mlp) if k]
+        return f"3 (fp16 normalised rows; MLP intermediates kept in {len(kept)} of {len(self.keep_mlp)} blocks: {_ranges(kept)})"
+
+
+def _ranges(idx):
+    """[0, 1, 2, 3, 31, 32, 39] -> '0-3, 31-32, 39'"""
+    out, i = [], 0
+    while i < len(idx):
+        j = i
+        while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+            j += 1
+        out.append(str(idx[i]) if i == j else f"{idx[i]}-{idx[j]}")
+        i = j + 1
+    return ", ".join(out) if out else "none"
 
 
 class DropPlan:
@@ -953,7 +976,10 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
         block_tokens = [kept * n_frames * N] * depth
     else:
         block_tokens = [t * (kept / max(kept - 0.02, 1e-6)) for t in block_tokens]      # (the same slack)
-    mlp_tokens_total = float(sum(block_tokens)) or 1.0
+    # what re-running fc1 costs per kept token of block i, relative to a plain block: the head-split blocks of the timed precision
+    # (runtime.CFG.head_split_blocks: x W_hi + x W_lo, K doubled) cost twice - their intermediates are the most valuable bytes to keep
+    fc1_w = [runtime.fc1_recompute_weight(i, bool(spec.arch["swiglu"])) for i in range(depth)]
+    mlp_work_total = float(sum(w * t for w, t in zip(fc1_w, block_tokens))) or 1.0
 
     def cheapest(budget):
         best = None
@@ -962,24 +988,26 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
             most = max(1, int(max(budget, 0) // pf))
             n_chunks = -(-n_frames // most)
             cost = extra[lv] + (n_chunks - 1) / n_chunks
-            mlp_blocks = 0
+            keep = None
             if lv == 3 and forced_diet is not None:
-                mlp_blocks = forced_diet[1]
+                keep = list(range(depth - min(depth, max(0, forced_diet[1])), depth))
             elif lv == 3 and n_chunks == 1:
-                # one pass at level 3: what is left of the budget keeps MLP intermediates, last block first; a kept block saves its share
-                # (by kept tokens) of the fc1 recompute
+                # one pass at level 3: what is left of the budget keeps MLP intermediates.  The LAST block first (the backward starts there: its
+                # recompute buffers would sit on top of the step's peak, every later recompute reuses what the finished blocks freed), then by
+                # recompute cost per byte - the head-split blocks, then from the end of the tower backwards.  A kept block saves its share of
+                # the fc1 recompute.
                 left = budget - pf * n_frames - _MLP_KEEP_MARGIN
-                saved_tokens = 0.0
-                for i in reversed(range(depth)):
+                order = [depth - 1] + sorted(range(depth - 1), key=lambda i: (-fc1_w[i], -i))
+                keep, saved = [], 0.0
+                for i in order:
                     need = block_tokens[i] * 4 * Hd
-                    if need > left:
-                        break
-                    left -= need
-                    saved_tokens += block_tokens[i]
-                    mlp_blocks += 1
-                cost = 0.02 + 0.33 * (1.0 - saved_tokens / mlp_tokens_total)
+                    if need <= left:
+                        left -= need
+                        saved += fc1_w[i] * block_tokens[i]
+                        keep.append(i)
+                cost = 0.02 + 0.33 * (1.0 - saved / mlp_work_total)
             if best is None or cost < best[0] - 1e-9:
-                best = (cost, -(-n_frames // n_chunks), lv, mlp_blocks)      # equal chunks: the one whose activations are kept is then as large as the others
+                best = (cost, -(-n_frames // n_chunks), lv, keep)      # equal chunks: the one whose activations are kept is then as large as the others
         return best
 
     bs, bh = cheapest(soft), cheapest(hard)
@@ -988,8 +1016,8 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     else:
         # only chunked recomputation keeps the step under the soft budget and the hard one avoids it: take the hard budget's level and chunking,
         # but none of its optional extras (MLP intermediates kept at level 3)
-        best = (bh[0], bh[1], bh[2], forced_diet[1] if (forced_diet is not None and bh[2] == 3) else 0)
-    return best[1], TowerDiet(depth, best[2], best[3])
+        best = (bh[0], bh[1], bh[2], bh[3] if (forced_diet is not None and bh[2] == 3) else None)
+    return best[1], TowerDiet(depth, best[2], keep=best[3] if best[2] == 3 else None)
 
 
 def tower_chunk_frames(spec, n_frames, device):
@@ -1020,10 +1048,11 @@ class EvaTowerFn(torch.autograd.Function):
 
             def record(**more):
                 runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet.level, mlp_blocks_kept=diet.mlp_blocks,
+                                               mlp_blocks=_ranges([i for i, k in enumerate(diet.keep_mlp) if k]) if diet.level == 3 else None,
                                                rows_fp16_normalised=diet.xh16, kept_fraction=kept, **more)
             record()
-            if (Bf, min(chunk, Bf), diet.level, diet.mlp_blocks) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
-                EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet.level, diet.mlp_blocks)
+            if (Bf, min(chunk, Bf), diet.level, tuple(diet.keep_mlp)) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
+                EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet.level, tuple(diet.keep_mlp))
                 _log.info("tower plan: %d frames, %d per pass, activation diet %s (kept fraction %.3f)", Bf, min(chunk, Bf), diet.describe(), kept)
         ctx.spec, ctx.params, ctx.diet = spec, params, diet
         if chunk >= Bf:
@@ -1050,7 +1079,7 @@ class EvaTowerFn(torch.autograd.Function):
                 dietable = not spec.arch["swiglu"] and not spec.arch.get("postnorm")
                 if dietable and runtime.activation_diet_override() is None and (diet.level < 3 or diet.mlp_blocks > 0):
                     # next more conservative diet: no MLP intermediates at level 3, else the next level
-                    diet = TowerDiet(depth, 3, 0) if diet.level == 3 else TowerDiet(depth, diet.level + 1, 0)
+                    diet = TowerDiet(depth, 3) if diet.level == 3 else TowerDiet(depth, diet.level + 1)
                 else:
                     chunk = -(-Bf // 2)
                 ctx.diet = diet

@@ -117,6 +117,18 @@ def enter_block(i, base, subln_swiglu=False, depth=None):
         restore(base)
 
 
+def fc1_recompute_weight(i, subln_swiglu=False):
+    """Relative cost of re-running block i's fc1 GEMM under the CURRENT pass-wide precision state (what enter_block(i, snapshot()) would set):
+    2 for a weights-split head block (x W_hi + x W_lo: the reduction is twice as long), 3 where activations are split as well, else 1.
+    functional.tower_plan weighs the blocks' MLP intermediates with it."""
+    dt, split, mode, fp8, n, hmode = snapshot()
+    if n and i < n and dt == torch.float16 and not split and not fp8:
+        split, mode = True, ("full" if subln_swiglu else hmode)
+    if not split:
+        return 1
+    return 3 if mode == "full" else 2
+
+
 def saved_precision(backward):
     """Decorator for autograd.Function.backward: runs it under the precision state its forward stored with remember_precision(ctx)."""
     import functools

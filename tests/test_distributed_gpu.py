@@ -192,6 +192,92 @@ def test_rccl_world_size_one(cuda):
     assert ret.get(0) == "ok", ret.get(0)
 
 
+def _mico_comm_worker(rank, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=0, world_size=1)          # (only carries the communicator's id: any backend does)
+        from common import build_model
+        from mico_amd import runtime, comm, distributed as D
+        from mico_amd.weights import synth_inputs
+        c = comm.get()
+        assert (c.rank, c.nranks) == (0, 1)
+        # ---- the collectives against their identities at one rank ----
+        x = torch.randn(5, 7, device=dev)
+        ids = torch.arange(10, device=dev).view(5, 2)
+        msk = (torch.arange(15, device=dev).view(5, 3) % 2).to(torch.uint8)            # an odd row width: the byte-granular pack path
+        gx, gi = c.allgather_packed([x, ids])
+        assert torch.equal(gx, x) and torch.equal(gi, ids) and gx.dtype == x.dtype and gi.dtype == ids.dtype
+        gx, gm, gi = c.allgather_packed([x, msk, ids])
+        assert torch.equal(gx, x) and torch.equal(gm, msk) and torch.equal(gi, ids)
+        rows = torch.randn(6, 3, 4, device=dev)
+        assert torch.equal(c.alltoallv_rows(rows, [6], [6]), rows)
+        assert c.alltoallv_rows(rows[:0], [0], [0]).shape == (0, 3, 4)
+        flat = torch.randn(1000, device=dev)
+        keep = flat.clone()
+        c.allreduce_(flat, average=True)
+        assert torch.equal(flat, keep)
+        assert torch.equal(c.reduce_scatter(keep, average=False), keep)
+        assert torch.equal(c.allgather(x)[0], x)
+        # ---- the alignment step with its packed all-gather and row exchange routed through mico_comm_* (MICO_COMM=1 semantics) ----
+        runtime.set_compute_dtype(torch.float16)
+        m, _ = build_model("evaclip02_base", 2, device=dev)
+        b = 4
+        inp = {k: v.to(dev) for k, v in synth_inputs(dict(b=b, vision=1, audio=1, S=12), seed=61).items()}
+        inj = {"tva": dict(neg_cond_idx=torch.tensor([(i + 1) % b for i in range(b)]), neg_text_idx=torch.tensor([(i + 2) % b for i in range(b)]))}
+        import random
+        from mico_amd.model import TokenMasker
+        mi, lab = TokenMasker(rng=random.Random(3))(inp["input_ids"].cpu(), 0.6)
+        inj["cap"] = dict(masked_ids=mi, labels=lab)
+
+        def run(on):
+            D.force_dist(on)
+            comm.enable(on)
+            m.zero_grad(set_to_none=True)
+            batch = dict(inp)
+            batch["_injected"] = inj
+            out = m(batch, "ret%tva_cap%tva")
+            sum(out.values()).backward()
+            torch.cuda.synchronize()
+            return {k: float(v) for k, v in out.items()}, {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+        calls = []
+        orig = c.allgather_packed
+        c.allgather_packed = lambda ts: (calls.append(len(ts)), orig(ts))[1]
+        l0, g0 = run(False)
+        l1, g1 = run(True)
+        comm.enable(False)
+        D.force_dist(False)
+        assert calls, "the step's packed all-gather must have gone through mico_comm_allgather_packed"
+        for k in l0:
+            assert abs(l0[k] - l1[k]) <= 1e-6 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+        worst = max(((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-20)).item() for n in g0)
+        assert g0.keys() == g1.keys() and worst < 1e-3, worst
+        comm.shutdown()
+        ret[0] = "ok"
+    except Exception:   # noqa
+        import traceback
+        ret[0] = traceback.format_exc()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_mico_comm_c_abi_one_rank(cuda):
+    """mico_comm_* (ABI 112, csrc/comm.hip): RCCL through the C-ABI - communicator from a broadcast id, packed all-gather (word and byte
+    pack paths), grouped send / receive row exchange, in-place all-reduce(AVG), reduce-scatter, all-gather - against their identities on a
+    one-rank communicator (the GPU boxes of this build have one GPU), and the alignment step with its two exchanges routed through them
+    (mico_amd.comm.enable) against the undistributed step."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mico_comm_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    assert ret.get(0) == "ok", ret.get(0)
+
+
 class _Seeds:
     """BERT dropout seeds of one rank: the k-th BERT pass of the step (text encode, ITM triplet(s), captioning) gets a seed that depends on
     (rank, k) only - so the data-parallel run and the single-process evaluation of the same rank draw identical dropout masks."""
