@@ -1246,6 +1246,10 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
             bias[u][h] = (g.e.bias && ok[u][h]) ? *(const f32x4*)(g.e.bias + ncol0 + gcol[u] + h * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     const unsigned ldc2 = (unsigned)(g.ldc * 2), ldaux2 = (unsigned)(g.e.ldaux * 2);
+    // (The activation epilogues are VALU work - exact-erf GELU: ~18 instruction slots per element, two of them quarter rate, ~10 us per tile -
+    // in front of stores a CU retires at ~10 B/clk (6.7 us per tile), and the two ADD UP: 47 -> 56 us per tile for GELU, 57.6 for the pair.
+    // Delaying the second wave of every SIMD by 8 ... 64 s_sleep units at this point, so that one wave computes while the other's stores drain,
+    // changed nothing - pair 904 -> 893-901, GELU 1031 -> 1026-1038 TFLOP/s, tools/probes/README.md round 5: the waves are not in lockstep.)
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
         const int64_t mrow0 = m0 + hb * 128 + wm * 64;

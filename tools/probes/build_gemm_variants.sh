@@ -11,7 +11,7 @@ pids=()
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $flags -c gemm.hip -o $OUT/gemm_$tag.o 2>/dev/null &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/gemm_$tag.o build/layernorm.o build/elementwise.o build/attention.o build/loss.o build/swin.o -o $OUT/libmico_$tag.so &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/gemm_$tag.o build/layernorm.o build/elementwise.o build/attention.o build/loss.o build/swin.o build/comm.o -ldl -o $OUT/libmico_$tag.so &&
     rm -f $OUT/gemm_$tag.o && echo "built $tag ($flags)" ) &
   pids+=($!)
 done
