@@ -465,7 +465,9 @@ def main():
         ops.GEMM_TIMER = timer
         DropPlan.stats[:] = [0, 0]
         finish_ms.clear()
+        ms0 = torch.cuda.memory_stats()
         el, losses = timed_steps(steps, batch, task, model)
+        ms1 = torch.cuda.memory_stats()
         ops.GEMM_TIMER = None
         kept = DropPlan.stats[0] / DropPlan.stats[1] if DropPlan.stats[1] else 1.0
         value = nb * world * steps / el
@@ -492,7 +494,13 @@ def main():
                    frames_per_sample=w["frames"], frames_per_sec=value * w["frames"], task=task, kept_branch_fraction=kept,
                    tflop_per_sample={"dense_nominal": nominal, "executed": executed}, step_executed_tflops_per_gpu=step_tflops,
                    step_mfma_frac=(step_tflops / MFMA_PEAK_TFLOPS) if step_tflops else None,
-                   peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, tower_plan=runtime.last_tower_plan,
+                   peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, peak_reserved_gb=torch.cuda.max_memory_reserved() / 2 ** 30,
+                   # caching-allocator events inside the timed region: a retry = a failed hipMalloc answered by releasing cached blocks (a device
+                   # synchronisation each) - the price of running close to the HBM capacity; device mallocs = segments newly requested from the driver
+                   allocator=dict(alloc_retries=ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+                                  device_mallocs=ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+                                  device_frees=ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+                   tower_plan=runtime.last_tower_plan,
                    losses={k: float(v.detach()) for k, v in losses.items()}, roofline=roofline)
         return res, batch
 
@@ -621,6 +629,8 @@ def main():
         "step_mfma_frac": head["step_mfma_frac"],
         "losses": head["losses"],
         "peak_mem_gb": head["peak_mem_gb"],
+        "peak_reserved_gb": head["peak_reserved_gb"],
+        "allocator": head["allocator"],
         "hbm_gb": torch.cuda.get_device_properties(dev).total_memory / 2 ** 30,
         "tower_plan": head["tower_plan"],
         "roofline": roofline,

@@ -168,6 +168,39 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_fwd_kernel(const XT* __restrict__
     }
 }
 
+// y = xhat * gamma + beta over fp16 normalised rows (mico_ln_fwd_params::x_normalized, the activation diet's LayerNorm recompute): no row
+// statistics, so no row ownership either - a thread keeps the gamma / beta of its 8 columns in registers and walks down the rows (the row
+// kernel re-reads both vectors for every row: 11 KB through L1 next to a row's 2.8 + 2.8 KB, and ran this case at 2.9 TB/s - 355 us at 717
+// frames; tools/ln_bench.py).  16-byte loads and stores, four rows in flight per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_affine16_kernel(const f16* __restrict__ xh, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          T* __restrict__ y, int64_t rows, int cols) {
+    const int chunk = blockIdx.x * blockDim.x + threadIdx.x;      // 8 columns
+    if (chunk * 8 >= cols) return;
+    const f32x4 g0 = *(const f32x4*)(gamma + chunk * 8), g1 = *(const f32x4*)(gamma + chunk * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + chunk * 8), b1 = *(const f32x4*)(beta + chunk * 8 + 4);
+    const int64_t stride = gridDim.y;
+    constexpr int U = 4;
+    for (int64_t r0 = blockIdx.y; r0 < rows; r0 += stride * U) {
+        s16x8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * stride;
+            if (r < rows) v[u] = ld_stream((const s16x8*)(xh + r * cols + chunk * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * stride;
+            if (r < rows) {
+                const f32x4 lo = unpack4<f16>((s16x4){v[u][0], v[u][1], v[u][2], v[u][3]}) * g0 + b0;
+                const f32x4 hi = unpack4<f16>((s16x4){v[u][4], v[u][5], v[u][6], v[u][7]}) * g1 + b1;
+                const s16x4 pl = pack4<T>(lo[0], lo[1], lo[2], lo[3]), ph = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
+                st_stream((s16x8*)(y + r * cols + chunk * 8), (s16x8){pl[0], pl[1], pl[2], pl[3], ph[0], ph[1], ph[2], ph[3]});
+            }
+        }
+    }
+}
+
 template <typename T, typename DT, typename XT, int NV>
 __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -377,6 +410,16 @@ extern "C" int mico_layernorm_fwd(const mico_ln_fwd_params* pp, int dtype, void*
         MICO_CHECK(!p.y32 && !p.post_add && p.drop_p == 0.f && !p.y16_split && valid_cols == cols, "mico_layernorm_fwd: the fp8 operand form takes the towers' subset of the features");
     }
     hipStream_t st = (hipStream_t)stream;
+    if (p.x_normalized && p.y16 && !p.y32 && !p.q8 && !p.post_add && !p.y16_split && !p.frame_map && p.drop_p == 0.f && cols % 8 == 0 && valid_cols == cols &&
+        (((uintptr_t)p.x | (uintptr_t)p.y16) & 15) == 0) {
+        // the recompute from normalised rows: a streaming affine map, no row statistics (ln_affine16_kernel)
+        const int chunks = cols / 8;
+        const int bx = chunks >= 192 ? 192 : 64;
+        const dim3 grid2((chunks + bx - 1) / bx, (unsigned)std::min<int64_t>(p.rows, 2048));
+        DISPATCH_T16(dtype, MICO_LAUNCH((ln_affine16_kernel<T>), grid2, dim3(bx), 0, st, (const f16*)p.x, p.gamma, p.beta, (T*)p.y16, p.rows, cols));
+        MICO_LAUNCH_CHECK();
+        return MICO_OK;
+    }
     const dim3 grid(ln_grid(p.rows, 1024));
     DISPATCH_T16(dtype, {
         if (p.x_dtype == MICO_F32) ln_fwd_launch<T, float>(grid, st, p, valid_cols);

@@ -210,7 +210,7 @@ def test_layernorm_normalised_rows(cuda, dtype, gather):
     # dx: the rounding enters through two row means only; dgamma = sum over rows of dy * xhat is a sum of random signs, so the fp16 rounding of
     # xhat (relative 2^-12 rms per element) shows at ~1e-3 of its largest entry (tools/probes/ln_xhat_diag.py: the kernels agree with fp32
     # torch evaluations of both forms to 2e-7; the difference between the forms is the rounding itself)
-    assert rel_err(g_b, g_a) < 1e-4 and rel_err(dgb, dga) < 5e-3 and torch.equal(dbb, dba)
+    assert rel_err(g_b, g_a) < 1e-4 and rel_err(dgb, dga) < 5e-3 and rel_err(dbb, dba) < 1e-5      # (dbeta: the same sums, in the order of fp32 atomics)
     # refusals: a normalised input is fp16 and produces no statistics / copies
     from mico_amd._lib import MicoHipError
     with pytest.raises(MicoHipError):

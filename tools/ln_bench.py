@@ -54,6 +54,16 @@ def main():
     ms = timeit(lambda: ops.layernorm_bwd(dy16, x, g, mean, rstd, dx_add=gr, dx32=gr, dgamma=dg, dbeta=db, dtype=dt, frame_map=fmap, rows_per_frame=N,
                                           dx16=g16n, scale16=1.0, dx16_dst=fmap, dx16_frame_scale=fsc))
     print(f"ln bwd in situ      : {ms * 1e3:7.1f} us  {M * D * 16 / ms / 1e6:7.1f} GB/s (16 B/elem: dy 2, x 4, g 4 + 4, next operand 2)")
+    # round 5 (activation diet level 3): the forward leaves fp16 normalised rows instead of the fp32 copy, the backward and the recomputing
+    # forward read them
+    xh = torch.empty(M, D, device=dev, dtype=torch.float16)
+    ms = timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-6, out16=y16, mean=mean, rstd=rstd, dtype=dt, frame_map=fmap, rows_per_frame=N, xhat16=xh))
+    print(f"ln fwd gather+xhat16: {ms * 1e3:7.1f} us  {M * D * 8 / ms / 1e6:7.1f} GB/s (8 B/elem)")
+    ms = timeit(lambda: ops.layernorm_fwd(xh, g, b, 1e-6, out16=y16, dtype=dt, x_normalized=True))
+    print(f"ln fwd from xhat16  : {ms * 1e3:7.1f} us  {M * D * 4 / ms / 1e6:7.1f} GB/s (4 B/elem)")
+    ms = timeit(lambda: ops.layernorm_bwd(dy16, xh, g, None, rstd, dx_add=gr, dx32=gr, dgamma=dg, dbeta=db, dtype=dt, frame_map=fmap, rows_per_frame=N,
+                                          dx16=g16n, scale16=1.0, dx16_dst=fmap, dx16_frame_scale=fsc, x_normalized=True))
+    print(f"ln bwd in situ xhat : {ms * 1e3:7.1f} us  {M * D * 14 / ms / 1e6:7.1f} GB/s (14 B/elem: dy 2, xhat 2, g 4 + 4, next operand 2)")
     ms = timeit(lambda: xc.copy_(x))
     print(f"device copy fp32    : {ms * 1e3:7.1f} us  {M * D * 8 / ms / 1e6:7.1f} GB/s (8 B/elem)")
     ms = timeit(lambda: y16.copy_(x))
