@@ -50,7 +50,7 @@ def main():
         cases = {
             "fwd": (lambda: torch.matmul(x, wt, out=y), lambda: ops.gemm(x, w, y)),
             "dx": (lambda: torch.matmul(dy, w, out=dx), lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N)),
-            "dw": (lambda: torch.matmul(dyt, x, out=dw16), lambda: ops.gemm(dy, x, dw32, ta=True, tb=True, M=N, N=K, K=M, accumulate=True)),
+            "dw": (lambda: torch.matmul(dyt, x, out=dw16), lambda: ops.gemm(dy, x, dw32, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=0)),   # (split_k = 0: the library's own K split, as functional.linear_wgrad calls it)
         }
         for c, (lib_fn, our_fn) in cases.items():
             for who, fn in (("hipblaslt", lib_fn), ("mico", our_fn), ("hipblaslt", lib_fn), ("mico", our_fn)):
