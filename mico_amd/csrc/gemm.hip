@@ -1315,6 +1315,106 @@ __device__ __forceinline__ void p8_epilogue_fast16(const GemmArgs& g, const f32x
     }
 }
 
+// Round 5: the same epilogue with the tile staged in 16 BITS.  tools/probes/store_scaling.hip showed that the stores are not what the 6.7 us of
+// p8_epilogue_fast16 are: a CU writes a 128 KiB tile in 1.1 us alone and in 1.9 us when all 256 CUs burst together after 40 us of silence (the GEMM's
+// regime) - the time is the two LDS round trips of 16 KiB fp32 blocks per wave (write, wait, read, wait, twice) in front of them.  Here bias / alpha /
+// activation are applied in the MFMA layout (elementwise: the layout does not matter), the values are rounded to the output type and staged as 8-byte
+// pieces - BOTH 64-row blocks at once in the wave's 16 KiB (128 rows x 128 B), half the LDS bytes, one round trip - and read back as 16-byte pieces
+// (8 columns of one row per lane: 64 contiguous bytes per lane quad, as before).  Same fp32 arithmetic per element in the same order (the product
+// with alpha is kept from contracting with the bias add: the fp32 staging separated the two), so the outputs are bit-identical
+// (tools/gemm_bench.py --variants on the probe build; MICO_P8_EPI16=0 rebuilds the fp32 staging).  The GELU pair stages its two outputs per
+// 64-row block (8 + 8 KiB).  MUL_AUX keeps the fp32 staging: its second factor arrives in the read-back layout and multiplies before the rounding.
+// Chunk swizzle of the 128-byte rows: key(row) = bit 0 of the row -> bit 2, bits 1-2 -> bits 0-1: the 16 rows x 8 bytes of a write instruction use
+// every bank exactly twice per 32 lanes (the minimum for 256 bytes), and the two rows x four chunks of 8 consecutive reading lanes are 8 distinct chunks.
+#ifndef MICO_P8_EPI16
+#define MICO_P8_EPI16 1
+#endif
+__device__ __forceinline__ int epi16_key(int row) { return ((row & 1) << 2) | ((row >> 1) & 3); }
+template <typename T, int ACT>
+__device__ __forceinline__ void p8_epilogue_fast16_h(const GemmArgs& g, const f32x4 (&acc)[8][4], LDS_AS char* wbuf, int64_t m0, int64_t n0, int wm, int wn,
+                                                     int lane) {
+    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV, "MUL_AUX keeps the fp32 staging");
+    const int p = lane & 15, gq = lane >> 4;
+    const int q = lane & 3, rr = lane >> 2;
+    const float alpha = g.e.alpha;
+    const int64_t ncol0 = n0 + wn * 32;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t col = ncol0 + (j >> 1) * 128 + (j & 1) * 16 + gq * 4;
+        bias[j] = (g.e.bias && col < g.N) ? *(const f32x4*)(g.e.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int wkey = epi16_key(p), rkey = epi16_key(rr);
+    const int woff = p * 128 + (gq & 1) * 8, wch = gq >> 1;
+    auto value = [&](int i, int j) {
+        f32x4 t = acc[i][j] * alpha;
+        asm volatile("" : "+v"(t));      // (no fused multiply-add with the bias: the fp32 staging rounded the product first)
+        return t + bias[j];
+    };
+    auto store_row = [&](char* base, int64_t ld2, int64_t grow, int u, s16x8 o) {
+        const int64_t col = ncol0 + u * 128 + q * 8;
+        if (grow >= g.M || col >= g.N) return;
+        char* cp = base + grow * ld2 + col * 2;
+        if (col + 4 < g.N) p8_store(cp, o);
+        else p8_store(cp, (s16x4){o[0], o[1], o[2], o[3]});
+    };
+    const int64_t ldc2 = g.ldc * 2;
+    if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = value(i, j);
+                if constexpr (ACT == MICO_ACT_GELU) v = gelu4(v);
+                *(LDS_AS s16x4*)(wbuf + i * 2048 + woff + (((j * 2 + wch) ^ wkey) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        s16x8 o[8][2];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[ps][u] = *(LDS_AS const s16x8*)(wbuf + ps * 2048 + rr * 128 + (((u * 4 + q) ^ rkey) << 4));
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int64_t grow = m0 + (ps >> 2) * 128 + wm * 64 + (ps & 3) * 16 + rr;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) store_row(g.C, ldc2, grow, u, o[ps][u]);
+        }
+    } else {
+        const int64_t lda2 = g.e.ldaux * 2;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 d;
+                    const f32x4 v = gelu_pair4(value(hb * 4 + i, j), d);
+                    const int off = i * 2048 + woff + (((j * 2 + wch) ^ wkey) << 4);
+                    *(LDS_AS s16x4*)(wbuf + off) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    *(LDS_AS s16x4*)(wbuf + 8192 + off) = pack4<T>(d[0], d[1], d[2], d[3]);
+                }
+            s16x8 o[4][2], od[4][2];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int off = ps * 2048 + rr * 128 + (((u * 4 + q) ^ rkey) << 4);
+                    o[ps][u] = *(LDS_AS const s16x8*)(wbuf + off);
+                    od[ps][u] = *(LDS_AS const s16x8*)(wbuf + 8192 + off);
+                }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int64_t grow = m0 + hb * 128 + wm * 64 + ps * 16 + rr;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    store_row(g.C, ldc2, grow, u, o[ps][u]);
+                    store_row((char*)g.e.aux_out, lda2, grow, u, od[ps][u]);
+                }
+            }
+        }
+    }
+}
+
 #ifndef MICO_P8_PRIO
 #define MICO_P8_PRIO 0     // s_setprio(1) around the 16-MFMA bursts
 #endif
@@ -1582,7 +1682,8 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
     if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX || ACT == MICO_ACT_GELU) {
         // (256 rows of ldc / ldaux 16-bit elements fit 32-bit byte offsets: checked on the host - GemmArgs::fast16)
         if (MICO_P8_FAST16 && g.fast16) {
-            p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
+            if constexpr (MICO_P8_EPI16 != 0 && ACT != MICO_ACT_MUL_AUX) p8_epilogue_fast16_h<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
+            else p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
             PHASE_STAMP(5);
             PHASE_STAMP(3);
             return;
