@@ -1702,6 +1702,290 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
 }
 
 // ======================================================================================================================
+// PERSISTENT form of the 8-phase kernel (round 5) for the launches whose epilogue is the 16-bit straight-line one (lean / GELU / GELU pair).
+// tools/probes/gemm_phases.py on a K = 1408 tile: prologue 2.3 us (workgroup start, descriptors, ~1.5 us of DMA latency before the first MFMA)
+// + K loop 41.4 + epilogue 4.35 + 1.2 us between a workgroup's end and its successor's first instruction = 49.2 us, of which 3.5 us are spent
+// with NOTHING in flight.  Here min(256, tiles) workgroups walk the same XCD-contiguous tile list (virtual block id += gridDim.x: a workgroup's
+// tiles stay on its XCD, the order inside an XCD's chunk is the dispatcher's own) and the stream positions 0 .. 5 of tile i + 1 - the six
+// half-tiles the prologue issues - are requested BEFORE the epilogue of tile i, into the six ring slots the epilogue does not use (its 16-bit
+// staging needs 4 KiB per wave: 32 rows at a time, the two free slots of the second tile buffer), so they land while the tile is stored.
+// The epilogue's stores go through a buffer descriptor with per-lane out-of-bounds offsets (rows beyond M by the descriptor's extent, columns
+// beyond N by the offset).  The K loop's counted waits are the one-tile kernel's vmcnt(6): they never rely on a store still being outstanding
+// (see VM0 below).  N % 8 == 0 (no 8-byte tail stores), reduction-major B: N % 128 == 0, no k-segments except the wrapped A stream, fast16
+// launches only (mico_gemm routes; MICO_P8_PERSIST=0 or, in the probe build, variant 16 = off).
+// ======================================================================================================================
+#ifndef MICO_P8_PERSIST
+#define MICO_P8_PERSIST 1
+#endif
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <typename T, bool TB, int ACT>
+__global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArgs g) {
+    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV, "the 16-bit staged epilogues");
+    constexpr int BM = P8C::BM, BN = P8C::BN, BK = P8C::BK, HALF = P8C::HALF, TILE = P8C::TILE;
+    constexpr int NS = ACT == MICO_ACT_GELU_SAVE_DERIV ? 32 : 16;      // buffer stores per wave and tile
+    // Counted waits never count on a STORE being outstanding: loads return in order among themselves, stores among themselves, but a store can
+    // retire before an older load (the first version waited vmcnt(NS + 6) while the wanted half-tile was older than the previous tile's NS stores -
+    // and read half-tiles that had not landed: 41 of 48 outputs wrong in tools/probes/epi16_check.py).  vmcnt(6) = "at most the three youngest
+    // half-tiles outstanding" is right whatever the stores do; where they are still in flight it simply waits for them too.
+    constexpr int VMW = 6, VM0 = 6;
+    (void)NS;
+    __shared__ __attribute__((aligned(16))) char smem[P8C::LDS_BYTES];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int T_ = g.ktiles;
+    const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+
+    // ---- tile state (changes per tile) ----
+    int64_t m0 = 0, n0 = 0;
+    __amdgpu_buffer_rsrc_t rsa, rsb, rsc, rsx;
+    unsigned vra[2][2], vrb[2][2];
+    const int rl = wave * 8 + (lane >> 3);
+    {
+        const unsigned va = (unsigned)(rl * lda_b) + (unsigned)(((lane & 7) ^ key_kc(rl)) << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) vra[h][it] = va + (unsigned)((h * 128 + it * 64) * lda_b);
+        if constexpr (!TB) {
+            const unsigned vb = (unsigned)(rl * ldb_b) + (unsigned)(((lane & 7) ^ key_kc(rl)) << 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) vrb[h][it] = vb + (unsigned)((h * 128 + it * 64) * ldb_b);
+        } else {
+            // reduction-major B: N % 128 == 0 (launcher), so a half-tile of 128 columns is inside the matrix or outside it as a whole - the
+            // per-lane column test of the one-tile kernel becomes the wave-uniform `bhi` below and the offsets do not depend on the tile
+            const int kr = wave * 4 + (lane >> 4), cg = (lane & 15) ^ key_tr(kr);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) vrb[h][it] = (unsigned)((kr + it * 32) * ldb_b) + (unsigned)(cg << 4) + (unsigned)(h * 256);
+        }
+    }
+    bool bhi = true;      // TB: the tile's upper 128 columns exist
+    auto locate = [&](int vb) {
+        int bid = vb;
+        {
+            const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+        }
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        m0 = (int64_t)(first + in % gm) * BM;
+        n0 = (int64_t)(in / gm) * BN;
+        const char* a_base = g.A + m0 * lda_b;
+        const char* b_base = TB ? g.B + n0 * 2 : g.B + n0 * ldb_b;
+        int64_t a_bytes = (g.M - m0) * lda_b;
+        int64_t b_bytes = TB ? g.kb_rows * ldb_b - n0 * 2 : (g.N - n0) * ldb_b;
+        if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+        if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+        if constexpr (TB) bhi = g.N - n0 > 128;
+    };
+    // descriptors of the output tile (base at (m0, n0)): rows beyond M end the buffer
+    auto out_desc = [&](char* base, int64_t ld2) {
+        int64_t bytes = (g.M - m0) * ld2 - n0 * 2;
+        if (bytes > 0xFFFFFF00ll) bytes = 0xFFFFFF00ll;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + m0 * ld2 + n0 * 2), 0, (int)bytes, 0x00020000);
+    };
+    const unsigned ld_dst = (unsigned)(wave * 1024);
+    // CHECKED = false: K-tile t exists for sure (the prologue's K-tiles 0 and 1: the launcher requires >= 2) - no select on the offsets, i.e.
+    // no per-tile-invariant copies of them for the register allocator to keep (it spilled twelve, reloaded behind vmcnt(0) in every tile)
+    auto issue = [&](int t, auto wv, auto checked) {
+        constexpr int W = decltype(wv)::value;
+        constexpr bool isA = (W == 0 || W == 3);               // stream order of a tile: A-lo, B-hi, B-lo, A-hi (quadrant walk 1)
+        constexpr int half = (W == 1 || W == 3) ? 1 : 0;
+        const bool valid = (!decltype(checked)::value || t < T_) && (!TB || isA || half == 0 || bhi);
+        const int ta_ = (!TB && g.a_wrap > 0 && t >= g.a_wrap) ? t - g.a_wrap : t;
+        const unsigned soff = isA ? (unsigned)(ta_ * BK * 2) : (TB ? (unsigned)((int64_t)t * BK * ldb_b) : (unsigned)(t * BK * 2));
+        LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ld_dst;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            unsigned v = isA ? vra[half][it] : vrb[half][it];
+            if (!valid) v = 0xFFFFFFF0u;
+            lds_dma16_soff(isA ? rsa : rsb, (LDS_AS void*)(dst + it * 8192), v, soff);
+        }
+    };
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using W3 = std::integral_constant<int, 3>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using NC = std::false_type;
+
+    const FragBase ab = frag_base<false, 256, BK>(wm * 64, lane);
+    const FragBase bb = TB ? frag_base<true, 128, BK>(wn * 32, lane) : frag_base<false, 256, BK>(wn * 32, lane);
+    s16x8 a0[4][2] = {}, a1[4][2] = {}, b0[2][2] = {}, b1[2][2] = {};
+    auto rdA = [&](s16x8 (&d)[4][2], int boff, int blk) {
+        LDS_AS const char* t = lds + boff + blk * HALF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i][kk] = read_frag_b<false, 256, BK>(t, kk ? ab.b1 : ab.b0, i);
+    };
+    auto rdB = [&](s16x8 (&d)[2][2], int boff, int blk) {
+        LDS_AS const char* t = lds + boff + 2 * HALF + blk * HALF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) d[j][kk] = read_frag_b<TB, TB ? 128 : 256, BK>(t, kk ? bb.b1 : bb.b0, j);
+    };
+    f32x4 acc[8][4];
+    auto mma = [&](const s16x8 (&a)[4][2], const s16x8 (&b)[2][2], auto iqv, auto jqv) {
+        constexpr int IQ = decltype(iqv)::value, JQ = decltype(jqv)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[IQ * 4 + i][JQ * 2 + j] = T16<T>::mfma(b[j][kk], a[i][kk], acc[IQ * 4 + i][JQ * 2 + j]);
+    };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    auto wait_bar = [&](auto vmv) {
+        fence();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(vmv)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+    auto bar = [&]() {
+        fence();
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+    using VMF = std::integral_constant<int, VM0>;
+    using VMS = std::integral_constant<int, VMW>;
+    auto issue_h = [&](int t, auto pv) {   // the half-tile issued in phase p of tile t: stream position 4 t + p + 6
+        constexpr int IDX = decltype(pv)::value + 6;
+        issue(t + IDX / 4, std::integral_constant<int, IDX % 4>{}, std::true_type{});
+    };
+    auto ktile = [&](int t, int cur, auto vm) {
+        const int nxt = cur ^ TILE;
+        rdB(b0, cur, 0);  issue_h(t, I0{}); wait_bar(vm); mma(a0, b0, I0{}, I0{}); bar();
+        rdA(a1, cur, 1);  issue_h(t, I1{}); wait_bar(vm); mma(a0, b1, I0{}, I1{}); bar();
+        rdA(a0, nxt, 0);  issue_h(t, std::integral_constant<int, 2>{}); wait_bar(vm); mma(a1, b1, I1{}, I1{}); bar();
+        rdB(b1, nxt, 1);  issue_h(t, std::integral_constant<int, 3>{}); wait_bar(VMS{}); mma(a1, b0, I1{}, I0{}); bar();
+    };
+
+    int vb = blockIdx.x;
+    locate(vb);
+    issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // stream positions 0, 1, 2 of this tile have landed (at most the six requests of positions 3, 4, 5 are still out)
+        fence();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM0) : "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+        rdA(a0, 0, 0); rdB(b1, 0, 1);
+        fence();
+        if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: row group 1 runs half a phase behind row group 0
+        fence();
+        ktile(0, 0, VMF{});
+        int cur = TILE;
+        for (int t = 1; t < T_; ++t) {
+            asm volatile("" : "+s"(cur));
+            ktile(t, cur, VMS{});
+            cur ^= TILE;
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued past the last tile must not land in what follows
+        __syncthreads();
+        // ---- the next tile's first six half-tiles, requested before this tile is stored ----
+        rsc = out_desc(g.C, g.ldc * 2);
+        if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) rsx = out_desc((char*)g.e.aux_out, g.e.ldaux * 2);
+        const int64_t n0e = n0;
+        vb += gridDim.x;
+        const bool more = vb < g.ntiles;
+        if (more) {
+            locate(vb);
+            issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
+        }
+        // ---- epilogue: 16-bit staging in the two ring slots the requests above do not use (second tile buffer: A-hi, B-lo), 4 KiB per wave ----
+        {
+            int le = lane;
+            asm volatile("" : "+v"(le));      // (lane arithmetic of the epilogue recomputed per tile: hoisted, it would live through every K loop)
+            const int p = le & 15, gq = le >> 4, q = le & 3, rr = le >> 2;
+            LDS_AS char* wbuf = lds + TILE + HALF + wave * 4096;
+            const float alpha = g.e.alpha;
+            const int64_t ncol0 = n0e + wn * 32;
+            f32x4 bias[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t col = ncol0 + (j >> 1) * 128 + (j & 1) * 16 + gq * 4;
+                bias[j] = (g.e.bias && col < g.N) ? *(const f32x4*)(g.e.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const int wkey = epi16_key(p), rkey = epi16_key(rr);
+            const int woff = p * 128 + (gq & 1) * 8, wch = gq >> 1;
+            const unsigned ldc2 = (unsigned)(g.ldc * 2), ldx2 = (unsigned)(g.e.ldaux * 2);
+            unsigned coff[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) coff[u] = (ncol0 + u * 128 + q * 8 < g.N) ? (unsigned)((wn * 32 + u * 128 + q * 8) * 2) : 0xFFFFFFF0u;
+            auto value = [&](int i, int j) {
+                f32x4 t = acc[i][j] * alpha;
+                asm volatile("" : "+v"(t));
+                return t + bias[j];
+            };
+            auto bstore = [&](__amdgpu_buffer_rsrc_t rs, unsigned ld2, int row_in_tile, int u, s16x8 o) {
+                const unsigned off = coff[u] == 0xFFFFFFF0u ? 0xFFFFFFF0u : (unsigned)row_in_tile * ld2 + coff[u];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rs, (int)off, 0, 0);
+            };
+            if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 v = value(r * 2 + ii, j);
+                            if constexpr (ACT == MICO_ACT_GELU) v = gelu4(v);
+                            *(LDS_AS s16x4*)(wbuf + ii * 2048 + woff + (((j * 2 + wch) ^ wkey) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
+                        }
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int i = r * 2 + ps;
+                        const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + ps * 2048 + rr * 128 + (((u * 4 + q) ^ rkey) << 4)));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 d;
+                        const f32x4 v = gelu_pair4(value(i, j), d);
+                        const int off = woff + (((j * 2 + wch) ^ wkey) << 4);
+                        *(LDS_AS s16x4*)(wbuf + off) = pack4<T>(v[0], v[1], v[2], v[3]);
+                        *(LDS_AS s16x4*)(wbuf + 2048 + off) = pack4<T>(d[0], d[1], d[2], d[3]);
+                    }
+                    const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int off = rr * 128 + (((u * 4 + q) ^ rkey) << 4);
+                        bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + off));
+                        bstore(rsx, ldx2, row, u, *(LDS_AS const s16x8*)(wbuf + 2048 + off));
+                    }
+                }
+            }
+        }
+        if (!more) return;
+    }
+}
+
+// ======================================================================================================================
 // MX-fp8 GEMM (BASELINE.json configs[4]: "fp8 MFMA"): C = epilogue(A B^T) with A [M, K] and B [N, K] in OCP e4m3 and one E8M0 scale per
 // 32 consecutive k (the OCP microscaling format), on v_mfma_scale_f32_16x16x128_f8f6f4 - the only fp8 MFMA on gfx950 that runs above
 // the bf16 rate (2x; the unscaled fp8 forms run AT the bf16 rate).
@@ -2787,8 +3071,23 @@ void launch_mid(int tb, const GemmArgs& g, hipStream_t st) {
     else MICO_LAUNCH((gemm_mid_kernel<T, true, 0>), grid, block, 0, st, g);
 }
 
+// the persistent form: fast16 launches with one of the 16-bit staged epilogues, enough tiles for several per CU
 template <typename T>
-void launch_p8(int tb, const GemmArgs& g, hipStream_t st) {
+bool launch_p8p(int tb, const GemmArgs& g, hipStream_t st) {
+    if (!MICO_P8_PERSIST || !g.fast16 || g.N % 8 != 0 || g.tm0 != 0 || g.ntiles <= 256 || g.ktiles < 2 || g.e.aux_in) return false;
+    const dim3 grid(256), block(P8C::THREADS);
+    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { if (tb) return false; MICO_LAUNCH((gemm_p8p_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return true; }
+    if (g.e.act == MICO_ACT_GELU) { if (tb || g.e.aux_out) return false; MICO_LAUNCH((gemm_p8p_kernel<T, false, MICO_ACT_GELU>), grid, block, 0, st, g); return true; }
+    if (g.e.act != MICO_ACT_NONE || g.e.aux_out) return false;
+    if (!tb) MICO_LAUNCH((gemm_p8p_kernel<T, false, ACT_LEAN>), grid, block, 0, st, g);
+    else if (g.N % 128 == 0) MICO_LAUNCH((gemm_p8p_kernel<T, true, ACT_LEAN>), grid, block, 0, st, g);
+    else return false;
+    return true;
+}
+
+template <typename T>
+void launch_p8(int tb, const GemmArgs& g, hipStream_t st, bool persist = true) {
+    if (persist && launch_p8p<T>(tb, g, st)) return;
     const dim3 grid(g.ntiles), block(P8C::THREADS);
     if (resid_epilogue(g) && !tb) { MICO_LAUNCH((gemm_p8_kernel<T, false, ACT_RESID>), grid, block, 0, st, g); return; }
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { MICO_LAUNCH((gemm_p8_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return; }
@@ -3212,9 +3511,9 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
             g2.ntiles = g2.ntm * g2.ntn;
             g.ntm = ntm1;
             g.ntiles = g.ntm * g.ntn;
-            DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st)));
+            DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st, g_mico_gemm_variant != 16)));
             DISPATCH_T16(dtype, (launch_mid<T>(tb, g2, st)));
-        } else DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st)));
+        } else DISPATCH_T16(dtype, (launch_p8<T>(tb, g, st, g_mico_gemm_variant != 16)));
     }
     else if (mid64) { g_mico_last_gemm_kernel = 7; DISPATCH_T16(dtype, (launch_mid<T>(tb, g, st))); }
 #ifdef MICO_GEMM_VARIANTS
