@@ -1721,6 +1721,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 template <typename T, bool TB, int ACT>
 __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArgs g) {
+    // (Measured and not kept: ACT_RESID - the towers' fp32 residual-scatter forward - and MUL_AUX - fc2's dX - through the shared fp32-staged
+    // epilogue in eight 16-row rounds of 4 KiB per wave: fc2 forward 1177 -> 1063, projection forward 830 -> 784, the GELU' multiply 1007 -> 880
+    // TFLOP/s in situ - eight dependent load -> LDS -> store round trips cost more than the hidden prologue saves.  Those launches stay on the
+    // one-tile kernel.)
     static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV, "the 16-bit staged epilogues");
     constexpr int BM = P8C::BM, BN = P8C::BN, BK = P8C::BK, HALF = P8C::HALF, TILE = P8C::TILE;
     constexpr int NS = ACT == MICO_ACT_GELU_SAVE_DERIV ? 32 : 16;      // buffer stores per wave and tile
@@ -1911,7 +1915,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
             locate(vb);
             issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
         }
-        // ---- epilogue: 16-bit staging in the two ring slots the requests above do not use (second tile buffer: A-hi, B-lo), 4 KiB per wave ----
+        // ---- epilogue: staging in the two ring slots the requests above do not use (second tile buffer: A-hi, B-lo), 4 KiB per wave ----
         {
             int le = lane;
             asm volatile("" : "+v"(le));      // (lane arithmetic of the epilogue recomputed per tile: hoisted, it would live through every K loop)
