@@ -1503,6 +1503,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_res_kernel(const T* __res
     }
 }
 
+// (The two round-3 experiment kernels below are compiled into the probe build only: `make -C mico_amd/csrc attnexp` ->
+// tools/probes/bin/libmico_attnexp.so, -DMICO_ATTN_EXPERIMENTS=1, where MICO_ATTN_DKV=res32|stream selects them; the product library
+// has neither them nor the switch.)
+#ifdef MICO_ATTN_EXPERIMENTS
 // ======================================================================================================================
 // backward dK / dV on 32x32x16 MFMAs (round 3; hd 65..96, i.e. the g/14 towers).  Same residency as attn_bwd_dkv_res_kernel - persistent 8-wave
 // workgroups, Q and dO of one (b, h) in LDS - but a wave owns 32 keys as ONE block: K / V fragments of the 32x32x16 operand layout in
@@ -1996,6 +2000,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_stream_kernel(const T* __
     }
 }
 
+#endif   // MICO_ATTN_EXPERIMENTS
 // ======================================================================================================================
 // backward for SHORT query sequences (BERT: 77 text tokens against 1285 condition tokens, hd 64): dQ, dK and dV in ONE pass.
 // The two tiled kernels above give every 64-query block and every 64-key block a workgroup of its own: at 77 x 1285 that is 2 + 21
@@ -2964,6 +2969,7 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
         // Round 3 experiments, selectable for A/B runs (tools/attn_bench.py; numbers in tools/probes/README.md): MICO_ATTN_DKV=res32 - the same
         // residency on 32x32x16 MFMAs; MICO_ATTN_DKV=stream - Q / dO by LDS-DMA in two halves per item, double buffered.  Both pass the kernel
         // tests; neither beats the 16x16 kernel by more than 2-3 % (1.27-1.29 vs 1.31 ms backward at 320 frames), so it keeps the launch.
+#ifdef MICO_ATTN_EXPERIMENTS
         static const char* dkv_env = getenv("MICO_ATTN_DKV");
         static const int dkv_mode = !dkv_env ? 0 : (dkv_env[0] == 'r' ? 1 : (dkv_env[0] == 's' ? 2 : 0));
         if (dkv_mode == 2 && p->Sk == 257 && p->Sq > 128 && p->Sq <= RES_KR)
@@ -2971,7 +2977,9 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
                                             (T*)dk, (T*)dv, *p));
         else if (dkv_mode == 1) DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res32_kernel<T>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
                                                                 (T*)dk, (T*)dv, *p));
-        else DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
+        else
+#endif
+        DISPATCH_T16(dtype, MICO_LAUNCH((attn_bwd_dkv_res_kernel<T, 96>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta,
                                              (T*)dk, (T*)dv, *p));
         MICO_LAUNCH_CHECK();
         return MICO_OK;

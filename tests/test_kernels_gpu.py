@@ -793,6 +793,10 @@ torch.save(dqkv.float().cpu(), sys.argv[1])
             if m:   # the experiments are variants of the two-kernel path; the default is the one-pass kernel (round 4), which they cross-check here
                 env["MICO_ATTN_DKV"] = m
                 env["MICO_ATTN_NOONEPASS"] = "1"
+                # (round 5: they live in the probe build only - `make -C mico_amd/csrc attnexp`; the product library has no such switch)
+                lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes", "bin", "libmico_attnexp.so")
+                assert os.path.exists(lib), "probe build missing: make -C mico_amd/csrc attnexp"
+                env["MICO_HIP_LIB"] = lib
             f = os.path.join(td, f"g_{m or 'default'}.pt")
             subprocess.run([sys.executable, "-c", code, f], check=True, env=env)
             outs[m] = torch.load(f)
