@@ -3391,7 +3391,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     // whose epilogue is heavy next to a short K loop gain from the second workgroup on the CU - fc1 forward with the GELU pair (two 16-bit
     // outputs: 845 -> 870 TFLOP/s) and the output projection's fp32 residual scatter at K = 1408 (727 -> 752 in the microbench); everywhere else
     // the two kernels are within +-2 % of each other and the 8-wave kernel keeps the launch.
-    const bool mid_default = (g_mico_gemm_variant == 0 || g_mico_gemm_variant == 11) && M >= 8192 &&
+    const bool mid_default = (g_mico_gemm_variant == 0 || g_mico_gemm_variant == 11 || g_mico_gemm_variant == 16) && M >= 8192 &&
                              (g.e.act == MICO_ACT_GELU_SAVE_DERIV || (g.e.resid != nullptr && c_dtype == MICO_F32 && K <= 2048));
     // the 8-phase 256x256x64 kernel: forward / dX orientation, no split, K % 64 == 0 (variant 10: every such problem, 11: those the
     // 256x128 kernel does not take by default, 12: off)
@@ -3403,7 +3403,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     const bool p8_ok = big && !pc && !w4 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || wrap_ok) &&
                        256 * lda * 2 + K * 2 < 0x7FFFFF00ll && (tb ? (K + 64) * ldb * 2 : 256 * ldb * 2 + K * 2) < 0x7FFFFF00ll;
     const bool p8 = p8_ok && (g_mico_gemm_variant == 10 || g_mico_gemm_variant == 13 || g_mico_gemm_variant == 14 || g_mico_gemm_variant == 15 || (g_mico_gemm_variant == 11 && !mid_default) ||
-                              (g_mico_gemm_variant == 0 && MICO_P8_DEFAULT));
+                              ((g_mico_gemm_variant == 0 || g_mico_gemm_variant == 16) && MICO_P8_DEFAULT));      // (16: default routing with the persistent form off)
     const bool mid64 = big && !pc && !w4 && !p8 && !ta && no_split && N % 4 == 0 && K % 64 == 0 && (g.e.nseg == 0 || g.e.kseg % 64 == 0) &&
                        (g_mico_gemm_variant == 8 || (g_mico_gemm_variant == 9 && K <= 2048) || mid_default);
     const int BM = pc ? Wide<32>::BM : (big ? 256 : 128), BN = (mid || mid64) ? 128 : (big ? 256 : 128);

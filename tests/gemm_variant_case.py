@@ -77,6 +77,50 @@ def run(variant, dtype):
 
 
 
+def run_persistent(dtype):
+    """The persistent form of the 8-phase kernel (default routing for 16-bit outputs with more than 256 tiles) against the one-tile kernel
+    (variant 16 = persistent form off): bit-identical outputs - lean with / without bias and alpha, GELU, the GELU pair (both outputs), the dX
+    orientation, the wrapped-A two-segment product of the head-split blocks; ragged M, N with a half-width edge tile column, N % 128 != 0 (the
+    dX launch then stays on the one-tile kernel by routing)."""
+    from mico_amd import ops, _lib
+    cuda = torch.device("cuda:0")
+    for (M, N, K) in ((257 * 131 - 100, 1408, 1408), (70001, 4224, 1408), (40000, 1368, 2816)):
+        g = torch.Generator().manual_seed(M + N)
+        A = (0.5 * torch.randn(M, K, generator=g)).to(cuda).to(dtype)
+        W = (0.05 * torch.randn(N, K, generator=g)).to(cuda).to(dtype)
+        bias = torch.randn(N, generator=g).to(cuda)
+        Wt = W.t().contiguous()
+        outs = {}
+        for variant in (0, 16):
+            _lib.set_gemm_variant(variant)
+            res = []
+            y = torch.empty(M, N, device=cuda, dtype=dtype)
+            ops.gemm(A, W, y, bias=bias, alpha=0.5)
+            assert _lib.lib().mico_gemm_last_kernel() == 8
+            res.append(y.clone())
+            ops.gemm(A, W, y)
+            res.append(y.clone())
+            ops.gemm(A, W, y, bias=bias, act=ops.ACT_GELU)
+            res.append(y.clone())
+            aux = torch.empty(M, N, device=cuda, dtype=dtype)
+            ops.gemm(A, W, y, bias=bias, aux_out=aux, act=ops.ACT_GELU_SAVE_DERIV)
+            res += [y.clone(), aux.clone()]
+            ops.gemm(A, Wt, y, tb=True, M=M, N=N, K=K)
+            res.append(y.clone())
+            if dtype == torch.float16 and K % 128 == 0:      # x W_hi + x W_lo as one product over [hi | lo] (a_wrap)
+                k2 = K // 2
+                ops.gemm(A[:, :k2].contiguous(), W, y, ksegs=(k2, [0, 0], [0, k2]))
+                res.append(y.clone())
+            outs[variant] = res
+        _lib.set_gemm_variant(0)
+        for i, (a, b) in enumerate(zip(outs[0], outs[16])):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (M, N, K, i, (a.float() - b.float()).abs().max().item())
+
+
 if __name__ == "__main__":
-    run(int(sys.argv[1]), torch.float16 if sys.argv[2] == "f16" else torch.bfloat16)
+    dt = torch.float16 if sys.argv[2] == "f16" else torch.bfloat16
+    if sys.argv[1] == "persistent":
+        run_persistent(dt)
+    else:
+        run(int(sys.argv[1]), dt)
     print("OK")

@@ -116,6 +116,22 @@ def test_gemm_chip_filling_kernels(cuda, dtype, variant):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_persistent_gemm_matches_one_tile_kernel(cuda, dtype):
+    """gemm_p8p_kernel (round 5: the persistent form of the 8-phase kernel - next tile's first half-tiles requested before the epilogue, 16-bit
+    staging in the free ring slots, buffer stores) against gemm_p8_kernel on the same problems, bit for bit; in a process of its own on the
+    probe build, whose variant 16 switches the persistent form off (tests/gemm_variant_case.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "probes", "bin", "libmico_variants.so")
+    assert os.path.exists(lib), "probe build missing: make -C mico_amd/csrc variants"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gemm_variant_case.py"), "persistent", "f16" if dtype == torch.float16 else "bf16"],
+                       env=dict(os.environ, MICO_HIP_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cols", [768, 1408, 2048])
 @pytest.mark.parametrize("xdt", ["f32", "16"])
 def test_layernorm(cuda, dtype, cols, xdt):

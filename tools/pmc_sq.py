@@ -24,7 +24,7 @@ def short(name):
     name = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)
     m = re.match(r"\(anonymous namespace\)::(\w+)", name) or re.match(r"(\w+?_kernel)", name)
     base = m.group(1) if m else name[:40]
-    if base in ("gemm_kernel", "gemm_mid_kernel", "gemm_pc_kernel", "gemm_p8_kernel"):
+    if base in ("gemm_kernel", "gemm_mid_kernel", "gemm_pc_kernel", "gemm_p8_kernel", "gemm_p8p_kernel"):
         tb = ["T" if b == "1" else "N" for b in re.findall(r"Lb([01])E", name)]
         tile = re.search(r"TileCfgILi(\d+)ELi(\d+)", name)
         last = re.search(r"ELi(\d+)EEEvNS", name)

@@ -23,8 +23,8 @@ def variant(name):
         kind = "big"
     elif "gemm_mx8_kernel" in name or "gemm_p8mx_kernel" in name:
         return "NN_mx8"
-    elif "gemm_p8_kernel" in name:   # gemm_p8_kernel<T, TB, ACT>: forward (TB = false) or dX orientation
-        m = re.search(r"gemm_p8_kernelI\w+?Lb([01])E|gemm_p8_kernel<[^,]+,\s*(true|false)", name)
+    elif "gemm_p8_kernel" in name or "gemm_p8p_kernel" in name:   # gemm_p8_kernel / its persistent form gemm_p8p_kernel<T, TB, ACT>: forward (TB = false) or dX
+        m = re.search(r"gemm_p8p?_kernelI\w+?Lb([01])E|gemm_p8p?_kernel<[^,]+,\s*(true|false)", name)
         tb = bool(m) and (m.group(1) == "1" or m.group(2) == "true")
         return ("dX" if tb else "NN") + "_p8"
     elif "gemm_mid_kernel" in name:   # gemm_mid_kernel<T, TB, ACT>: forward (TB = false) or dX orientation
