@@ -1719,6 +1719,80 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8_kernel(const GemmArgs
 #endif
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+// Epilogue of the persistent 8-phase kernels (16-bit and MX-fp8): the tile's accumulators through 4 KiB of LDS per wave (32 rows of 128 bytes per
+// round; the GELU pair: 16 rows x two outputs) and out through buffer descriptors whose base is the tile's (m0, n0) - rows beyond M end the buffer,
+// columns beyond N get an out-of-range offset.  Arithmetic per element as p8_epilogue_fast16_h.
+template <typename T, int ACT>
+__device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], LDS_AS char* wbuf, __amdgpu_buffer_rsrc_t rsc, __amdgpu_buffer_rsrc_t rsx,
+                                             int64_t n0e, int wm, int wn, int lane) {
+        int le = lane;
+        asm volatile("" : "+v"(le));      // (lane arithmetic of the epilogue recomputed per tile: hoisted, it would live through every K loop)
+        const int p = le & 15, gq = le >> 4, q = le & 3, rr = le >> 2;
+                const float alpha = g.e.alpha;
+        const int64_t ncol0 = n0e + wn * 32;
+        f32x4 bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t col = ncol0 + (j >> 1) * 128 + (j & 1) * 16 + gq * 4;
+            bias[j] = (g.e.bias && col < g.N) ? *(const f32x4*)(g.e.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int wkey = epi16_key(p), rkey = epi16_key(rr);
+        const int woff = p * 128 + (gq & 1) * 8, wch = gq >> 1;
+        const unsigned ldc2 = (unsigned)(g.ldc * 2), ldx2 = (unsigned)(g.e.ldaux * 2);
+        unsigned coff[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) coff[u] = (ncol0 + u * 128 + q * 8 < g.N) ? (unsigned)((wn * 32 + u * 128 + q * 8) * 2) : 0xFFFFFFF0u;
+        auto value = [&](int i, int j) {
+            f32x4 t = acc[i][j] * alpha;
+            asm volatile("" : "+v"(t));
+            return t + bias[j];
+        };
+        auto bstore = [&](__amdgpu_buffer_rsrc_t rs, unsigned ld2, int row_in_tile, int u, s16x8 o) {
+            const unsigned off = coff[u] == 0xFFFFFFF0u ? 0xFFFFFFF0u : (unsigned)row_in_tile * ld2 + coff[u];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rs, (int)off, 0, 0);
+        };
+        if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = value(r * 2 + ii, j);
+                        if constexpr (ACT == MICO_ACT_GELU) v = gelu4(v);
+                        *(LDS_AS s16x4*)(wbuf + ii * 2048 + woff + (((j * 2 + wch) ^ wkey) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    }
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int i = r * 2 + ps;
+                    const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + ps * 2048 + rr * 128 + (((u * 4 + q) ^ rkey) << 4)));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 d;
+                    const f32x4 v = gelu_pair4(value(i, j), d);
+                    const int off = woff + (((j * 2 + wch) ^ wkey) << 4);
+                    *(LDS_AS s16x4*)(wbuf + off) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    *(LDS_AS s16x4*)(wbuf + 2048 + off) = pack4<T>(d[0], d[1], d[2], d[3]);
+                }
+                const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int off = rr * 128 + (((u * 4 + q) ^ rkey) << 4);
+                    bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + off));
+                    bstore(rsx, ldx2, row, u, *(LDS_AS const s16x8*)(wbuf + 2048 + off));
+                }
+            }
+        }
+}
+
 template <typename T, bool TB, int ACT>
 __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArgs g) {
     // (Measured and not kept: ACT_RESID - the towers' fp32 residual-scatter forward - and MUL_AUX - fc2's dX - through the shared fp32-staged
@@ -1908,6 +1982,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
         // ---- the next tile's first six half-tiles, requested before this tile is stored ----
         rsc = out_desc(g.C, g.ldc * 2);
         if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) rsx = out_desc((char*)g.e.aux_out, g.e.ldaux * 2);
+        else rsx = rsc;
         const int64_t n0e = n0;
         vb += gridDim.x;
         const bool more = vb < g.ntiles;
@@ -1916,75 +1991,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
             issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
         }
         // ---- epilogue: staging in the two ring slots the requests above do not use (second tile buffer: A-hi, B-lo), 4 KiB per wave ----
-        {
-            int le = lane;
-            asm volatile("" : "+v"(le));      // (lane arithmetic of the epilogue recomputed per tile: hoisted, it would live through every K loop)
-            const int p = le & 15, gq = le >> 4, q = le & 3, rr = le >> 2;
-            LDS_AS char* wbuf = lds + TILE + HALF + wave * 4096;
-            const float alpha = g.e.alpha;
-            const int64_t ncol0 = n0e + wn * 32;
-            f32x4 bias[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t col = ncol0 + (j >> 1) * 128 + (j & 1) * 16 + gq * 4;
-                bias[j] = (g.e.bias && col < g.N) ? *(const f32x4*)(g.e.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            const int wkey = epi16_key(p), rkey = epi16_key(rr);
-            const int woff = p * 128 + (gq & 1) * 8, wch = gq >> 1;
-            const unsigned ldc2 = (unsigned)(g.ldc * 2), ldx2 = (unsigned)(g.e.ldaux * 2);
-            unsigned coff[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) coff[u] = (ncol0 + u * 128 + q * 8 < g.N) ? (unsigned)((wn * 32 + u * 128 + q * 8) * 2) : 0xFFFFFFF0u;
-            auto value = [&](int i, int j) {
-                f32x4 t = acc[i][j] * alpha;
-                asm volatile("" : "+v"(t));
-                return t + bias[j];
-            };
-            auto bstore = [&](__amdgpu_buffer_rsrc_t rs, unsigned ld2, int row_in_tile, int u, s16x8 o) {
-                const unsigned off = coff[u] == 0xFFFFFFF0u ? 0xFFFFFFF0u : (unsigned)row_in_tile * ld2 + coff[u];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rs, (int)off, 0, 0);
-            };
-            if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4 v = value(r * 2 + ii, j);
-                            if constexpr (ACT == MICO_ACT_GELU) v = gelu4(v);
-                            *(LDS_AS s16x4*)(wbuf + ii * 2048 + woff + (((j * 2 + wch) ^ wkey) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
-                        }
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
-                        const int i = r * 2 + ps;
-                        const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + ps * 2048 + rr * 128 + (((u * 4 + q) ^ rkey) << 4)));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 d;
-                        const f32x4 v = gelu_pair4(value(i, j), d);
-                        const int off = woff + (((j * 2 + wch) ^ wkey) << 4);
-                        *(LDS_AS s16x4*)(wbuf + off) = pack4<T>(v[0], v[1], v[2], v[3]);
-                        *(LDS_AS s16x4*)(wbuf + 2048 + off) = pack4<T>(d[0], d[1], d[2], d[3]);
-                    }
-                    const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int off = rr * 128 + (((u * 4 + q) ^ rkey) << 4);
-                        bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + off));
-                        bstore(rsx, ldx2, row, u, *(LDS_AS const s16x8*)(wbuf + 2048 + off));
-                    }
-                }
-            }
-        }
+        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, n0e, wm, wn, lane);
         if (!more) return;
     }
 }
@@ -2305,13 +2312,207 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8mx_kernel(const Mx8Arg
     __syncthreads();
     if constexpr (ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == MICO_ACT_MUL_AUX || ACT == MICO_ACT_GELU) {
         if (MICO_P8_FAST16 && g.fast16) {
-            p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
+            // (round 5: the 16-bit staged epilogue of the 16-bit kernels - same accumulator layout; at K = 1408 an fp8 tile is 11 K-tiles next to the
+            // same fixed cost, so the 2.5 us it saves weigh twice as much here)
+            if constexpr (MICO_P8_EPI16 != 0 && ACT != MICO_ACT_MUL_AUX) p8_epilogue_fast16_h<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
+            else p8_epilogue_fast16<T, ACT>(g, acc, lds + wave * 16384, m0, n0, wm, wn, lane);
             return;
         }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
         gemm_epilogue_block<T, 4, ACT, false, 96>(g, &acc[h * 4], lds + wave * 16384, m0 + h * 128 + wm * 64, n0 + wn * 32, lane);
+}
+
+// The persistent form of gemm_p8mx_kernel (round 5; see gemm_p8p_kernel): 256 workgroups walk the XCD-contiguous tile list, the scale words of
+// K-tiles 0 / 1 and the first six half-tiles of tile i + 1 are requested before tile i's epilogue (16-bit staging in the two free ring slots,
+// buffer stores).  An fp8 tile at K = 1408 is 11 K-tiles (~15 us) next to the same ~8 us of prologue + epilogue + dispatch gap the 16-bit tiles
+// have next to 41 us: the fixed cost is what the format's 2x runs into.  Lean and GELU-pair launches with 16-bit outputs, N % 8 == 0.
+template <typename T, int ACT>
+__global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8pmx_kernel(const Mx8Args a) {
+    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU_SAVE_DERIV, "the 16-bit staged epilogues of the fp8 launches");
+    const GemmArgs& g = a.g;
+    constexpr int BM = P8C::BM, BN = P8C::BN, HALF = P8C::HALF, TILE = P8C::TILE, SCB = 2 * P8C::TILE;
+    __shared__ __attribute__((aligned(16))) char smem[P8C::LDS_BYTES + 4 * 2048];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int T_ = g.ktiles;
+    int64_t m0 = 0, n0 = 0;
+    __amdgpu_buffer_rsrc_t rsa, rsb, rsc, rsx;
+    __amdgpu_buffer_rsrc_t rss = wave < 4
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)a.sa, 0, (int)min((int64_t)T_ * g.M * 4, (int64_t)0x7FFFFF00), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)a.sb, 0, (int)min((int64_t)T_ * g.N * 4, (int64_t)0x7FFFFF00), 0x00020000);
+    unsigned vsc = 0;
+    const unsigned sc_stride = (unsigned)((wave < 4 ? g.M : g.N) * 4);
+    const unsigned sc_dst = (unsigned)(SCB + (wave < 4 ? 0 : 1024) + (wave & 3) * 256);
+    const int rl = wave * 8 + (lane >> 3);
+    unsigned vra[2][2], vrb[2][2];
+    {
+        const unsigned sw = (unsigned)(((lane & 7) ^ key_kc(rl)) << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                vra[h][it] = (unsigned)((rl + h * 128 + it * 64) * g.lda) + sw;
+                vrb[h][it] = (unsigned)((rl + h * 128 + it * 64) * g.ldb) + sw;
+            }
+    }
+    auto locate = [&](int vb) {
+        int bid = vb;
+        {
+            const int nx = 8, q = g.ntiles / nx, r = g.ntiles % nx, x = bid % nx, o = bid / nx;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+        }
+        const int gsz = GROUP_M * g.ntn;
+        const int grp = bid / gsz;
+        const int first = grp * GROUP_M;
+        const int gm = min(g.ntm - first, GROUP_M);
+        const int in = bid - grp * gsz;
+        m0 = (int64_t)(first + in % gm) * BM;
+        n0 = (int64_t)(in / gm) * BN;
+        int64_t a_bytes = (g.M - m0) * g.lda, b_bytes = (g.N - n0) * g.ldb;
+        if (a_bytes > 0xFFFFFF00ll) a_bytes = 0xFFFFFF00ll;
+        if (b_bytes > 0xFFFFFF00ll) b_bytes = 0xFFFFFF00ll;
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + m0 * g.lda), 0, (int)a_bytes, 0x00020000);
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + n0 * g.ldb), 0, (int)b_bytes, 0x00020000);
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        vsc = (unsigned)(((wave < 4 ? m0 : n0) + (wave & 3) * 64 + l2) * 4);
+    };
+    auto out_desc = [&](char* base, int64_t ld2) {
+        int64_t bytes = (g.M - m0) * ld2 - n0 * 2;
+        if (bytes > 0xFFFFFF00ll) bytes = 0xFFFFFF00ll;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + m0 * ld2 + n0 * 2), 0, (int)bytes, 0x00020000);
+    };
+    const unsigned ld_dst = (unsigned)(wave * 1024);
+    auto issue = [&](int t, auto wv, auto checked) {   // stream position W of tile t: 0 A-lo, 1 B-hi, 2 B-lo, 3 A-hi
+        constexpr int W = decltype(wv)::value;
+        constexpr bool isA = (W == 0 || W == 3);
+        constexpr int half = (W == 1 || W == 3) ? 1 : 0;
+        const bool valid = !decltype(checked)::value || t < T_;
+        const unsigned soff = (unsigned)(t * 128);
+        LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ld_dst;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            unsigned v = isA ? vra[half][it] : vrb[half][it];
+            if (!valid) v = 0xFFFFFFF0u;
+            lds_dma16_soff(isA ? rsa : rsb, (LDS_AS void*)(dst + it * 8192), v, soff);
+        }
+    };
+    auto issue_scales = [&](int t) {
+        lds_dma4_soff(rss, (LDS_AS void*)(lds + sc_dst + (t & 3) * 2048), t < T_ ? vsc : 0xFFFFFFF0u, t < T_ ? (unsigned)t * sc_stride : 0u);
+    };
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using W3 = std::integral_constant<int, 3>;
+    using NC = std::false_type;
+    using CK = std::true_type;
+    const FragBase ab = frag_base<false, 256, 64>(wm * 64, lane);
+    const FragBase bb = frag_base<false, 256, 64>(wn * 32, lane);
+    const int p = lane & 15, sh = (lane >> 4) * 8;
+    i32x8 a0[4], a1[4], b0[2], b1[2];
+    int sa0 = 0, sa1 = 0, sb0 = 0, sb1 = 0;
+    auto frag = [&](LDS_AS const char* t, const FragBase& fbs, int i) {
+        const u32x4 l4 = __builtin_bit_cast(u32x4, *(LDS_AS const s16x8*)(t + fbs.b0 + i * 2048));
+        const u32x4 h4 = __builtin_bit_cast(u32x4, *(LDS_AS const s16x8*)(t + fbs.b1 + i * 2048));
+        return (i32x8){(int)l4[0], (int)l4[1], (int)l4[2], (int)l4[3], (int)h4[0], (int)h4[1], (int)h4[2], (int)h4[3]};
+    };
+    auto rdA = [&](i32x8 (&d)[4], int& s, int boff, int blk, int sslot) {
+        LDS_AS const char* t = lds + boff + blk * HALF;
+        LDS_AS const unsigned* sc = (LDS_AS const unsigned*)(lds + SCB + sslot) + blk * 128 + wm * 64 + p;
+        unsigned pk = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = frag(t, ab, i);
+            pk |= ((sc[i * 16] >> sh) & 0xFFu) << (8 * i);
+        }
+        s = (int)pk;
+    };
+    auto rdB = [&](i32x8 (&d)[2], int& s, int boff, int blk, int sslot) {
+        LDS_AS const char* t = lds + boff + 2 * HALF + blk * HALF;
+        LDS_AS const unsigned* sc = (LDS_AS const unsigned*)(lds + SCB + sslot + 1024) + blk * 128 + wn * 32 + p;
+        unsigned pk = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            d[j] = frag(t, bb, j);
+            pk |= ((sc[j * 16] >> sh) & 0xFFu) << (8 * j);
+        }
+        s = (int)pk;
+    };
+    f32x4 acc[8][4];
+    auto mma = [&](const i32x8 (&fa)[4], int sa, const i32x8 (&fb)[2], int sb, auto iqv, auto jqv) {
+        constexpr int IQ = decltype(iqv)::value, JQ = decltype(jqv)::value;
+#define P8MX_MMA(I, J) acc[IQ * 4 + I][JQ * 2 + J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[J], fa[I], acc[IQ * 4 + I][JQ * 2 + J], 0, 0, J, sb, I, sa)
+        P8MX_MMA(0, 0); P8MX_MMA(0, 1); P8MX_MMA(1, 0); P8MX_MMA(1, 1); P8MX_MMA(2, 0); P8MX_MMA(2, 1); P8MX_MMA(3, 0); P8MX_MMA(3, 1);
+#undef P8MX_MMA
+    };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    auto wait_bar = [&](auto nv) {
+        fence();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(nv)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+    auto bar = [&]() {
+        fence();
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+    using N6 = std::integral_constant<int, 3 * P8C::DMA_PER_HALF>;
+    using N7 = std::integral_constant<int, 3 * P8C::DMA_PER_HALF + 1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto request_first = [&]() {      // what a tile finds in flight when it starts: the scale words of K-tiles 0 and 1, stream positions 0 .. 5
+        issue_scales(0); issue_scales(1);
+        issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
+    };
+    int vb = blockIdx.x;
+    locate(vb);
+    request_first();
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        fence();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N6::value) : "memory");      // (never counts on a store being outstanding: see gemm_p8p_kernel)
+        __builtin_amdgcn_s_barrier();
+        fence();
+        rdA(a0, sa0, 0, 0, 0);
+        rdB(b1, sb1, 0, 1, 0);
+        fence();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        fence();
+        int cur = 0;
+        for (int t = 0; t < T_; ++t) {
+            asm volatile("" : "+s"(cur));
+            const int nxt = cur ^ TILE;
+            const int sc_cur = (t & 3) * 2048, sc_nxt = ((t + 1) & 3) * 2048;
+            rdB(b0, sb0, cur, 0, sc_cur);  issue(t + 1, W2{}, CK{}); issue_scales(t + 2); wait_bar(N7{}); mma(a0, sa0, b0, sb0, I0{}, I0{}); bar();
+            rdA(a1, sa1, cur, 1, sc_cur);  issue(t + 1, W3{}, CK{}); wait_bar(N7{}); mma(a0, sa0, b1, sb1, I0{}, I1{}); bar();
+            rdA(a0, sa0, nxt, 0, sc_nxt);  issue(t + 2, W0{}, CK{}); wait_bar(N7{}); mma(a1, sa1, b1, sb1, I1{}, I1{}); bar();
+            rdB(b1, sb1, nxt, 1, sc_nxt);  issue(t + 2, W1{}, CK{}); wait_bar(N6{}); mma(a1, sa1, b0, sb0, I1{}, I0{}); bar();
+            cur = nxt;
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        rsc = out_desc(g.C, g.ldc * 2);
+        if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) rsx = out_desc((char*)g.e.aux_out, g.e.ldaux * 2);
+        else rsx = rsc;
+        const int64_t n0e = n0;
+        vb += gridDim.x;
+        const bool more = vb < g.ntiles;
+        if (more) {
+            locate(vb);
+            request_first();
+        }
+        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, n0e, wm, wn, lane);
+        if (!more) return;
+    }
 }
 
 // 16-bit [rows, cols] -> e4m3 [rows, cols] + E8M0 block scales (one per 32 consecutive columns, packed 4 per uint32, K-tile-major).
@@ -3310,7 +3511,11 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
                (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true);
 #define MX8(ACTV) do { if (p8mx) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_p8mx_kernel<T, ACTV>), grid, block, 0, st, a)); \
                        else DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_mx8_kernel<T, ACTV>), grid, block, 0, st, a)); } while (0)
-    if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MX8(MICO_ACT_GELU_SAVE_DERIV);
+    // the persistent form (gemm_p8pmx_kernel): 16-bit outputs through the 16-bit staged epilogue, several tiles per CU (variant 17, probe build: off)
+    const bool persist = MICO_P8_PERSIST && p8mx && g.fast16 && N % 8 == 0 && g.ntiles > 256 && g.ktiles >= 2 && !g.e.aux_in && g_mico_gemm_variant != 17;
+    if (persist && g.e.act == MICO_ACT_GELU_SAVE_DERIV) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_p8pmx_kernel<T, MICO_ACT_GELU_SAVE_DERIV>), dim3(256), block, 0, st, a));
+    else if (persist && lean) DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_p8pmx_kernel<T, ACT_LEAN>), dim3(256), block, 0, st, a));
+    else if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MX8(MICO_ACT_GELU_SAVE_DERIV);
     else if (g.e.act == MICO_ACT_MUL_AUX) MX8(MICO_ACT_MUL_AUX);
     else if (lean) MX8(ACT_LEAN);
     else DISPATCH_T16(out_dtype, MICO_LAUNCH((gemm_mx8_kernel<T, 0>), grid, block, 0, st, a));

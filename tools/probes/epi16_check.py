@@ -35,6 +35,13 @@ def run():
             Wt = W.t().contiguous()
             ops.gemm(A, Wt, y, tb=True, M=M, N=N, K=K)
             out[tag + "-dx"] = y.cpu()
+            if K % 128 == 0:      # the MX-fp8 kernels (same epilogues; the persistent form gemm_p8pmx_kernel)
+                qa, qw = ops.quant_mx8(A), ops.quant_mx8(W)
+                ops.gemm_mx8(qa, qw, y, dtype=dt, bias=bias)
+                out[tag + "-mx8-lean"] = y.cpu()
+                ops.gemm_mx8(qa, qw, y, dtype=dt, bias=bias, aux_out=aux, act=ops.ACT_GELU_SAVE_DERIV)
+                out[tag + "-mx8-pair"] = y.cpu()
+                out[tag + "-mx8-pair-aux"] = aux.cpu()
     return out
 
 
