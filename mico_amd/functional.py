@@ -913,7 +913,7 @@ def _slice_groups(groups, c0, c1):
     return out
 
 
-_SOFT_FRAC = float(os.environ.get("MICO_HBM_SOFT_FRAC", "0.82"))
+_SOFT_FRAC = float(os.environ.get("MICO_HBM_SOFT_FRAC", "0.87"))
 # Level 3 fills what its smaller rows free with MLP intermediates - up to the soft budget minus this margin: the budget's activation estimate is
 # exact for them (4 hidden bytes per kept MLP token) while the levels' own bytes are priced with slack (kept + 0.02), so a plan filled to the
 # brim peaks ~10 GiB above the same budget's level-2 plan (measured on one rank of configs[3]: 237 against 227 GiB with 14 blocks kept)
@@ -964,9 +964,11 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     headroom = (12 << 30) + n_frames * (52 << 20)
     # Two budgets for the saved activations.  HARD: what fits at all - 0.90 of the free memory beyond the headroom (0.95 put one rank of
     # configs[3] on level 1 at a 268 of 288 GiB peak).  SOFT: what keeps the step's projected peak (allocated now + headroom + activations)
-    # under MICO_HBM_SOFT_FRAC (0.82) of the device memory, i.e. ~236 of 288 GiB - the margin a data-parallel job needs for RCCL's buffers, a
-    # second reducer and allocator fragmentation (level 1 "fitted" one rank of configs[3] at 266-268 GiB; level 2 costs
-    # 0.02 of a tower forward more and peaks at 231).  The soft budget decides unless staying under it would need chunked recomputation
+    # under MICO_HBM_SOFT_FRAC of the device memory - the margin a data-parallel job needs for RCCL's buffers, a second reducer and allocator
+    # fragmentation (level 1 "fitted" one rank of configs[3] at 266-268 GiB ALLOCATED; level 2 costs 0.02 of a tower forward
+    # more and peaks at 231).  0.82 until late in round 5, 0.87 since: with level 3 every 0.01 is one more block's MLP intermediates kept,
+    # and one rank of configs[3] measured 40.56 / 40.66 samples/s at 0.82 (12 blocks, 250 GiB RESERVED by the caching allocator), 41.28 / 41.00
+    # at 0.86 (15, 262 GiB), 41.47 / 41.47 at 0.90 (18, 274 GiB), no allocator retry in any; 24 forced blocks ran out of memory.  The soft budget decides unless staying under it would need chunked recomputation
     # that the hard budget avoids (> 0.05 of a tower forward dearer): memory margin is worth a LayerNorm recompute, not half a forward.
     total = torch.cuda.get_device_properties(device).total_memory
     hard = int(0.90 * max(free - headroom, free // 4))

@@ -195,9 +195,9 @@ def test_activation_diet_recompute(cuda):
     # "fit" at a 266 GiB peak - the plan must stay in ONE pass under the soft budget: level 3 (fp16 normalised rows) with the MLP intermediates
     # of SOME blocks kept from what the smaller rows free (round 4: level 2, 231 GiB measured), leaving room for RCCL and a second reducer
     if torch.cuda.mem_get_info(cuda)[0] > 250 << 30:
-        assert (chunk, diet.level) == (896, 3) and 4 <= diet.mlp_blocks <= 20, (chunk, diet.describe())
+        assert (chunk, diet.level) == (896, 3) and 4 <= diet.mlp_blocks <= 24, (chunk, diet.describe())
         proj = torch.cuda.memory_allocated(cuda) + (12 << 30) + 896 * (52 << 20) + acts
-        assert proj < 0.82 * torch.cuda.mem_get_info(cuda)[1]
+        assert proj < Fn._SOFT_FRAC * torch.cuda.mem_get_info(cuda)[1]
         # with the per-block kept tokens of a real draw (later blocks keep fewer frames) the last blocks are cheaper than the average
         toks = [int(896 * 257 * (1.0 - 0.4 * i / 39)) for i in range(40)]
         chunk_b, diet_b = Fn.tower_plan(big, 896, cuda, kept=sum(toks) / (40 * 896 * 257), block_tokens=toks)

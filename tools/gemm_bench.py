@@ -78,10 +78,11 @@ def main():
                     if a.resid else (lambda: ops.gemm(x, w, y, bias=bias))),
             **({"quant": lambda: ops.quant_mx8(x)} if a.mx8 else {}),
             "dx": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N),
+            "dxaux": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N, aux_in=x, act=ops.ACT_MUL_AUX),   # (fc2's dX times the stored GELU': x stands in for it)
             "dw": lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=sk),
         }
         for cname, fn, var in [(c, f, v) for c, f in cases.items() for v in (variants * 2 if len(variants) > 1 else variants)]:
-            if (a.only and cname not in a.only.split(",")) or (a.mx8 and cname in ("dx", "dw")):
+            if (a.only and cname not in a.only.split(",")) or (a.mx8 and cname in ("dx", "dxaux", "dw")) or (cname == "dxaux" and "dxaux" not in a.only.split(",")):
                 continue
             if var is not None:
                 ops._lib.set_gemm_variant(var)

@@ -35,6 +35,8 @@ def run():
             Wt = W.t().contiguous()
             ops.gemm(A, Wt, y, tb=True, M=M, N=N, K=K)
             out[tag + "-dx"] = y.cpu()
+            ops.gemm(A, Wt, y, tb=True, M=M, N=N, K=K, aux_in=aux, act=ops.ACT_MUL_AUX, alpha=0.5)      # (aux: the pair launch's GELU')
+            out[tag + "-dxaux"] = y.cpu()
             if K % 128 == 0:      # the MX-fp8 kernels (same epilogues; the persistent form gemm_p8pmx_kernel)
                 qa, qw = ops.quant_mx8(A), ops.quant_mx8(W)
                 ops.gemm_mx8(qa, qw, y, dtype=dt, bias=bias)
