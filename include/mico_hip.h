@@ -113,6 +113,14 @@ typedef struct mico_gemm_epilogue {
      * `stream`; two launches that may run concurrently (different streams) must be given different scratch buffers. */
     void* splitk_ws;
     int64_t splitk_ws_bytes;
+    /* The MLP pair's private layout for gelu'(pre-activation) (round 5).  The tensor GELU_SAVE_DERIV writes (aux_out) is read by exactly one other
+     * launch, MUL_AUX (aux_in), of the same [M, N] - so with aux_tiled != 0 both keep it the way the persistent 8-phase kernel's accumulators
+     * hold it instead of row-major: tile (tm, tn) of 256 x 256 is the 128 KiB at ((tm * N / 256) + tn) * 128 KiB, wave w its 16 KiB at w * 16 KiB,
+     * unit u (0..15) of a wave is one KiB with lane l's eight values at l * 16 bytes.  Written and read with whole-KiB accesses straight from /
+     * into registers (a row-major aux costs the dX launch 6 %: 32-byte row segments in the accumulator layout).  ldaux is ignored; the buffer holds
+     * mico_gemm_aux_tiled_elems(M, N, K) elements (M rounded up to 256 rows), which is 0 when these launches would not take that kernel
+     * - then the aux tensor stays row-major.  16-bit launches only (mico_gemm_mx8 refuses it).  A launch given aux_tiled that cannot honour it fails with MICO_EINVAL. */
+    int aux_tiled;
 } mico_gemm_epilogue;
 
 /* which kernel the calling thread's last mico_gemm launched: 0 = 128x128 tile, 1 = 256x256 8-wave ping-pong, 2 = 192x256
@@ -123,6 +131,7 @@ int mico_gemm_last_kernel(void);
  * mico_gemm_set_variant(v) - force the 32-deep 8-wave kernel (12), the 256x128 two-workgroups-per-CU kernels (5 / 6, 8 / 9), the 8-phase kernel
  * (10; 15 = with its generic epilogue) ... onto every large problem they support, for same-process A/B measurements - is exported by the probe
  * build only: `make -C mico_amd/csrc variants` -> tools/probes/bin/libmico_variants.so, loaded through MICO_HIP_LIB.) */
+int64_t mico_gemm_aux_tiled_elems(int64_t M, int64_t N, int64_t K);   /* see mico_gemm_epilogue::aux_tiled */
 int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K,
               const void* A, int64_t lda, const void* B, int64_t ldb,
               void* C, int64_t ldc, int c_dtype,

@@ -28,7 +28,7 @@ class GemmEpilogue(C.Structure):
         ("nseg", c_int), ("kseg", c_int), ("a_seg_off", c_int * 3), ("b_seg_off", c_int * 3),
         ("row_map", c_vp), ("rows_per_map", c_int),
         ("drop_p", c_f), ("drop_seed", C.c_uint), ("drop_site", c_int), ("colsum_out", c_vp),
-        ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64),
+        ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64), ("aux_tiled", c_int),
     ]
 
 
@@ -67,6 +67,7 @@ PROTOTYPES = {
     "mico_last_error_string": [],
     "mico_struct_layout": [C.POINTER(c_int), c_int],
     "mico_gemm_last_kernel": [],
+    "mico_gemm_aux_tiled_elems": [c_i64, c_i64, c_i64],
     "mico_gemm": [c_int, c_int, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int,
                   C.POINTER(GemmEpilogue), c_int, c_int, c_vp],
     "mico_quant_mx8": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_f, c_int, c_vp],
@@ -122,7 +123,7 @@ PROTOTYPES = {
     "mico_comm_allreduce_f32": [c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_comm_reduce_scatter_f32": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }
-_RESTYPES = {"mico_last_error_string": C.c_char_p}
+_RESTYPES = {"mico_last_error_string": C.c_char_p, "mico_gemm_aux_tiled_elems": c_i64}
 
 _lib = None
 
@@ -131,7 +132,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 112   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 113   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

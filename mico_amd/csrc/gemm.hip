@@ -1722,9 +1722,29 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // Epilogue of the persistent 8-phase kernels (16-bit and MX-fp8): the tile's accumulators through 4 KiB of LDS per wave (32 rows of 128 bytes per
 // round; the GELU pair: 16 rows x two outputs) and out through buffer descriptors whose base is the tile's (m0, n0) - rows beyond M end the buffer,
 // columns beyond N get an out-of-range offset.  Arithmetic per element as p8_epilogue_fast16_h.
+// The TILED layout of the GELU' tensor (mico_gemm_epilogue::aux_tiled; include/mico_hip.h): written by the pair epilogue and read by the MUL_AUX
+// epilogue of THESE kernels only, so it is stored the way their accumulators hold it - tile (tm, tn) of 256 x 256 is the 128 KiB at
+// ((tm * N / 256) + tn) * 128 KiB, wave w its 16 KiB at w * 16 KiB, and unit u (0..15) of a wave is one KiB: lane l's 16 bytes = the eight values
+// acc[u >> 1][2 (u & 1)] and acc[u >> 1][2 (u & 1) + 1] of that lane.  Both sides move it with whole-KiB 16-byte-per-lane buffer accesses straight
+// from / to registers (no LDS staging; the accumulator layout of a ROW-major aux is 32-byte row segments: measured 6 % of the launch).
+// MUL_AUX: all 16 loads of a wave are issued BEFORE the K loop's closing wait (the fragment registers are dead by then), so their latency is behind
+// the next tile's requests and the first epilogue rounds; loads return in order, so they must be older than those 96 KiB of requests.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p8p_aux_tile_desc(const void* aux, const GemmArgs& g, int64_t m0, int64_t n0) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)aux + ((m0 >> 8) * (g.N >> 8) + (n0 >> 8)) * 131072), 0, 131072, 0x00020000);
+}
+__device__ __forceinline__ void p8p_aux_load(i32x4 (&xa)[16], __amdgpu_buffer_rsrc_t rsx, int wave, int lane) {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const unsigned base = (unsigned)(wave * 16384 + le * 16);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) xa[u] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(base + u * 1024), 0, 0));
+}
+// ACT_PAIR_TILED / ACT_MUL_TILED: the GELU pair / the GELU' multiply with the tiled aux layout (rsx: p8p_aux_tile_desc).
+// `xa` / `more`: ACT_MUL_TILED only (the multipliers of p8p_aux_load, 16 loads older than the next tile's twelve requests when there is a next tile).
+constexpr int ACT_PAIR_TILED = 7, ACT_MUL_TILED = 8;
 template <typename T, int ACT>
 __device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], LDS_AS char* wbuf, __amdgpu_buffer_rsrc_t rsc, __amdgpu_buffer_rsrc_t rsx,
-                                             int64_t n0e, int wm, int wn, int lane) {
+                                             int64_t n0e, int wm, int wn, int lane, const i32x4* xa = nullptr, bool more = false) {
         int le = lane;
         asm volatile("" : "+v"(le));      // (lane arithmetic of the epilogue recomputed per tile: hoisted, it would live through every K loop)
         const int p = le & 15, gq = le >> 4, q = le & 3, rr = le >> 2;
@@ -1752,14 +1772,46 @@ __device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&ac
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rs, (int)off, 0, 0);
         };
         if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
+            s16x4 dlo = {0, 0, 0, 0};
+            const unsigned xbase = (unsigned)((wm * 4 + wn) * 16384 + le * 16);
+            (void)dlo; (void)xbase;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if constexpr (ACT == ACT_MUL_TILED) {
+                    // round r reads units 4 r .. 4 r + 3: 4 (3 - r) younger multiplier loads + the next tile's twelve requests may stay out (never a
+                    // store counted on: see gemm_p8p_kernel)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        if (r == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                        else if (r == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                        else if (r == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    } else {
+                        if (r == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        else if (r == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (r == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f32x4 v = value(r * 2 + ii, j);
                         if constexpr (ACT == MICO_ACT_GELU) v = gelu4(v);
+                        if constexpr (ACT == ACT_PAIR_TILED) {      // GELU' leaves from the registers: unit (i, j >> 1) of the wave's 16 KiB (p8p_aux_load)
+                            f32x4 d;
+                            v = gelu_pair4(v, d);
+                            const s16x4 dp = pack4<T>(d[0], d[1], d[2], d[3]);
+                            if ((j & 1) == 0) dlo = dp;
+                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, (s16x8){dlo[0], dlo[1], dlo[2], dlo[3], dp[0], dp[1], dp[2], dp[3]}), rsx,
+                                                                        (int)(xbase + (unsigned)(((r * 2 + ii) * 2 + (j >> 1)) * 1024)), 0, 0);
+                        }
+                        if constexpr (ACT == ACT_MUL_TILED) {
+                            const i32x4 x4 = xa[(r * 2 + ii) * 2 + (j >> 1)];
+                            v *= unpack4<T>(__builtin_bit_cast(s16x4, (j & 1) ? (i32x2){x4[2], x4[3]} : (i32x2){x4[0], x4[1]}));
+                        }
                         *(LDS_AS s16x4*)(wbuf + ii * 2048 + woff + (((j * 2 + wch) ^ wkey) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
                     }
 #pragma unroll
@@ -1799,9 +1851,9 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
     // epilogue in eight 16-row rounds of 4 KiB per wave: fc2 forward 1177 -> 1063, projection forward 830 -> 784, the GELU' multiply 1007 -> 880
     // TFLOP/s in situ - eight dependent load -> LDS -> store round trips cost more than the hidden prologue saves.  Those launches stay on the
     // one-tile kernel.)
-    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV, "the 16-bit staged epilogues");
+    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == ACT_PAIR_TILED || ACT == ACT_MUL_TILED, "the 16-bit staged epilogues");
     constexpr int BM = P8C::BM, BN = P8C::BN, BK = P8C::BK, HALF = P8C::HALF, TILE = P8C::TILE;
-    constexpr int NS = ACT == MICO_ACT_GELU_SAVE_DERIV ? 32 : 16;      // buffer stores per wave and tile
+    constexpr int NS = (ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == ACT_PAIR_TILED) ? 32 : 16;      // buffer stores per wave and tile
     // Counted waits never count on a STORE being outstanding: loads return in order among themselves, stores among themselves, but a store can
     // retire before an older load (the first version waited vmcnt(NS + 6) while the wanted half-tile was older than the previous tile's NS stores -
     // and read half-tiles that had not landed: 41 of 48 outputs wrong in tools/probes/epi16_check.py).  vmcnt(6) = "at most the three youngest
@@ -1976,13 +2028,23 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
             ktile(t, cur, VMS{});
             cur ^= TILE;
         }
+        i32x4 xa[ACT == ACT_MUL_TILED ? 16 : 1];
+        if constexpr (ACT == ACT_MUL_TILED) {   // the multiplier tile, requested before the closing wait (which then leaves these 16 loads out)
+            fence();
+            rsx = p8p_aux_tile_desc(g.e.aux_in, g, m0, n0);
+            p8p_aux_load(xa, rsx, wave, lane);
+            fence();
+        }
         if (wm == 0) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued past the last tile must not land in what follows
+        // the zero-fill DMAs issued past the last tile must not land in what follows
+        if constexpr (ACT == ACT_MUL_TILED) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---- the next tile's first six half-tiles, requested before this tile is stored ----
         rsc = out_desc(g.C, g.ldc * 2);
         if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) rsx = out_desc((char*)g.e.aux_out, g.e.ldaux * 2);
-        else rsx = rsc;
+        else if constexpr (ACT == ACT_PAIR_TILED) rsx = p8p_aux_tile_desc(g.e.aux_out, g, m0, n0);
+        else if constexpr (ACT != ACT_MUL_TILED) rsx = rsc;
         const int64_t n0e = n0;
         vb += gridDim.x;
         const bool more = vb < g.ntiles;
@@ -1991,7 +2053,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
             issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
         }
         // ---- epilogue: staging in the two ring slots the requests above do not use (second tile buffer: A-hi, B-lo), 4 KiB per wave ----
-        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, n0e, wm, wn, lane);
+        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, n0e, wm, wn, lane, xa, more);
         if (!more) return;
     }
 }
@@ -3279,8 +3341,15 @@ void launch_mid(int tb, const GemmArgs& g, hipStream_t st) {
 // the persistent form: fast16 launches with one of the 16-bit staged epilogues, enough tiles for several per CU
 template <typename T>
 bool launch_p8p(int tb, const GemmArgs& g, hipStream_t st) {
-    if (!MICO_P8_PERSIST || !g.fast16 || g.N % 8 != 0 || g.tm0 != 0 || g.ntiles <= 256 || g.ktiles < 2 || g.e.aux_in) return false;
+    if (!MICO_P8_PERSIST || !g.fast16 || g.N % 8 != 0 || g.tm0 != 0 || g.ntiles <= 256 || g.ktiles < 2) return false;
     const dim3 grid(256), block(P8C::THREADS);
+    if (g.e.aux_tiled) {      // the MLP pair with the tiled GELU' tensor (p8p_aux_tile_desc): the only kernels that know the layout
+        if (g.N % 256 != 0) return false;
+        if (g.e.act == MICO_ACT_MUL_AUX && tb && g.e.aux_in && !g.e.aux_out) { MICO_LAUNCH((gemm_p8p_kernel<T, true, ACT_MUL_TILED>), grid, block, 0, st, g); return true; }
+        if (g.e.act == MICO_ACT_GELU_SAVE_DERIV && !tb && g.e.aux_out) { MICO_LAUNCH((gemm_p8p_kernel<T, false, ACT_PAIR_TILED>), grid, block, 0, st, g); return true; }
+        return false;
+    }
+    if (g.e.aux_in) return false;
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) { if (tb) return false; MICO_LAUNCH((gemm_p8p_kernel<T, false, MICO_ACT_GELU_SAVE_DERIV>), grid, block, 0, st, g); return true; }
     if (g.e.act == MICO_ACT_GELU) { if (tb || g.e.aux_out) return false; MICO_LAUNCH((gemm_p8p_kernel<T, false, MICO_ACT_GELU>), grid, block, 0, st, g); return true; }
     if (g.e.act != MICO_ACT_NONE || g.e.aux_out) return false;
@@ -3403,7 +3472,7 @@ static constexpr int g_mico_gemm_variant = 0;
 static constexpr int g_mico_mid_group = 0;
 #endif
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 112; }
+extern "C" int mico_version(void) { return 113; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {
@@ -3417,6 +3486,7 @@ extern "C" int mico_struct_layout(int* out, int n) {
         OFF(mico_gemm_epilogue, kseg), OFF(mico_gemm_epilogue, a_seg_off), OFF(mico_gemm_epilogue, b_seg_off), OFF(mico_gemm_epilogue, row_map),
         OFF(mico_gemm_epilogue, rows_per_map), OFF(mico_gemm_epilogue, drop_p), OFF(mico_gemm_epilogue, drop_seed), OFF(mico_gemm_epilogue, drop_site),
         OFF(mico_gemm_epilogue, colsum_out), OFF(mico_gemm_epilogue, splitk_ws), OFF(mico_gemm_epilogue, splitk_ws_bytes),
+        OFF(mico_gemm_epilogue, aux_tiled),
         -1,
         (int)sizeof(mico_attn_params),
         OFF(mico_attn_params, B), OFF(mico_attn_params, H), OFF(mico_attn_params, Sq), OFF(mico_attn_params, Sk), OFF(mico_attn_params, hd),
@@ -3487,6 +3557,7 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
     if (epi) g.e = *epi;
     else { g.e = mico_gemm_epilogue{}; g.e.alpha = 1.f; }
     MICO_CHECK(g.e.nseg == 0, "mico_gemm_mx8: k-segments are a 16-bit feature");
+    MICO_CHECK(!g.e.aux_tiled, "mico_gemm_mx8: the tiled aux layout belongs to the 16-bit MLP pair (its fp8 dX launch reads a row-major aux)");
     MICO_CHECK(g.e.act >= MICO_ACT_NONE && g.e.act <= MICO_ACT_MUL_AUX, "mico_gemm_mx8: unknown act %d", g.e.act);
     if (g.e.act == MICO_ACT_GELU_GRAD || g.e.act == MICO_ACT_MUL_AUX) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm_mx8: GELU_GRAD / MUL_AUX need aux_in");
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MICO_CHECK(g.e.aux_out && c_dtype != MICO_F32, "mico_gemm_mx8: GELU_SAVE_DERIV needs aux_out and a 16-bit C");
@@ -3522,6 +3593,20 @@ extern "C" int mico_gemm_mx8(int64_t M, int64_t N, int64_t K, const void* A, int
 #undef MX8
     MICO_LAUNCH_CHECK();
     return MICO_OK;
+}
+
+// The element count of a TILED aux tensor for an [M, N] MLP hidden activation (mico_gemm_epilogue::aux_tiled), or 0 when the pair of launches that
+// would write (forward orientation, GELU_SAVE_DERIV) and read it (dX orientation, MUL_AUX) - both M x N over a reduction of K (the forward's may
+// be 2 K: x W_hi + x W_lo on the wrapped A stream), contiguous operands, 16-bit MFMA - does not run on the persistent 8-phase kernel in this build
+// (then the aux tensor is row-major as documented).  Mirrors mico_gemm's routing.
+extern "C" int64_t mico_gemm_aux_tiled_elems(int64_t M, int64_t N, int64_t K) {
+    static const bool no_wrap = getenv("MICO_P8_NOWRAP") != nullptr;
+    if (!MICO_P8_PERSIST || !MICO_P8_DEFAULT || g_mico_gemm_variant != 0 || no_wrap) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || N % 256 != 0 || K % 64 != 0 || K < 128) return 0;
+    const int64_t tiles = ((M + 255) / 256) * (N / 256);
+    if (tiles <= 256 || tiles >= 0x7FFFFFFFll) return 0;                       // (> 256: several tiles per CU; also mico_gemm's `big`: >= 128 tiles, N >= 192)
+    if (256 * N * 2 >= 0x7FFFFFFFll || 256 * (2 * K) * 2 + 2 * K * 2 >= 0x7FFFFF00ll || (K + 64) * N * 2 >= 0x7FFFFF00ll) return 0;   // the 31-bit offsets of fast16 / p8_ok
+    return ((M + 255) / 256) * 256 * N;
 }
 
 extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
@@ -3686,6 +3771,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else if (w4) DISPATCH_T16(dtype, (launch_w4<T, 0>(ta, tb, g, st)));
     else
 #endif
+    if (g.e.aux_tiled) MICO_CHECK(p8 && !pc && !w4, "mico_gemm: aux_tiled is the layout of the persistent 8-phase kernel's MLP pair (ask mico_gemm_aux_tiled_elems first)");
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (p8) {
         g_mico_last_gemm_kernel = 8;
@@ -3693,6 +3779,10 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         g.fast16 = c_dtype != MICO_F32 && !g.e.row_scale && !g.e.row_map && !g.e.resid && !g.e.accumulate && !g.e.pos && !g.e.remap_group && g.e.drop_p == 0.f &&
                    (g.e.act == MICO_ACT_NONE ? (!g.e.aux_out && !g.e.aux_in) : true) && 256 * ldc * 2 < 0x7FFFFFFFll &&
                    (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true) && g_mico_gemm_variant != 15;
+        if (g.e.aux_tiled)      // exactly launch_p8p's conditions for the two tiled instantiations
+            MICO_CHECK(MICO_P8_PERSIST && g_mico_gemm_variant != 16 && g.fast16 && N % 256 == 0 && g.ntiles > 256 && g.ktiles >= 2 &&
+                           ((g.e.act == MICO_ACT_GELU_SAVE_DERIV && !tb && g.e.aux_out) || (g.e.act == MICO_ACT_MUL_AUX && tb && g.e.aux_in && !g.e.aux_out)),
+                       "mico_gemm: aux_tiled is the layout of the persistent 8-phase kernel's MLP pair (ask mico_gemm_aux_tiled_elems first)");
         // Round quantisation: T tiles on 256 CUs take ceil(T / 256) rounds and the towers' N = 1408 launches have only ~6 (M = kept frames x 257
         // rows: 257 row tiles x 6 = 6.02 rounds is SEVEN).  The row tiles beyond the last full round can go to the 256x128 two-workgroups-per-CU
         // kernel instead: the same rows as <= 512 half-size tiles in one pass (cost model below; MICO_P8_SPLIT in the build or variant 14).

@@ -298,6 +298,13 @@ def _gemm_dx(dy16, plist, tag, out, k_pad=None, n_pad=None, ln=True, **epi):
     return ops.gemm(dy16, runtime.gemm_weight(plist, tag, ln_fed=ln)[0], out, tb=True, M=dy16.shape[0], N=k_in, K=n_out, **epi)
 
 
+def _aux_buf(M, N, K, dt, dev):
+    """(buffer, tiled) for an MLP's gelu'(pre-activation) tensor between its forward GEMM and its backward (ops.aux_buffer).  Row-major where one
+    of the two launches leaves the 16-bit persistent kernel: fp8 mode (the dX launch is an MX-fp8 one), the parity configuration (activation
+    [hi | lo]: three k-segments)."""
+    return ops.aux_buffer(M, N, K, dt, dev, tiled_ok=not (runtime.fp8_enabled() or runtime.split_precision()))
+
+
 def _qkv_params(P, b, arch):
     if arch["subln"]:
         return [P(b + "attn.q_proj.weight"), P(b + "attn.k_proj.weight"), P(b + "attn.v_proj.weight")]
@@ -660,10 +667,10 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
             else:
                 act = _empty((M2, Hd), dt, dev)
                 if (save and diet.keep_mlp[i]) or runtime.fp8_enabled() or not runtime.CFG.fc1_plain_gelu:   # (the 8-phase fp8 kernel has the pair epilogue only)
-                    h = _empty((M2, Hd), dt, dev)
-                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV)
+                    h, h_tiled = _aux_buf(M2, Hd, D, dt, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=h_tiled)
                     if diet.keep_mlp[i]:
-                        a.update(h=h, act=act)
+                        a.update(h=h, act=act, h_tiled=h_tiled)
                     del h
                 else:   # nobody will read GELU' (no backward, or the activation diet recomputes the pair): half the output bytes of the launch
                     _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), act=ops.ACT_GELU)
@@ -804,14 +811,14 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                     if ln2b is None:
                         ln2b, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, mx8_for=Hd,
                                                      x_normalized=a["xn"])
-                    a["h"], a["act"] = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
-                    _gemm_fwd(ln2b, D, [w1], "w", a["act"], bias=P(b + "mlp.fc1.bias"), aux_out=a["h"], act=ops.ACT_GELU_SAVE_DERIV)
+                    (a["h"], a["h_tiled"]), a["act"] = _aux_buf(M2, Hd, D, dt, dev), _empty((M2, Hd), dt, dev)
+                    _gemm_fwd(ln2b, D, [w1], "w", a["act"], bias=P(b + "mlp.fc1.bias"), aux_out=a["h"], act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=a["h_tiled"])
                     del ln2b
                 elif a["ln2"] is None:      # the MLP intermediates were kept, the LayerNorm output (fc1's weight gradient reads it) was not
                     _, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, x_normalized=a["xn"])
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX)   # a["h"] = gelu'(pre-activation)
+                _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX, aux_tiled=a["h_tiled"])   # a["h"] = gelu'(pre-activation)
                 linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
                 _gemm_dx(dh, [w1], "w", dln2)
                 del dh

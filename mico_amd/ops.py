@@ -4,6 +4,7 @@ No autograd here and no fallback: every function requires CUDA(HIP) tensors and 
 All launches go to torch's current stream.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -83,9 +84,10 @@ def release_scratch():
 
 def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, aux_out=None, aux_in=None, act=ACT_NONE,
          row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0, remap=(0, 0, 0), alpha=1.0,
-         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0, drop=None, colsum_out=None):
+         accumulate=False, split_k=1, dtype=None, ksegs=None, row_map=None, rows_per_map=0, drop=None, colsum_out=None, aux_tiled=False):
     """out = epilogue(opA(A) @ opB(B)); see include/mico_hip.h (mico_gemm).  A/B are 2-D 16-bit tensors (row stride =
-    leading dim).  ta: A stored [K,M]; tb: B stored [K,N]."""
+    leading dim).  ta: A stored [K,M]; tb: B stored [K,N].  aux_tiled: the aux tensor is an AuxTiled-sized buffer in the MLP pair's
+    private layout (mico_gemm_epilogue::aux_tiled; aux_buffer() below decides)."""
     dtype = dtype or A.dtype
     if A.dtype != B.dtype:   # the kernel takes ONE element type for both operands: mixed bit patterns would multiply silently
         raise MicoHipError(f"mico_gemm operands differ in dtype ({A.dtype} x {B.dtype}): a backward pass running under another "
@@ -102,6 +104,9 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.aux_in = _p(aux_in)
     aux = aux_out if aux_out is not None else aux_in
     e.ldaux = aux.stride(0) if aux is not None else 0
+    if aux_tiled:
+        _check_tiled(aux, M, N)
+        e.aux_tiled, e.ldaux = 1, N
     e.act = act
     e.row_scale = _p(row_scale)
     e.rows_per_scale = rows_per_scale
@@ -145,12 +150,35 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     return out
 
 
+def _check_tiled(aux, M, N):
+    need = ((M + 255) // 256) * 256 * N
+    if aux is None or not aux.is_contiguous() or aux.numel() < need:
+        raise MicoHipError(f"aux_tiled: the aux tensor of an [{M}, {N}] launch is a contiguous buffer of >= {need} elements (ops.aux_buffer)")
+
+
+def aux_buffer(M, N, K, dtype, device, tiled_ok=True):
+    """The tensor that carries gelu'(pre-activation) from an MLP's forward GEMM (GELU_SAVE_DERIV, aux_out) to its backward (MUL_AUX, aux_in):
+    (buffer, tiled).  tiled = both launches - [M, N] over a reduction of K - run on the persistent 8-phase kernel, which keeps the tensor in its
+    accumulator layout (mico_gemm_epilogue::aux_tiled; M rounded up to 256 rows); otherwise (or with tiled_ok = False: launches the caller
+    knows to go elsewhere - fp8 mode, three k-segments) the documented row-major [M, N]."""
+    n = int(_lib.lib().mico_gemm_aux_tiled_elems(M, N, K)) if (AUX_TILED and tiled_ok) else 0
+    if n > 0:
+        return torch.empty((n // N, N), dtype=dtype, device=device), True
+    return torch.empty((M, N), dtype=dtype, device=device), False
+
+
+AUX_TILED = os.environ.get("MICO_AUX_TILED", "1") != "0"     # A/B switch: 0 keeps every aux tensor row-major
+
+
 def _epilogue(bias=None, aux_out=None, aux_in=None, act=ACT_NONE, row_scale=None, rows_per_scale=0, resid=None, pos=None, pos_rows=0,
-              remap=(0, 0, 0), alpha=1.0, accumulate=False, row_map=None, rows_per_map=0, drop=None):
+              remap=(0, 0, 0), alpha=1.0, accumulate=False, row_map=None, rows_per_map=0, drop=None, aux_tiled=False, tiled_shape=None):
     e = GemmEpilogue()
     e.bias, e.aux_out, e.aux_in = _p(bias), _p(aux_out), _p(aux_in)
     aux = aux_out if aux_out is not None else aux_in
     e.ldaux = aux.stride(0) if aux is not None else 0
+    if aux_tiled:
+        _check_tiled(aux, *tiled_shape)
+        e.aux_tiled, e.ldaux = 1, tiled_shape[1]
     e.act = act
     e.row_scale, e.rows_per_scale = _p(row_scale), rows_per_scale
     e.resid, e.pos, e.pos_rows = _p(resid), _p(pos), pos_rows
@@ -194,7 +222,7 @@ def gemm_mx8(A, B, out, *, dtype, M=None, **epi):
     aux tensors; epilogue keywords as ops.gemm (no split-K, no k-segments)."""
     M = M if M is not None else A.q.shape[0]
     N, K = B.q.shape
-    e = _epilogue(**epi)
+    e = _epilogue(tiled_shape=(M, N), **epi)
     timer = GEMM_TIMER
     timed = timer is not None and (0, 0) in timer.variants
     if timed:

@@ -132,6 +132,53 @@ def test_persistent_gemm_matches_one_tile_kernel(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(40000, 768, 256), (33001, 1536, 1408)])
+def test_mlp_pair_tiled_aux_matches_row_major(cuda, dtype, M, N, K):
+    """mico_gemm_epilogue::aux_tiled (round 5): the GELU pair writes gelu'(pre-activation) in the persistent kernel's accumulator layout and the
+    dX launch's multiply reads it back from there - both outputs (gelu, and dX * gelu') bit for bit those of the row-major aux tensor, on a
+    ragged M (rows of the last tile beyond M), plus: the library refuses the layout where it cannot honour it."""
+    from mico_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x = (0.5 * torch.randn(M, K, generator=g)).to(cuda).to(dtype)
+    w1 = (0.05 * torch.randn(N, K, generator=g)).to(cuda).to(dtype)
+    bias = torch.randn(N, generator=g).to(cuda)
+    dy = torch.randn(M, 512, generator=g).to(cuda).to(dtype)
+    w2 = (0.05 * torch.randn(512, N, generator=g)).to(cuda).to(dtype)       # dH = dy @ w2 : [M, N] over K2 = 512
+    act_r, h_r = torch.empty(M, N, device=cuda, dtype=dtype), torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(x, w1, act_r, bias=bias, aux_out=h_r, act=ops.ACT_GELU_SAVE_DERIV)
+    dh_r = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(dy, w2, dh_r, tb=True, M=M, N=N, K=512, aux_in=h_r, act=ops.ACT_MUL_AUX, alpha=0.5)
+    h_t, tiled = ops.aux_buffer(M, N, K, dtype, cuda)
+    assert tiled and h_t.numel() == ((M + 255) // 256) * 256 * N
+    h_t.fill_(float("nan"))
+    act_t = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(x, w1, act_t, bias=bias, aux_out=h_t, act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=True)
+    assert ops._lib.lib().mico_gemm_last_kernel() == 8
+    dh_t = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(dy, w2, dh_t, tb=True, M=M, N=N, K=512, aux_in=h_t, act=ops.ACT_MUL_AUX, alpha=0.5, aux_tiled=True)
+    assert torch.equal(act_t.view(torch.int16), act_r.view(torch.int16))
+    assert torch.equal(dh_t.view(torch.int16), dh_r.view(torch.int16))
+    # the tiled image holds exactly the row-major values: tile (tm, tn) -> wave (wm, wn) -> unit (i, jj) -> lane (p, gq) -> 2 x 4 columns
+    t = h_t.view(-1)[:((M + 255) // 256) * (N // 256) * 65536].view((M + 255) // 256, N // 256, 2, 4, 8, 2, 4, 16, 2, 4)   # tm tn wm wn i jj gq p half c
+    rows = h_r.new_zeros(((M + 255) // 256) * 256, N)
+    rows[:M] = h_r
+    # row = tm 256 + (i >> 2) 128 + wm 64 + (i & 3) 16 + p ; col = tn 256 + wn 32 + jj 128 + half 16 + gq 4 + c
+    r5 = rows.view((M + 255) // 256, 2, 2, 4, 16, N // 256, 2, 4, 2, 4, 4)        # tm ihi wm ilo p | tn jj wn half gq c
+    want = r5.permute(0, 5, 2, 7, 1, 3, 6, 9, 4, 8, 10).reshape(t.shape[0], t.shape[1], 2, 4, 8, 2, 4, 16, 2, 4)
+    live = torch.zeros_like(rows, dtype=torch.bool)
+    live[:M] = True
+    lv = live.view((M + 255) // 256, 2, 2, 4, 16, N // 256, 2, 4, 2, 4, 4).permute(0, 5, 2, 7, 1, 3, 6, 9, 4, 8, 10).reshape(t.shape)
+    assert torch.equal(t[lv].view(torch.int16), want[lv].view(torch.int16))
+    # refused where the launch is not the persistent pair: a small problem, and a buffer that is too small
+    small = torch.empty(512, N, device=cuda, dtype=dtype)
+    with pytest.raises(ops.MicoHipError):
+        ops.gemm(x[:512], w1, small, bias=bias, aux_out=torch.empty(512, N, device=cuda, dtype=dtype), act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=True)
+    with pytest.raises(ops.MicoHipError):
+        ops.gemm(x, w1, act_t, bias=bias, aux_out=h_r, act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=True)
+    assert ops.aux_buffer(512, N, K, dtype, cuda)[1] is False and ops.aux_buffer(M, N + 8, K, dtype, cuda)[1] is False
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cols", [768, 1408, 2048])
 @pytest.mark.parametrize("xdt", ["f32", "16"])
 def test_layernorm(cuda, dtype, cols, xdt):

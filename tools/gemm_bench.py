@@ -63,6 +63,8 @@ def main():
         dw = torch.zeros(N, K, device=dev)
         bias = torch.randn(N, device=dev)
         sk = a.split_k
+        auxt, t1 = ops.aux_buffer(M, N, K, dt, dev)
+        auxt2, t2 = ops.aux_buffer(M, K, N, dt, dev)
         if a.mx8:
             qx, qw = ops.quant_mx8(x), ops.quant_mx8(w)
         if a.resid:
@@ -79,10 +81,14 @@ def main():
             **({"quant": lambda: ops.quant_mx8(x)} if a.mx8 else {}),
             "dx": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N),
             "dxaux": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N, aux_in=x, act=ops.ACT_MUL_AUX),   # (fc2's dX times the stored GELU': x stands in for it)
+            # the MLP pair, row-major and tiled aux (mico_gemm_epilogue::aux_tiled): forward with the GELU pair, dX times the stored GELU'
+            "pair": lambda: ops.gemm(x, w, y, bias=bias, aux_out=dy, act=ops.ACT_GELU_SAVE_DERIV),
+            "pairt": lambda: ops.gemm(x, w, y, bias=bias, aux_out=auxt, act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=True),
+            "dxauxt": lambda: ops.gemm(dy, w, dx, tb=True, M=M, N=K, K=N, aux_in=auxt2, act=ops.ACT_MUL_AUX, aux_tiled=True),
             "dw": lambda: ops.gemm(dy, x, dw, ta=True, tb=True, M=N, N=K, K=M, accumulate=True, split_k=sk),
         }
         for cname, fn, var in [(c, f, v) for c, f in cases.items() for v in (variants * 2 if len(variants) > 1 else variants)]:
-            if (a.only and cname not in a.only.split(",")) or (a.mx8 and cname in ("dx", "dxaux", "dw")) or (cname == "dxaux" and "dxaux" not in a.only.split(",")):
+            if (a.only and cname not in a.only.split(",")) or (a.mx8 and cname in ("dx", "dxaux", "dw", "pair", "pairt", "dxauxt")) or (cname in ("dxaux", "pair", "pairt", "dxauxt") and cname not in a.only.split(",")) or (cname == "pairt" and not t1) or (cname == "dxauxt" and not t2):
                 continue
             if var is not None:
                 ops._lib.set_gemm_variant(var)
