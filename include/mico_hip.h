@@ -346,6 +346,14 @@ int mico_cls_rows(float* x, int64_t ld, int B, int group_rows, const float* cls,
 /* y[r,:] = a[r,:] + b[r,:] (fp32), optional 16-bit copy */
 int mico_add_f32(const float* a, const float* b, float* y, void* y16, int64_t n, float scale16, int dtype, void* stream);
 
+/* Weight gradient of a Linear whose input is a LayerNorm output y = xhat * gamma + beta (eva_vit_model.py:409-416: norm1 -> attn.qkv,
+ * norm2 -> mlp.fc1; torch autograd forms dy^T y from the saved y).  With only the fp16 normalised rows xhat kept (mico_ln_fwd_params::xhat16)
+ * the backward runs mico_gemm(ta = tb = 1) against xhat into the zeroed scratch pair dwt[M, N] / dbt[M] (colsum_out) and this call adds
+ *     dw[m, n] += dwt[m, n] * gamma[n] + dbt[m] * beta[n],    db[m] += dbt[m]  (db may be NULL)
+ * - the same sums, without re-creating y over all rows.  fp32 throughout (16-byte accesses when N, ld_dw are multiples of 4 and the bases aligned). */
+int mico_dw_colfold(const float* dwt, const float* dbt, const float* gamma, const float* beta, float* dw, int64_t ld_dw, float* db, int M, int N,
+                    void* stream);
+
 /* exact-erf GELU (nn.GELU; mico.py:22-28) forward / backward, fp32 and 16-bit flat arrays. */
 int mico_gelu_f32(const float* x, float* y, int64_t n, void* stream);
 int mico_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);

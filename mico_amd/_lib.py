@@ -106,6 +106,7 @@ PROTOTYPES = {
     "mico_gelu_bwd_16": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "mico_cls_pool_fwd": [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
     "mico_cls_pool_bwd": [c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
+    "mico_dw_colfold": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_vp],
     "mico_pool_video_fwd": [c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "mico_pool_video_bwd": [c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "mico_l2norm_fwd": [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
@@ -132,7 +133,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 113   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 114   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

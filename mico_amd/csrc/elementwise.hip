@@ -232,6 +232,31 @@ __global__ void add_f32_kernel(const float* __restrict__ a, const float* __restr
     }
 }
 
+// ---- LayerNorm affine folded into a weight gradient ----------------------------------------------------------------------
+// The weight gradient of a Linear fed by y = xhat * gamma + beta (xhat: the fp16 normalised rows the activation diet keeps) is
+//     dy^T y = (dy^T xhat) . gamma[n]  +  colsum(dy)[m] beta[n]
+// so the backward multiplies against the normalised rows themselves (into the scratch pair dwt / dbt) and this pass adds the result, column-scaled
+// and with the rank-one term, to the parameter gradients - instead of re-creating y with a pass over all rows (ln_affine16_kernel: 4 bytes per row
+// element against 12 bytes per WEIGHT element here).
+template <int V>   // V = 4: 16-byte accesses (every base 16-byte aligned, N and ld_dw multiples of 4);  1: element by element
+__global__ void dw_colfold_kernel(const float* __restrict__ dwt, const float* __restrict__ dbt, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  float* __restrict__ dw, int64_t ld_dw, float* __restrict__ db, int M, int nv) {
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int m = (int)(i / nv), c = (int)(i - (int64_t)m * nv);
+        const vec t = ((const vec*)dwt)[i];
+        const vec gm = ((const vec*)gamma)[c], bt = ((const vec*)beta)[c];
+        const float s = dbt[m];
+        vec* o = (vec*)(dw + (int64_t)m * ld_dw) + c;
+        vec v = *o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] += __builtin_fmaf(t[k], gm[k], s * bt[k]);
+        *o = v;
+        if (db && c == 0) db[m] += s;
+    }
+}
+
 // ---- SwiGLU gate ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -558,6 +583,16 @@ extern "C" int mico_add_f32(const float* a, const float* b, float* y, void* y16,
     MICO_CHECK(dtype_ok(dtype) && a && (y || y16) && n % 4 == 0, "mico_add_f32: bad args (n must be a multiple of 4)");
     if (n <= 0) return MICO_OK;
     DISPATCH_T16(dtype, MICO_LAUNCH(add_f32_kernel<T>, dim3(egrid(n / 4)), dim3(EB), 0, ST, a, b, y, (T*)y16, n / 4, scale16));
+    MICO_LAUNCH_CHECK();
+    return MICO_OK;
+}
+
+extern "C" int mico_dw_colfold(const float* dwt, const float* dbt, const float* gamma, const float* beta, float* dw, int64_t ld_dw, float* db, int M, int N,
+                               void* stream) {
+    MICO_CHECK(dwt && dbt && gamma && beta && dw && M > 0 && N > 0 && ld_dw >= N, "mico_dw_colfold: bad args");
+    const bool vec = N % 4 == 0 && ld_dw % 4 == 0 && (((uintptr_t)dwt | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)dw) & 15) == 0;
+    if (vec) MICO_LAUNCH(dw_colfold_kernel<4>, dim3(egrid((int64_t)M * (N / 4))), dim3(EB), 0, ST, dwt, dbt, gamma, beta, dw, ld_dw, db, M, N / 4);
+    else MICO_LAUNCH(dw_colfold_kernel<1>, dim3(egrid((int64_t)M * N)), dim3(EB), 0, ST, dwt, dbt, gamma, beta, dw, ld_dw, db, M, N);
     MICO_LAUNCH_CHECK();
     return MICO_OK;
 }

@@ -3472,7 +3472,7 @@ static constexpr int g_mico_gemm_variant = 0;
 static constexpr int g_mico_mid_group = 0;
 #endif
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 113; }
+extern "C" int mico_version(void) { return 114; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {

@@ -171,6 +171,26 @@ def linear_wgrad(dy16, x16, dw, inv_s, n_out=None, n_in=None, dbias=None):
              split_k=0, colsum_out=dbias)   # 0 = let the library size the K split in whole waves of resident workgroups
 
 
+def _ln_fold_ok(a, dt):
+    """The block's LayerNorm inputs are kept as fp16 normalised rows (activation diet level 3) and the step multiplies in fp16: a weight gradient
+    against a LayerNorm OUTPUT can be taken against those rows directly (_wgrad_ln_folded)."""
+    return bool(a.get("xn", False)) and dt == torch.float16 and runtime.CFG.ln_fold_wgrad
+
+
+def _wgrad_ln_folded(dy16, xhat16, gamma, beta, dw, db, inv_s, dbt=None):
+    """dw += inv_s * dy16^T (xhat16 * gamma + beta),  db += inv_s * colsum(dy16)  without forming the LayerNorm output:
+    dy^T (xhat gamma + beta) = (dy^T xhat) . gamma[n] + colsum(dy)[m] beta[n]  (mico_dw_colfold).  The reference's autograd multiplies against the
+    saved LayerNorm output (eva_vit_model.py:409-416 -> nn.Linear backward); here xhat is rounded to fp16 once and the affine map stays in fp32.
+    dbt: a zeroed fp32 [n_out] buffer that receives this launch's bias gradient (then db is not touched)."""
+    n_out, n_in = dw.shape
+    dwt = torch.zeros((n_out, n_in), dtype=torch.float32, device=dy16.device)
+    own = dbt is None
+    if own:
+        dbt = torch.zeros(n_out, dtype=torch.float32, device=dy16.device)
+    linear_wgrad(dy16, xhat16, dwt, inv_s, dbias=dbt)
+    ops.dw_colfold(dwt, dbt, gamma.detach(), beta.detach(), dw, db if own else None)
+
+
 # ======================================================================================================================
 # EVA ViT tower  (reference: model/evaclip/eva_vit_model.py:611-650 forward_features, :409-416 Block, :293-365 Attention,
 # :190-224 Mlp / SwiGLU, :427-448 PatchEmbed)
@@ -804,6 +824,7 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 del dhln, dhsw, dx1, dx2, pend
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
+                fold2 = False
                 if "act" not in a:
                     # activation diet: the LayerNorm output (from the saved rows - fp32: compact kept rows or the whole stream, in either case
                     # exactly the M2 rows the forward normalised; or their fp16 normalised form), then fc1 + GELU / GELU' as the forward ran them
@@ -815,11 +836,16 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                     _gemm_fwd(ln2b, D, [w1], "w", a["act"], bias=P(b + "mlp.fc1.bias"), aux_out=a["h"], act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=a["h_tiled"])
                     del ln2b
                 elif a["ln2"] is None:      # the MLP intermediates were kept, the LayerNorm output (fc1's weight gradient reads it) was not
-                    _, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, x_normalized=a["xn"])
+                    fold2 = _ln_fold_ok(a, dt)   # ... and need not be: the gradient is taken against the normalised rows (below)
+                    if not fold2:
+                        _, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, x_normalized=a["xn"])
                 linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
                 dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
                 _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX, aux_tiled=a["h_tiled"])   # a["h"] = gelu'(pre-activation)
-                linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
+                if fold2:
+                    _wgrad_ln_folded(dh, a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), G(b + "mlp.fc1.weight"), G(b + "mlp.fc1.bias"), inv_s)
+                else:
+                    linear_wgrad(dh, a["ln2"], G(b + "mlp.fc1.weight"), inv_s, dbias=G(b + "mlp.fc1.bias"))
                 _gemm_dx(dh, [w1], "w", dln2)
                 del dh
             ho, pre = handover(a["tr2"], a["B1"], a["sc1"], a["sc2"] is not None)
@@ -846,7 +872,8 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                                   dgamma=G(b + "attn.inner_attn_ln.weight"), dbeta=G(b + "attn.inner_attn_ln.bias"),
                                   grad_scale=inv_s, dtype=dt)
                 dao = dao2
-            if a["ln1"] is None:      # activation diet: the LayerNorm output was not kept
+            fold1 = a["ln1"] is None and not arch["subln"] and _ln_fold_ok(a, dt)
+            if a["ln1"] is None and not fold1:      # activation diet: the LayerNorm output was not kept
                 _, a["ln1"], _, _ = _ln16(a["x1"], P(b + "norm1.weight"), P(b + "norm1.bias"), spec.eps, M1, D, dt, dev, x_normalized=a["xn"])
             qkv = a["qkv"]
             dqkv = _empty((M1, 3 * D), dt, dev)
@@ -863,6 +890,8 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                 G(b + "attn.q_proj.weight").add_(dwf[:D])
                 G(b + "attn.k_proj.weight").add_(dwf[D:2 * D])
                 G(b + "attn.v_proj.weight").add_(dwf[2 * D:])
+            elif fold1:     # against the kept normalised rows; norm1's gamma / beta applied to the [3 D, D] result
+                _wgrad_ln_folded(dqkv, a["x1"], P(b + "norm1.weight"), P(b + "norm1.bias"), G(b + "attn.qkv.weight"), None, inv_s, dbt=dbias)
             else:
                 linear_wgrad(dqkv, a["ln1"], G(b + "attn.qkv.weight"), inv_s, dbias=dbias)
             G(b + "attn.q_bias").add_(dbias[:D])

@@ -411,6 +411,15 @@ def colsum(x, out, *, rows=None, cols=None, ld=None, scale=1.0, accumulate=False
     return out
 
 
+def dw_colfold(dwt, dbt, gamma, beta, dw, db=None):
+    """dw[m, n] += dwt[m, n] * gamma[n] + dbt[m] * beta[n];  db[m] += dbt[m]  (mico_dw_colfold: a LayerNorm's affine folded into the weight
+    gradient of the Linear it feeds - dwt / dbt come from the weight-gradient GEMM against the normalised rows)."""
+    M, N = dwt.shape
+    assert dwt.is_contiguous() and dwt.dtype == dbt.dtype == gamma.dtype == beta.dtype == dw.dtype == torch.float32 and dw.stride(1) == 1
+    assert dw.shape[0] >= M and dw.shape[1] == N and dbt.numel() >= M and gamma.numel() == N and beta.numel() == N
+    check(_lib.lib().mico_dw_colfold(_p(dwt), _p(dbt), _p(gamma), _p(beta), _p(dw), dw.stride(0), _p(db), M, N, _st()), "mico_dw_colfold")
+
+
 def cls_rows(x, B, group_rows, cls, pos0):
     check(_lib.lib().mico_cls_rows(_p(x), x.stride(0), B, group_rows, _p(cls), _p(pos0), x.shape[1], _st()), "mico_cls_rows")
 

@@ -29,6 +29,9 @@ class _Cfg:
     # MICO_NO_GRAD_HANDOVER: A/B switch, every branch gathers its operand with mico_gather_rows_cast
     fuse_grad_handover = os.environ.get("MICO_NO_GRAD_HANDOVER") is None
     ln_grad_16bit = os.environ.get("MICO_LN_GRAD_FP32") is None   # gradient at the LayerNorm outputs stored 16-bit (functional._tower_backward)
+    # activation diet level 3: qkv / fc1 weight gradients taken against the kept fp16 NORMALISED rows, the LayerNorm's gamma / beta applied to the
+    # [out, in] result (ops.dw_colfold) instead of re-creating the LayerNorm output over all rows first (functional._tower_backward)
+    ln_fold_wgrad = os.environ.get("MICO_LN_NOFOLD") is None
     head_split_blocks = 0     # plain fp16 only: the first n tower blocks in a split mode (see enter_block)
     head_split_mode = "weights"
     # BASELINE.json configs[4] ("fp8 MFMA"): the ViT towers' and BERT's forward and input-gradient GEMMs run on the block-scaled fp8 MFMA

@@ -176,6 +176,42 @@ def test_activation_diet_recompute(cuda):
                 if key[0] == 3:
                     worst = max(worst, rel_err(g1[n], g0[n]))
     print("level 3 (fp16 normalised rows) against level 0: worst gradient difference", worst)
+    # round 5 (late): at level 3 the qkv / kept-block fc1 weight gradients are taken against the normalised rows and norm1 / norm2's gamma, beta
+    # applied to the result (functional._wgrad_ln_folded) - against the same level with the LayerNorm outputs re-created first
+    # (runtime.CFG.ln_fold_wgrad off): the same sums up to the fp16 rounding of the re-created output that the folded form does not make
+    assert rt.CFG.ln_fold_wgrad
+    with torch.no_grad():       # (LayerNorms start as the identity map: give the fold something to fold)
+        gp = torch.Generator().manual_seed(3)
+        for n, p in vis.named_parameters():
+            if ".norm1." in n or ".norm2." in n:
+                p.add_((torch.randn(p.shape, generator=gp) * 0.3).to(cuda))
+    both, calls, real_fold = {}, {True: 0, False: 0}, Fn.ops.dw_colfold
+    try:
+        rt.set_activation_diet(3, 1)
+        for fold in (True, False):
+            rt.CFG.ln_fold_wgrad = fold
+
+            def counted(*a, _f=fold, **k):
+                calls[_f] += 1
+                return real_fold(*a, **k)
+            Fn.ops.dw_colfold = counted
+            with rt.precision(torch.float16):
+                m.zero_grad(set_to_none=True)
+                out = vis.forward_groups([img, aud], drop_path_scale=None)      # (this draw of `dps` drops the last block's MLP branch in every frame)
+                (out * w).sum().backward()
+            both[fold] = (out.detach().clone(), {n: p.grad.clone() for n, p in vis.named_parameters() if p.grad is not None})
+    finally:
+        Fn.ops.dw_colfold = real_fold
+        rt.CFG.ln_fold_wgrad = True
+        rt.set_activation_diet(None)
+    (o1, g1), (o2, g_plain) = both[True], both[False]
+    assert torch.equal(o1, o2)
+    fold_worst = max(rel_err(g1[n], g_plain[n]) for n in g_plain)
+    differs = [n for n in g_plain if not torch.equal(g1[n], g_plain[n])]
+    print("folded against re-created LayerNorm outputs: worst", fold_worst, "in", len(differs), "tensors;", calls[True], "folded weight gradients")
+    assert fold_worst < 1e-3 and any("qkv.weight" in n for n in differs) and any("fc1.weight" in n for n in differs)
+    # qkv of both blocks + fc1 of the one block that kept its MLP intermediates (per tower pass), and none with the switch off
+    assert calls[True] >= depth + 1 and calls[True] % (depth + 1) == 0 and calls[False] == 0, calls
     # the plan: the cheapest combination that fits - everything fits here, so nothing is dropped
     spec, _ = vis._tower_spec()
     chunk0, diet0 = Fn.tower_plan(spec, 5, cuda)

@@ -925,3 +925,32 @@ def test_pool_video_kernel(cuda):
         gx, = torch.autograd.grad((y * w).sum(), x)
         gr, = torch.autograd.grad((ref * w).sum(), x)
         assert (gx - gr).abs().max().item() <= 1e-6 * gr.abs().max().item()
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_dw_colfold_kernel(cuda, aligned):
+    """mico_dw_colfold: dw += dwt . gamma[n] + dbt[m] beta[n], db += dbt - the LayerNorm affine folded into the weight gradient of the Linear it
+    feeds (eva_vit_model.py:409-416: norm1 -> attn.qkv, norm2 -> mlp.fc1).  Against the torch expression, as views of a parameter-gradient arena
+    (16-byte aligned: the vector form; off by one element: the element-wise form), and end to end: dy^T (xhat gamma + beta) from the pieces."""
+    from mico_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, R = 4224, 1408, 3000
+    off = 0 if aligned else 1
+    arena = torch.randn(off + M * N + M + 8, device=cuda, generator=g)
+    dw, db = arena[off:off + M * N].view(M, N), arena[off + M * N:off + M * N + M]
+    dw0, db0 = dw.clone(), db.clone()
+    gamma, beta = torch.randn(N, device=cuda, generator=g), torch.randn(N, device=cuda, generator=g)
+    dy = (torch.randn(R, M, device=cuda, generator=g) * 0.1).half()
+    xhat = torch.randn(R, N, device=cuda, generator=g).half()
+    dwt, dbt = torch.zeros(M, N, device=cuda), torch.zeros(M, device=cuda)
+    ops.gemm(dy, xhat, dwt, ta=True, tb=True, M=M, N=N, K=R, accumulate=True, alpha=0.5, split_k=0, colsum_out=dbt)
+    ops.dw_colfold(dwt, dbt, gamma, beta, dw, db)
+    assert torch.allclose(dw, dw0 + dwt * gamma + dbt[:, None] * beta, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(db, db0 + dbt, rtol=1e-6, atol=1e-6)
+    y = xhat.float() * gamma + beta
+    ref = 0.5 * dy.float().t() @ y
+    assert rel_err(dw - dw0, ref) < 1e-4
+    assert rel_err(db - db0, 0.5 * dy.float().sum(0)) < 1e-5
+    dw1 = dw.clone()
+    ops.dw_colfold(dwt, dbt, gamma, beta, dw, None)      # db = NULL: the caller owns the bias gradient
+    assert torch.allclose(dw - dw1, dwt * gamma + dbt[:, None] * beta, rtol=1e-5, atol=1e-5) and torch.equal(db, db0 + dbt)
