@@ -3626,6 +3626,10 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
     else MICO_CHECK(ldb >= N, "mico_gemm: B^T[K,N] needs ldb >= N");
     MICO_CHECK(c_dtype == MICO_F32 || c_dtype == dtype, "mico_gemm: c_dtype must be MICO_F32 or dtype");
     MICO_CHECK(256 * lda * 2 < 0x7FFFFFFFll && 256 * ldb * 2 < 0x7FFFFFFFll, "mico_gemm: leading dimension too large");
+    // a reduction-major operand is addressed by 32-bit byte offsets from the first row of its tile column (buffer descriptors): K rows of it must
+    // stay below 4 GiB - larger reductions are issued as accumulating launches over row chunks (functional.CrossKVFn.backward does)
+    if (ta) MICO_CHECK(K * lda * 2 <= 0xFFFFFF00ll, "mico_gemm: A^T[K,M] spans %lld bytes (K * lda * 2); reduction-major operands are limited to 4 GiB per launch", (long long)(K * lda * 2));
+    if (tb) MICO_CHECK(K * ldb * 2 <= 0xFFFFFF00ll, "mico_gemm: B^T[K,N] spans %lld bytes (K * ldb * 2); reduction-major operands are limited to 4 GiB per launch", (long long)(K * ldb * 2));
     GemmArgs g;
     g.A = (const char*)A; g.B = (const char*)B; g.C = (char*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

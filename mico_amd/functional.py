@@ -1462,6 +1462,25 @@ def _fwd_gemm(x, key, plist, out, **kw):
 SITE_SELF_OUT, SITE_CROSS_OUT, SITE_FFN_OUT, SITE_SELF_P, SITE_CROSS_P, SITE_EMB = 0, 1, 2, 3, 4, 100000
 
 
+def _kv_all_weights(kvparams, L):
+    """key.weight, value.weight of every layer in order: the rows of the [L * 2 D, D] weight behind the interleaved K/V memory."""
+    return [kvparams[4 * li + j] for li in range(L) for j in (0, 2)]
+
+
+def _kv_rows_view(t, L, D):
+    """t: [L][rows][2 D] tensor that is a permuted view of a [rows][L * 2 D] row-major buffer -> that 2-D buffer (no copy), else None."""
+    if t.dim() != 3 or t.shape[0] != L or t.shape[2] != 2 * D or t.stride() != (2 * D, L * 2 * D, 1):
+        return None
+    return torch.as_strided(t, (t.shape[1], L * 2 * D), (L * 2 * D, 1))
+
+
+def _kv_grad_buffer(L, rows, D, dt, dev, interleaved):
+    """[L][rows][2 D] gradient buffer of the shared K/V memory in the memory's own layout."""
+    if interleaved:
+        return _empty((rows, L * 2 * D), dt, dev).view(rows, L, 2 * D).permute(1, 0, 2)
+    return _empty((L, rows, 2 * D), dt, dev)
+
+
 class CrossKVFn(torch.autograd.Function):
     """Cross-attention K/V projections of the condition tokens for ALL layers, computed once per step and shared by every BERT pass
     that attends to the same tokens with the same weights: the ITM triplet [own | hard negative | own] (vast.py:438-447) contains
@@ -1483,10 +1502,18 @@ class CrossKVFn(torch.autograd.Function):
         ops.cast_f32_to_16(cond_own.contiguous().view(n * E, D), cond16[:n * E])
         if cond_neg is not None:
             ops.cast_f32_to_16(cond_neg.contiguous().view(n * E, D), cond16[n * E:])
-        kv = _empty((spec.L, sets * n * E, 2 * D), dt, dev)
-        for li in range(spec.L):
-            wk, bk, wv, bv = kvparams[4 * li: 4 * li + 4]
-            _fwd_gemm(cond16, "bkv", [wk, wv], kv[li], bias=torch.cat((bk.detach(), bv.detach())))
+        L = spec.L
+        ctx.interleaved = bool(runtime.CFG.kv_interleaved)
+        if ctx.interleaved:
+            # [rows][layer][K | V]: every layer's projection in one launch (N = L * 2 D); a layer is the view kv[li] with row stride L * 2 D
+            kvbuf = _empty((sets * n * E, L * 2 * D), dt, dev)
+            _fwd_gemm(cond16, "bkv_all", _kv_all_weights(kvparams, L), kvbuf, bias=torch.cat([kvparams[4 * li + j].detach() for li in range(L) for j in (1, 3)]))
+            kv = kvbuf.view(sets * n * E, L, 2 * D).permute(1, 0, 2)
+        else:
+            kv = _empty((L, sets * n * E, 2 * D), dt, dev)
+            for li in range(L):
+                wk, bk, wv, bv = kvparams[4 * li: 4 * li + 4]
+                _fwd_gemm(cond16, "bkv", [wk, wv], kv[li], bias=torch.cat((bk.detach(), bv.detach())))
         ctx.spec, ctx.kvparams, ctx.cond16, ctx.shape, ctx.sets = spec, kvparams, cond16, (n, E, D), sets
         ctx.needs = (cond_own.requires_grad, cond_neg is not None and cond_neg.requires_grad)
         if sets == 2:
@@ -1503,6 +1530,31 @@ class CrossKVFn(torch.autograd.Function):
         parts = [(dkv_own, cond16[:n * E])]
         if ctx.sets == 2:
             parts.append((dkv_neg, cond16[n * E:]))
+        L = spec.L
+        if ctx.interleaved and all(d is None or _kv_rows_view(d, L, D) is not None for d, _ in parts):
+            # the gradients arrived in the forward's layout ([rows][layer][dK | dV], BertFn writes them so and autograd's sums keep it): all layers
+            # at once - dW [L * 2 D, D] in one launch per set, the condition-token gradient as ONE product over K = L * 2 D
+            wall = _fused_w("bkv_all", _kv_all_weights(kvparams, L))
+            dw = torch.zeros((L * 2 * D, D), dtype=torch.float32, device=dev)
+            db = torch.zeros(L * 2 * D, dtype=torch.float32, device=dev)
+            dconds = [None, None]
+            for pi, (dkv, c16) in enumerate(parts):
+                if dkv is None:
+                    continue
+                d2 = _kv_rows_view(dkv, L, D)
+                # (the weight-gradient kernels address a reduction-major operand with 32-bit byte offsets from its first row: row chunks of < 4 GiB)
+                rmax = max(64, (0xF0000000 // (L * 2 * D * d2.element_size())) // 64 * 64)
+                for r0 in range(0, n * E, rmax):
+                    linear_wgrad(d2[r0:r0 + rmax], c16[r0:r0 + rmax], dw, inv_s, dbias=db)
+                if ctx.needs[pi]:
+                    dconds[pi] = _empty((n * E, D), torch.float32, dev)
+                    ops.gemm(d2, wall, dconds[pi], tb=True, M=n * E, N=D, K=L * 2 * D, alpha=inv_s)
+            grads = []
+            for li in range(L):
+                r0 = li * 2 * D
+                grads += [dw[r0:r0 + D], db[r0:r0 + D], dw[r0 + D:r0 + 2 * D], db[r0 + D:r0 + 2 * D]]
+            dc = [d.view(n, E, D) if d is not None else None for d in dconds]
+            return (None, dc[0], dc[1]) + tuple(grads)
         dconds = [torch.zeros((n * E, D), dtype=torch.float32, device=dev) if (need and d is not None) else None
                   for need, (d, _) in zip(ctx.needs, parts)] + [None] * (2 - len(parts))
         grads = []
@@ -1562,7 +1614,8 @@ class BertFn(torch.autograd.Function):
             n_own = b if kv_neg is None else b // 3
             E = kv_own.shape[1] // n_own
             if kv_neg is not None:   # the triplet reads one [own | neg] buffer modulo 2 n: the two views must be adjacent per layer
-                assert b == 3 * n_own and kv_neg.data_ptr() == kv_own.data_ptr() + n_own * E * 2 * D * kv_own.element_size()
+                assert b == 3 * n_own and kv_neg.stride() == kv_own.stride() and \
+                    kv_neg.data_ptr() == kv_own.data_ptr() + n_own * E * kv_own.stride(1) * kv_own.element_size()
                 kv_mod = 2 * n_own
         if cond is not None:
             E = cond.shape[1]
@@ -1615,7 +1668,8 @@ class BertFn(torch.autograd.Function):
                         kv_cache[li] = kv
                 cc = _empty((rows, D), dt, dev)
                 lse_c = _empty((b, H, S), torch.float32, dev)
-                stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
+                krs = kv.stride(0)       # 2 D, or L * 2 D for a layer of the interleaved shared memory (CrossKVFn)
+                stc = dict(q_strides=(S * D, D), k_strides=(E * krs, krs), v_strides=(E * krs, krs), o_strides=(S * D, D))
                 ops.attn_fwd(q, kv, kv[:, D:], cc, lse_c, B=b, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None,
                              drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod, **stc)
                 u2 = _empty((rows, D), torch.float32, dev)
@@ -1639,6 +1693,7 @@ class BertFn(torch.autograd.Function):
         ctx.drop = drop
         ctx.cond_needs_grad = cond is not None and cond.requires_grad
         ctx.kv_shared = (kv_own is not None, kv_neg is not None, kv_mod)
+        ctx.kv_row_stride = kv_own.stride(1) if kv_own is not None else 2 * D
         return x32.view(b, S, D)
 
     @staticmethod
@@ -1679,12 +1734,13 @@ class BertFn(torch.autograd.Function):
         # gradients of the shared K/V memory, still in the 16-bit gradient scale (CrossKVFn.backward removes it)
         # (ITM triplet: [own | neg] adjacent per layer - batch entries 0 .. 2 n of the backward write their dK / dV rows straight into the pair, the
         # third third accumulates onto the own half in a second launch: no per-entry buffer, no add / copy passes)
+        kv_il = shared and ctx.kv_row_stride != 2 * D      # the memory is interleaved over the layers: so are its gradients
         if has_neg:
-            dkv_pair = _empty((spec.L, 2 * n_own * E, 2 * D), dt, dev)
+            dkv_pair = _kv_grad_buffer(spec.L, 2 * n_own * E, D, dt, dev, kv_il)
             dkv_own, dkv_neg = dkv_pair[:, :n_own * E], dkv_pair[:, n_own * E:]
         else:
             dkv_pair = None
-            dkv_own = _empty((spec.L, n_own * E, 2 * D), dt, dev) if shared else None
+            dkv_own = _kv_grad_buffer(spec.L, n_own * E, D, dt, dev, kv_il) if shared else None
             dkv_neg = None
 
         def ln_bwd(gin, u, m_, r_, pre, site):
@@ -1718,8 +1774,16 @@ class BertFn(torch.autograd.Function):
                 ops.gemm(d16, _fused_w("w1", [P(p + "crossattention.output.dense.weight")]), dcc, tb=True, M=rows, N=D, K=D)
                 dq = _empty((rows, D), dt, dev)
                 delta = _empty((b, H, S), torch.float32, dev)
-                stc = dict(q_strides=(S * D, D), k_strides=(E * 2 * D, 2 * D), v_strides=(E * 2 * D, 2 * D), o_strides=(S * D, D))
                 kv = a["kv"]
+                two_launch = shared and has_neg and ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(li * 8 + SITE_CROSS_P), batch0=2 * n_own)
+                if shared and has_neg and not two_launch and kv.stride(0) != 2 * D:
+                    # one-launch triplet backward into a per-entry [3 n E, 2 D] buffer: dK / dV use the K / V strides, so this (rare) path reads a
+                    # row-major copy of the layer's [own | neg] sets
+                    kv = torch.as_strided(kv, (2 * n_own * E, 2 * D), (kv.stride(0), 1)).contiguous()
+                krs = kv.stride(0)
+                stc = dict(q_strides=(S * D, D), k_strides=(E * krs, krs), v_strides=(E * krs, krs), o_strides=(S * D, D))
+                if two_launch:
+                    assert dkv_pair[li].stride(0) == krs
                 if shared and has_neg and ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(li * 8 + SITE_CROSS_P), batch0=2 * n_own):
                     # two launches over the triplet: entries [0, 2 n) own exactly the [own | neg] K/V sets, entries [2 n, 3 n) read the own sets again
                     # and ADD their dK / dV (mico_attn_params.batch0 keeps the dropout counters of the one-launch forward)

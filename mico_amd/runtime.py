@@ -32,6 +32,10 @@ class _Cfg:
     # activation diet level 3: qkv / fc1 weight gradients taken against the kept fp16 NORMALISED rows, the LayerNorm's gamma / beta applied to the
     # [out, in] result (ops.dw_colfold) instead of re-creating the LayerNorm output over all rows first (functional._tower_backward)
     ln_fold_wgrad = os.environ.get("MICO_LN_NOFOLD") is None
+    # shared cross-attention K/V memory (functional.CrossKVFn) laid out [rows][layer][K | V] instead of [layer][rows][K | V]: the 12 layers' projections
+    # are ONE GEMM (N = 12 x 2 D), and in the backward the condition-token gradient one K = 12 x 2 D product (no fp32 read-modify-write of the
+    # [rows, D] gradient per layer) and the weight gradients one launch; the attention kernels read a layer through its row stride
+    kv_interleaved = os.environ.get("MICO_KV_LAYER_MAJOR") is None
     head_split_blocks = 0     # plain fp16 only: the first n tower blocks in a split mode (see enter_block)
     head_split_mode = "weights"
     # BASELINE.json configs[4] ("fp8 MFMA"): the ViT towers' and BERT's forward and input-gradient GEMMs run on the block-scaled fp8 MFMA
