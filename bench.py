@@ -65,6 +65,15 @@ PRECISIONS = {   # --dtype -> (torch dtype, split_fp16, split_mode, description)
 HEAD_SPLIT_BLOCKS = 4
 
 
+def release_memory():
+    """Between the measurements of one process: drop what the previous one left (autograd graphs are reference cycles: the collector first, then the
+    caching allocator's blocks), so that the next measurement's tower plan (functional.tower_plan prices the FREE device memory) sees what a
+    process of its own would see - the parity_config step of round 5's first collection ran 23 % slower in-process than stand-alone."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -641,14 +650,14 @@ def main():
     if extras:
         # ---- the timed precision against the reference goldens, measured here and now ----
         del batch
-        torch.cuda.empty_cache()
+        release_memory()
         res["parity"] = dict(precision=PRECISIONS[args.dtype][3], **measure_parity(model, dev))
     if extras and world == 1:
         # ---- the other ViT-g/14 configuration of BASELINE.json, timed as a first-class object next to the headline: configs[2] (image +
         # audio + text, 5 frames per sample: the headline of rounds 1-3) when the headline is the omni share, and vice versa
         other = "img_aud_txt" if args.workload == "omni" else "omni"
         try:
-            torch.cuda.empty_cache()
+            release_memory()
             sec, sbatch = measure(other, WORKLOADS[other]["task"], b, max(10, args.steps // 2), 2, seed=4321)
             r2 = sec.get("roofline")
             if r2 is not None:
@@ -663,7 +672,7 @@ def main():
         # ---- BASELINE configs[1] (ViT-B/16 image + text contrastive step, b = 256): its own model, timed with its own GEMM roofline ----
         if args.workload != "b16_img_txt":
             try:
-                torch.cuda.empty_cache()
+                release_memory()
                 wb = WORKLOADS["b16_img_txt"]
                 mb = MiCo(default_cfg(wb["vision"]))
                 mb.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in mb.state_dict().items()}, seed=0), strict=False)
@@ -684,7 +693,7 @@ def main():
         # evaluated, dropped ones multiplied by 0) - identical values and gradients, more work, its own tower plan ----
         if not args.eval_mode and not args.dense_droppath:
             try:
-                torch.cuda.empty_cache()
+                release_memory()
                 DropPlan.skip_dropped = False
                 kd = max(3, args.steps // 5)
                 dm, db_ = measure(args.workload, args.task, b, kd, 1, seed=1234)
@@ -699,7 +708,7 @@ def main():
             finally:
                 DropPlan.skip_dropped = True
         # ---- the same (headline) step in the configuration with margin under the 1e-3 gate, timed next to it ----
-        torch.cuda.empty_cache()
+        release_memory()
         pc = "fp16-split-w" if args.dtype != "fp16-split-w" else "fp16"
         names = [pc] + ([oc for oc in ("fp16-plain", "fp8") if oc != args.dtype] if args.all_precisions else [])
         k2 = max(3, args.steps // 5)
@@ -710,7 +719,7 @@ def main():
                 m, pb = measure(args.workload, args.task, b, k2, 1, seed=1234)
                 del pb
                 entry = dict(precision=PRECISIONS[oc][3], value=m["value"], unit="samples/s", steps=k2, warmup=1, ms_per_step=m["ms_per_step"],
-                             peak_mem_gb=m["peak_mem_gb"], parity=measure_parity(model, dev))
+                             peak_mem_gb=m["peak_mem_gb"], tower_plan=m.get("tower_plan"), parity=measure_parity(model, dev))
                 if oc == "fp8":
                     entry["parity_note"] = ("the golden inputs (1-8 frames) are below the size at which GEMMs route to the fp8 kernel (>= 128 "
                                             "tiles of 256x256): this parity is the bf16 path's; the fp8 tolerance is measured by "

@@ -477,6 +477,13 @@ __device__ __forceinline__ void res_tile_step(LDS_AS const char* ktile, LDS_AS c
     }
 }
 
+// EXPERIMENT (round 5, off): the last key of Sk = 64 k + 1 as the initial state of the running softmax instead of a fifth key step (see `r1` in
+// attn_fwd_res_kernel).  Measured (tools/attn_bench.py, 320 frames x 16 heads x 257 x hd 88): forward 0.386 -> 0.362 ms (-6 %; ~0.13 % of the omni
+// step), all attention tests green - but the un-rounded last probability moves the max-norm statistic of the timed precision over 8 images
+// (tests/test_precision_stats_gpu.py) from 9.2e-4 / 9.8e-4 to 1.03e-3 / 1.12e-3 (tokens / feat_v): the gate's margin is worth more than 2 ms.
+#ifndef MICO_ATTN_R1
+#define MICO_ATTN_R1 0
+#endif
 template <int HDP> struct ResCfg {
     static constexpr int NXMAX = HDP <= 96 ? 4 : 3;    // query rows beyond 256 (their partials live in the LDS left over by K/V)
     static constexpr int PST = HDP + 2;                // floats per partial row: O[HDP], max, sum
@@ -523,7 +530,12 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
     const int nst = (p.Sk + 15) >> 4;
     constexpr bool WIDE = HDP <= 64;   // the 80-key step needs 24 more registers than hd 96 / 128 leave next to the prefetch
     const bool wide_last = WIDE && nst > 4 && (nst & 3) == 1;
-    const int nsteps = wide_last ? (nst >> 2) : ((nst + 3) >> 2);
+    // Sk = 64 k + 1 (the towers' 257 tokens) without the 80-key step: the LAST key is not a fifth step over one live sub-tile column (a 16-key
+    // MFMA pass, a softmax round and a rescale of the output tiles for ONE key) but the INITIAL state of the running softmax - m = s(q, k_last),
+    // l = 1, O = v_last - computed with a dot product per query row (MICO_ATTN_R1=0: the fifth step, for A/B runs)
+    const bool r1 = MICO_ATTN_R1 && !WIDE && p.Sk > 64 && (p.Sk & 63) == 1;
+    const int nstm = r1 ? nst - 1 : nst;      // 16-key sub-tiles of the main pass
+    const int nsteps = wide_last ? (nst >> 2) : ((nstm + 3) >> 2);
     // the 17th query block: this wave's key sub-tiles [4*xt + xlo, 4*xt + xhi)
     const int nx = p.Sq - 256;
     const int xt = wave >> 1, xlo = (wave & 1) * 2;
@@ -674,6 +686,34 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
             oacc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             oacc[1][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if (r1 && main_live) {
+            LDS_AS const char* krow = kt + (p.Sk - 1) * C::RS;      // (row & 7 == 0: chunk c of the row sits in chunk slot c)
+            LDS_AS const char* vrow = vt + (p.Sk - 1) * C::RS;
+            float dot[2] = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                float k8[8];
+                unpack8<T>(*(LDS_AS const s16x8*)(krow + ((ks * 4 + g) << 4)), k8);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    float q8[8];
+                    unpack8<T>(qf[rb][ks], q8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dot[rb] = __builtin_fmaf(q8[e], k8[e], dot[rb]);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                m_run[rb] = group_sum(dot[rb]) * sc2;
+                l_run[rb] = 1.f;
+            }
+#pragma unroll
+            for (int td = 0; td < C::TD; ++td) {      // this lane's head dims of output tile td: td * 16 + g * 4 .. + 3
+                const f32x4 v4 = unpack4<T>(*(LDS_AS const s16x4*)(vrow + ((td * 2 + (g >> 1)) << 4) + (g & 1) * 8));
+                oacc[0][td] = v4;
+                oacc[1][td] = v4;
+            }
+        }
         // The step loop is unrolled by hand (at most 5 steps) with the prefetch parts as unconditional straight-line code in between:
         // loads issued under control flow come back through copies at the loop back-edge, i.e. behind an s_waitcnt vmcnt(0).
         auto key_step = [&](int t) {
@@ -683,7 +723,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_res_kernel(const T* __restric
             if (WIDE && t == nsteps - 1 && wide_last) {
                 res_tile_step<T, HDP, 2, 5, true>(ktile, vtile, t * 64, 0, 5, (p.Sk & 15) ? 1 : 0, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
             } else {
-                const int ntn = min(4, nst - 4 * t);
+                const int ntn = min(4, nstm - 4 * t);
                 if (ntn == 4) res_tile_step<T, HDP, 2, 4, true>(ktile, vtile, t * 64, 0, 4, t * 64 + 64 <= p.Sk ? 0 : 1, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
                 else res_tile_step<T, HDP, 2, 4, false>(ktile, vtile, t * 64, 0, ntn, 2, qf, oacc, m_run, l_run, p.Sk, sc2, lane, rf, tf);
             }

@@ -1467,28 +1467,24 @@ def _kv_all_weights(kvparams, L):
     return [kvparams[4 * li + j] for li in range(L) for j in (0, 2)]
 
 
-def _kv_rows_view(t, L, D):
-    """t: [L][rows][2 D] tensor that is a permuted view of a [rows][L * 2 D] row-major buffer -> that 2-D buffer (no copy), else None."""
-    if t.dim() != 3 or t.shape[0] != L or t.shape[2] != 2 * D or t.stride() != (2 * D, L * 2 * D, 1):
-        return None
-    return torch.as_strided(t, (t.shape[1], L * 2 * D), (L * 2 * D, 1))
-
-
-def _kv_grad_buffer(L, rows, D, dt, dev, interleaved):
-    """[L][rows][2 D] gradient buffer of the shared K/V memory in the memory's own layout."""
-    if interleaved:
-        return _empty((rows, L * 2 * D), dt, dev).view(rows, L, 2 * D).permute(1, 0, 2)
-    return _empty((L, rows, 2 * D), dt, dev)
+def _kv_layers(t2d, L, D):
+    """[rows, L * 2 D] row-major shared K/V memory (or its gradient) -> its per-layer view [L][rows][2 D] (row stride L * 2 D)."""
+    return t2d.view(t2d.shape[0], L, 2 * D).permute(1, 0, 2)
 
 
 class CrossKVFn(torch.autograd.Function):
     """Cross-attention K/V projections of the condition tokens for ALL layers, computed once per step and shared by every BERT pass
     that attends to the same tokens with the same weights: the ITM triplet [own | hard negative | own] (vast.py:438-447) contains
     the batch's own condition tokens twice and the captioning pass (vast.py:486-512) a third time - the reference projects them in
-    every pass (bert.py:206-215).  Returns (kv_own, kv_neg): per-layer [L][n E, 2 D] 16-bit views of ONE buffer laid out
-    [L][own | neg], so that a BERT pass over the triplet reads it through mico_attn_params.kv_batch_mod.
+    every pass (bert.py:206-215).  Returns (kv_own, kv_neg): 16-bit views of ONE buffer whose rows are [own | neg], so that a BERT pass over the
+    triplet reads it through mico_attn_params.kv_batch_mod.  Memory layout (runtime.CFG.kv_interleaved, default): [rows][L][K | V], handed out as
+    2-D [n E, L * 2 D] tensors - a layer is a column block with row stride L * 2 D, every layer's projection one GEMM, and the backward one product
+    over K = L * 2 D for the condition-token gradient; or [L][rows][K | V] (3-D [L][n E, 2 D] views) with a launch per layer (fp32 accumulation
+    into the token gradient 12 times).
     The gradients handed back by BertFn for these two outputs stay in the engine's 16-bit gradient scale (runtime.grad_scale());
     this function removes it - the one place where a scaled gradient crosses autograd, between two of our own functions."""
+
+    concat_backwards = 0      # backward passes that took the all-layers-at-once path of the interleaved layout (tests)
 
     @staticmethod
     def forward(ctx, spec, cond_own, cond_neg, *kvparams):
@@ -1508,7 +1504,7 @@ class CrossKVFn(torch.autograd.Function):
             # [rows][layer][K | V]: every layer's projection in one launch (N = L * 2 D); a layer is the view kv[li] with row stride L * 2 D
             kvbuf = _empty((sets * n * E, L * 2 * D), dt, dev)
             _fwd_gemm(cond16, "bkv_all", _kv_all_weights(kvparams, L), kvbuf, bias=torch.cat([kvparams[4 * li + j].detach() for li in range(L) for j in (1, 3)]))
-            kv = kvbuf.view(sets * n * E, L, 2 * D).permute(1, 0, 2)
+            kv = None
         else:
             kv = _empty((L, sets * n * E, 2 * D), dt, dev)
             for li in range(L):
@@ -1516,6 +1512,8 @@ class CrossKVFn(torch.autograd.Function):
                 _fwd_gemm(cond16, "bkv", [wk, wv], kv[li], bias=torch.cat((bk.detach(), bv.detach())))
         ctx.spec, ctx.kvparams, ctx.cond16, ctx.shape, ctx.sets = spec, kvparams, cond16, (n, E, D), sets
         ctx.needs = (cond_own.requires_grad, cond_neg is not None and cond_neg.requires_grad)
+        if ctx.interleaved:      # 2-D [rows, L * 2 D]: contiguous row blocks (so are their gradients: autograd's sums over the passes stay on its fast path)
+            return (kvbuf[:n * E], kvbuf[n * E:]) if sets == 2 else (kvbuf, None)
         if sets == 2:
             return kv[:, :n * E], kv[:, n * E:]
         return kv, None
@@ -1531,9 +1529,10 @@ class CrossKVFn(torch.autograd.Function):
         if ctx.sets == 2:
             parts.append((dkv_neg, cond16[n * E:]))
         L = spec.L
-        if ctx.interleaved and all(d is None or _kv_rows_view(d, L, D) is not None for d, _ in parts):
+        if ctx.interleaved:
             # the gradients arrived in the forward's layout ([rows][layer][dK | dV], BertFn writes them so and autograd's sums keep it): all layers
             # at once - dW [L * 2 D, D] in one launch per set, the condition-token gradient as ONE product over K = L * 2 D
+            CrossKVFn.concat_backwards += 1
             wall = _fused_w("bkv_all", _kv_all_weights(kvparams, L))
             dw = torch.zeros((L * 2 * D, D), dtype=torch.float32, device=dev)
             db = torch.zeros(L * 2 * D, dtype=torch.float32, device=dev)
@@ -1541,7 +1540,7 @@ class CrossKVFn(torch.autograd.Function):
             for pi, (dkv, c16) in enumerate(parts):
                 if dkv is None:
                     continue
-                d2 = _kv_rows_view(dkv, L, D)
+                d2 = dkv if (dkv.stride(1) == 1 and dkv.stride(0) % 8 == 0) else dkv.contiguous()      # [n E, L * 2 D]
                 # (the weight-gradient kernels address a reduction-major operand with 32-bit byte offsets from its first row: row chunks of < 4 GiB)
                 rmax = max(64, (0xF0000000 // (L * 2 * D * d2.element_size())) // 64 * 64)
                 for r0 in range(0, n * E, rmax):
@@ -1612,8 +1611,15 @@ class BertFn(torch.autograd.Function):
         if kv_own is not None:
             assert cond is None and kv_cache is None
             n_own = b if kv_neg is None else b // 3
+            kv_2d = kv_own.dim() == 2        # the interleaved memory: [n E, L * 2 D] row-major (CrossKVFn), read per layer through its row stride
+            if kv_2d:
+                assert kv_own.is_contiguous() and kv_own.shape[1] == spec.L * 2 * D
+                kv_own = _kv_layers(kv_own, spec.L, D)
             E = kv_own.shape[1] // n_own
             if kv_neg is not None:   # the triplet reads one [own | neg] buffer modulo 2 n: the two views must be adjacent per layer
+                if kv_2d:
+                    assert kv_neg.dim() == 2 and kv_neg.is_contiguous()
+                    kv_neg = _kv_layers(kv_neg, spec.L, D)
                 assert b == 3 * n_own and kv_neg.stride() == kv_own.stride() and \
                     kv_neg.data_ptr() == kv_own.data_ptr() + n_own * E * kv_own.stride(1) * kv_own.element_size()
                 kv_mod = 2 * n_own
@@ -1693,7 +1699,7 @@ class BertFn(torch.autograd.Function):
         ctx.drop = drop
         ctx.cond_needs_grad = cond is not None and cond.requires_grad
         ctx.kv_shared = (kv_own is not None, kv_neg is not None, kv_mod)
-        ctx.kv_row_stride = kv_own.stride(1) if kv_own is not None else 2 * D
+        ctx.kv_2d = kv_own is not None and kv_2d
         return x32.view(b, S, D)
 
     @staticmethod
@@ -1734,14 +1740,23 @@ class BertFn(torch.autograd.Function):
         # gradients of the shared K/V memory, still in the 16-bit gradient scale (CrossKVFn.backward removes it)
         # (ITM triplet: [own | neg] adjacent per layer - batch entries 0 .. 2 n of the backward write their dK / dV rows straight into the pair, the
         # third third accumulates onto the own half in a second launch: no per-entry buffer, no add / copy passes)
-        kv_il = shared and ctx.kv_row_stride != 2 * D      # the memory is interleaved over the layers: so are its gradients
+        kv_il = shared and ctx.kv_2d      # the memory is interleaved over the layers (a 2-D tensor to autograd): so are its gradients
+        dkv2d = None        # interleaved: the 2-D [rows, L * 2 D] buffer behind the per-layer views - what autograd gets back
         if has_neg:
-            dkv_pair = _kv_grad_buffer(spec.L, 2 * n_own * E, D, dt, dev, kv_il)
+            if kv_il:
+                dkv2d = _empty((2 * n_own * E, spec.L * 2 * D), dt, dev)
+                dkv_pair = _kv_layers(dkv2d, spec.L, D)
+            else:
+                dkv_pair = _empty((spec.L, 2 * n_own * E, 2 * D), dt, dev)
             dkv_own, dkv_neg = dkv_pair[:, :n_own * E], dkv_pair[:, n_own * E:]
         else:
             dkv_pair = None
-            dkv_own = _kv_grad_buffer(spec.L, n_own * E, D, dt, dev, kv_il) if shared else None
             dkv_neg = None
+            if shared and kv_il:
+                dkv2d = _empty((n_own * E, spec.L * 2 * D), dt, dev)
+                dkv_own = _kv_layers(dkv2d, spec.L, D)
+            else:
+                dkv_own = _empty((spec.L, n_own * E, 2 * D), dt, dev) if shared else None
 
         def ln_bwd(gin, u, m_, r_, pre, site):
             """d(LN input) fp32 (in place into gin: the residual branch's gradient) and its scaled 16-bit copy for the dense
@@ -1842,6 +1857,8 @@ class BertFn(torch.autograd.Function):
         ops.embed_scatter_add(ids, g, G("embeddings.word_embeddings.weight"), G("embeddings.position_embeddings.weight"), dtype0, S)
         G("embeddings.token_type_embeddings.weight")[0].add_(dtype0)
         dc = dcond.view(b, E, D) if (dcond is not None and ctx.cond_needs_grad) else None
+        if dkv2d is not None:      # contiguous row blocks [own | neg] of the one buffer
+            dkv_own, dkv_neg = (dkv2d[:n_own * E], dkv2d[n_own * E:]) if has_neg else (dkv2d, None)
         return (None, None, None, dc, None, dkv_own, dkv_neg) + grads.result()
 
 

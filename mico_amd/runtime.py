@@ -305,8 +305,9 @@ def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False, ln_fe
     """16-bit GEMM weight for nn.Linear-style parameters (rows of all `plist` entries concatenated).
     Returns (w16, ksegs): w16 is the [N(_pad), Kp] operand (a strided view of the [N, 2 Kp] hi|lo buffer in split-precision
     mode), ksegs the k-segment descriptor for *forward* launches (None in plain mode).
-    ln_fed: the GEMM's input is a LayerNorm output (qkv, fc1) - the split mode "weights-ln" splits only those weights."""
-    split = split_precision() and (ln_fed or CFG.split_mode != "weights-ln")
+    ln_fed: the GEMM's input is a LayerNorm output (qkv, fc1) - the split mode "weights-ln" splits only those weights, "weights-res" only the
+    others (the projections that write the residual stream: attn.proj, fc2)."""
+    split = split_precision() and (CFG.split_mode != "weights-res" if ln_fed else CFG.split_mode != "weights-ln")
 
     def build(dt):
         w = plist[0].detach() if len(plist) == 1 else torch.cat([p.detach() for p in plist], 0)

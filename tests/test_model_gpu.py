@@ -308,34 +308,42 @@ def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
     r = fx["W1"]
     b = fx["meta"]["b"]
     batch0 = to_dev(synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234), cuda)
-    res = {}
-    for share in (False, True):
+    from mico_amd import functional as Fn
+    res, concat = {}, {}
+    # per-pass projection; the shared memory interleaved over the layers (default: one projection GEMM, one K = L * 2 D product for the token
+    # gradient); the shared memory layer-major (a launch per layer)
+    for share, interleaved in ((False, True), (True, True), (True, False)):
         batch = dict(batch0)
         batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
         batch["_injected"]["cap"] = r["inj"]["cap"]
-        old = runtime.CFG.share_cross_kv
-        runtime.CFG.share_cross_kv = share
+        old = runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved
+        runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved = share, interleaved
+        c0 = Fn.CrossKVFn.concat_backwards
         try:
             with runtime.precision(torch.float16):
                 m.zero_grad(set_to_none=True)
                 out = m(batch, fx["meta"]["task"], compute_loss=True)
                 sum(out.values()).backward()
         finally:
-            runtime.CFG.share_cross_kv = old
-        res[share] = ({k: v.item() for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-    for k in res[False][0]:
-        assert abs(res[True][0][k] - res[False][0][k]) <= 2e-4 * max(1.0, abs(res[False][0][k])), k
-    assert set(res[True][1]) == set(res[False][1])
-    worst = ("", 0.0)
-    for n, g0 in res[False][1].items():
-        if n.endswith("self.key.bias"):   # analytically zero (a constant added to every score of a softmax row): rounding noise only
-            continue
-        e = rel_err(res[True][1][n], g0) if g0.abs().max() > 0 else float(res[True][1][n].abs().max())
-        if e > worst[1]:
-            worst = (n, e)
-    print(tag, "shared vs per-pass K/V: worst gradient difference", worst)
-    assert worst[1] < 5e-3, worst
-    assert any("crossattention.self.key.weight" in n for n in res[True][1])
+            runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved = old
+        concat[(share, interleaved)] = Fn.CrossKVFn.concat_backwards - c0
+        res[(share, interleaved)] = ({k: v.item() for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert concat[(True, True)] > 0 and concat[(True, False)] == 0 and concat[(False, True)] == 0, concat
+    ref_l, ref_g = res[(False, True)]
+    for key in ((True, True), (True, False)):
+        for k in ref_l:
+            assert abs(res[key][0][k] - ref_l[k]) <= 2e-4 * max(1.0, abs(ref_l[k])), (key, k)
+        assert set(res[key][1]) == set(ref_g)
+        worst = ("", 0.0)
+        for n, g0 in ref_g.items():
+            if n.endswith("self.key.bias"):   # analytically zero (a constant added to every score of a softmax row): rounding noise only
+                continue
+            e = rel_err(res[key][1][n], g0) if g0.abs().max() > 0 else float(res[key][1][n].abs().max())
+            if e > worst[1]:
+                worst = (n, e)
+        print(tag, "shared", "interleaved" if key[1] else "layer-major", "vs per-pass K/V: worst gradient difference", worst)
+        assert worst[1] < 5e-3, (key, worst)
+        assert any("crossattention.self.key.weight" in n for n in res[key][1])
 
 
 def test_cap_subtask_without_retrieval_twin_keeps_cross_kv_gradients(setup, cuda):
