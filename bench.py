@@ -719,7 +719,8 @@ def main():
                 m, pb = measure(args.workload, args.task, b, k2, 1, seed=1234)
                 del pb
                 entry = dict(precision=PRECISIONS[oc][3], value=m["value"], unit="samples/s", steps=k2, warmup=1, ms_per_step=m["ms_per_step"],
-                             peak_mem_gb=m["peak_mem_gb"], tower_plan=m.get("tower_plan"), parity=measure_parity(model, dev))
+                             peak_mem_gb=m["peak_mem_gb"], peak_reserved_gb=m.get("peak_reserved_gb"), allocator=m.get("allocator"), tower_plan=m.get("tower_plan"),
+                             parity=measure_parity(model, dev))
                 if oc == "fp8":
                     entry["parity_note"] = ("the golden inputs (1-8 frames) are below the size at which GEMMs route to the fp8 kernel (>= 128 "
                                             "tiles of 256x256): this parity is the bf16 path's; the fp8 tolerance is measured by "
