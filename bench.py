@@ -542,7 +542,12 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
             D.force_dist(True)
+            # the reducer's buckets (one fp32 copy of the gradients) change the tower plan: start from an empty allocator cache and give the new plan two
+            # untimed steps, as a rank of an N > 1 job gets from its warm-up (with the headline's cached blocks in place the first steps of the new
+            # plan free and re-request device memory: 1742 ms per step measured that way against 1512)
+            release_memory()
             state["reducer"] = GradBucketReducer(model.parameters())
+            step(batch, args.task)
             step(batch, args.task)
             finish_ms.clear()
             torch.cuda.synchronize()
@@ -713,14 +718,21 @@ def main():
         names = [pc] + ([oc for oc in ("fp16-plain", "fp8") if oc != args.dtype] if args.all_precisions else [])
         k2 = max(3, args.steps // 5)
         others = {}
+        from mico_amd import functional as _Fn
+        soft0 = _Fn._SOFT_FRAC
         for oc in names:
             try:
                 set_precision(oc)
+                release_memory()
+                # a process that has already run five other measurements (and RCCL) carries their allocator history: the weights-split step planned
+                # at the headline's soft budget reserved 277 GiB of the 288 here and paid for it in allocator retries (1 retry, 16 device mallocs,
+                # 126 frees inside 3 timed steps: 2209 ms per step against 1792 in a process of its own) - these extras plan 0.04 lower
+                _Fn._SOFT_FRAC = soft0 - 0.04
                 m, pb = measure(args.workload, args.task, b, k2, 1, seed=1234)
                 del pb
                 entry = dict(precision=PRECISIONS[oc][3], value=m["value"], unit="samples/s", steps=k2, warmup=1, ms_per_step=m["ms_per_step"],
                              peak_mem_gb=m["peak_mem_gb"], peak_reserved_gb=m.get("peak_reserved_gb"), allocator=m.get("allocator"), tower_plan=m.get("tower_plan"),
-                             parity=measure_parity(model, dev))
+                             hbm_soft_frac=_Fn._SOFT_FRAC, parity=measure_parity(model, dev))
                 if oc == "fp8":
                     entry["parity_note"] = ("the golden inputs (1-8 frames) are below the size at which GEMMs route to the fp8 kernel (>= 128 "
                                             "tiles of 256x256): this parity is the bf16 path's; the fp8 tolerance is measured by "
@@ -728,6 +740,8 @@ def main():
                 others[oc] = entry
             except Exception as e:
                 others[oc] = {"error": repr(e)}
+            finally:
+                _Fn._SOFT_FRAC = soft0
         set_precision(args.dtype)
         res["parity_config"] = others.pop(pc)
         if others:
