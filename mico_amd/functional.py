@@ -1472,6 +1472,24 @@ def _kv_layers(t2d, L, D):
     return t2d.view(t2d.shape[0], L, 2 * D).permute(1, 0, 2)
 
 
+class DkvSession:
+    """One per shared cross-attention K/V memory (BertModel.project_cross_kv attaches it to kv_own): the BERT passes of a step that read the same
+    own set - the ITM triplet and the captioning pass - put its 16-bit gradient into ONE [n E, L * 2 D] buffer.  The first BertFn.backward of
+    a backward pass writes the buffer, registers it here and hands it to autograd; the later ones add to it inside the short-query attention
+    backward (mico_attn_params.dkv_accumulate) and return None for kv_own, so the engine holds exactly one gradient for CrossKVFn's output and
+    never sums two 7 GB tensors out of place at the step's memory peak.  CrossKVFn.backward ends the session.
+    closed: a pass could not take part (no short-query kernel for its shape) and returned a buffer of its own - the engine's sum replaces the
+    registered buffer, so nothing may be added to it any more in this backward pass."""
+    __slots__ = ("own", "closed")
+    accumulated = 0      # BertFn backward passes that added to another pass's buffer (tests)
+
+    def __init__(self):
+        self.own, self.closed = None, False
+
+    def reset(self):
+        self.own, self.closed = None, False
+
+
 class CrossKVFn(torch.autograd.Function):
     """Cross-attention K/V projections of the condition tokens for ALL layers, computed once per step and shared by every BERT pass
     that attends to the same tokens with the same weights: the ITM triplet [own | hard negative | own] (vast.py:438-447) contains
@@ -1487,8 +1505,9 @@ class CrossKVFn(torch.autograd.Function):
     concat_backwards = 0      # backward passes that took the all-layers-at-once path of the interleaved layout (tests)
 
     @staticmethod
-    def forward(ctx, spec, cond_own, cond_neg, *kvparams):
+    def forward(ctx, spec, session, cond_own, cond_neg, *kvparams):
         runtime.remember_precision(ctx)
+        ctx.session = session      # DkvSession or None: ended by the backward
         # kvparams: per layer key.weight, key.bias, value.weight, value.bias
         dt = runtime.compute_dtype()
         dev = cond_own.device
@@ -1525,6 +1544,8 @@ class CrossKVFn(torch.autograd.Function):
         n, E, D = ctx.shape
         dev = cond16.device
         inv_s = 1.0 / runtime.grad_scale()
+        if ctx.session is not None:
+            ctx.session.reset()
         parts = [(dkv_own, cond16[:n * E])]
         if ctx.sets == 2:
             parts.append((dkv_neg, cond16[n * E:]))
@@ -1553,7 +1574,7 @@ class CrossKVFn(torch.autograd.Function):
                 r0 = li * 2 * D
                 grads += [dw[r0:r0 + D], db[r0:r0 + D], dw[r0 + D:r0 + 2 * D], db[r0 + D:r0 + 2 * D]]
             dc = [d.view(n, E, D) if d is not None else None for d in dconds]
-            return (None, dc[0], dc[1]) + tuple(grads)
+            return (None, None, dc[0], dc[1]) + tuple(grads)
         dconds = [torch.zeros((n * E, D), dtype=torch.float32, device=dev) if (need and d is not None) else None
                   for need, (d, _) in zip(ctx.needs, parts)] + [None] * (2 - len(parts))
         grads = []
@@ -1571,7 +1592,7 @@ class CrossKVFn(torch.autograd.Function):
                     ops.gemm(d, _fused_w("bkv", [wk, wv]), dconds[pi], tb=True, M=n * E, N=D, K=2 * D, alpha=inv_s, accumulate=True)
             grads += [dw[:D], db[:D], dw[D:], db[D:]]
         dc = [d.view(n, E, D) if d is not None else None for d in dconds]
-        return (None, dc[0], dc[1]) + tuple(grads)
+        return (None, None, dc[0], dc[1]) + tuple(grads)
 
 
 class BertFn(torch.autograd.Function):
@@ -1608,6 +1629,7 @@ class BertFn(torch.autograd.Function):
         cond16 = None
         E = 0
         kv_mod = 0
+        ctx.dkv_session = getattr(kv_own, "_mico_dkv", None) if kv_own is not None else None      # (DkvSession, attached by project_cross_kv)
         if kv_own is not None:
             assert cond is None and kv_cache is None
             n_own = b if kv_neg is None else b // 3
@@ -1742,7 +1764,26 @@ class BertFn(torch.autograd.Function):
         # third third accumulates onto the own half in a second launch: no per-entry buffer, no add / copy passes)
         kv_il = shared and ctx.kv_2d      # the memory is interleaved over the layers (a 2-D tensor to autograd): so are its gradients
         dkv2d = None        # interleaved: the 2-D [rows, L * 2 D] buffer behind the per-layer views - what autograd gets back
-        if has_neg:
+        # DkvSession: the passes that read one own set share ONE gradient buffer for it.  acc_own = the buffer an earlier backward of this pass
+        # wrote (this one adds to it in the attention kernel and returns None for kv_own).  Only when the engine wants kv_own's gradient in this
+        # pass at all - then CrossKVFn.backward runs after every reader and ends the session.
+        sess = ctx.dkv_session if (kv_il and runtime.CFG.dkv_inplace and ctx.needs_input_grad[5]) else None
+        acc_own = None
+        if sess is not None and sess.own is not None and not sess.closed:
+            if (ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(SITE_CROSS_P), batch0=2 * n_own if has_neg else 0)
+                    and tuple(sess.own.shape) == (n_own * E, spec.L * 2 * D) and sess.own.dtype == dt):
+                acc_own = sess.own
+            else:
+                sess.closed = True
+        dkv2d_neg = None
+        if acc_own is not None:
+            dkv_pair = None
+            dkv_own = _kv_layers(acc_own, spec.L, D)
+            dkv_neg = None
+            if has_neg:        # the triplet's hard negatives: only this pass reads them - a buffer of their own
+                dkv2d_neg = _empty((n_own * E, spec.L * 2 * D), dt, dev)
+                dkv_neg = _kv_layers(dkv2d_neg, spec.L, D)
+        elif has_neg:
             if kv_il:
                 dkv2d = _empty((2 * n_own * E, spec.L * 2 * D), dt, dev)
                 dkv_pair = _kv_layers(dkv2d, spec.L, D)
@@ -1797,9 +1838,23 @@ class BertFn(torch.autograd.Function):
                     kv = torch.as_strided(kv, (2 * n_own * E, 2 * D), (kv.stride(0), 1)).contiguous()
                 krs = kv.stride(0)
                 stc = dict(q_strides=(S * D, D), k_strides=(E * krs, krs), v_strides=(E * krs, krs), o_strides=(S * D, D))
-                if two_launch:
+                if two_launch and acc_own is None:
                     assert dkv_pair[li].stride(0) == krs
-                if shared and has_neg and ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(li * 8 + SITE_CROSS_P), batch0=2 * n_own):
+                if acc_own is not None and has_neg:
+                    # three launches over the triplet: entries [0, n) and [2 n, 3 n) ADD their dK / dV to the session's own-set buffer (the captioning
+                    # pass wrote it), entries [n, 2 n) write the hard negatives' buffer
+                    ne, r1 = n_own * E, n_own * S
+                    dko, dkn = dkv_own[li], dkv_neg[li]
+                    assert dko.stride(0) == krs and dkn.stride(0) == krs
+                    kvn = torch.as_strided(kv, kv.shape, kv.stride(), kv.storage_offset() + ne * krs)     # (kv = the own rows of the layer's [own | neg] sets)
+                    for e0, kvs, dst, acc in ((0, kv, dko, True), (1, kvn, dkn, False), (2, kv, dko, True)):
+                        rs = slice(e0 * r1, (e0 + 1) * r1)
+                        ops.attn_bwd(a["q"][rs], kvs, kvs[:, D:], a["cc"][rs], dcc[rs], a["lse_c"][e0 * n_own:(e0 + 1) * n_own], dq[rs], dst, dst[:, D:],
+                                     delta, B=n_own, H=H, Sq=S, Sk=E, hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P),
+                                     batch0=e0 * n_own, dkv_accumulate=acc, **stc)
+                    dkv = None
+                    split_done = True
+                elif shared and has_neg and ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(li * 8 + SITE_CROSS_P), batch0=2 * n_own):
                     # two launches over the triplet: entries [0, 2 n) own exactly the [own | neg] K/V sets, entries [2 n, 3 n) read the own sets again
                     # and ADD their dK / dV (mico_attn_params.batch0 keeps the dropout counters of the one-launch forward)
                     dkv = dkv_pair[li]
@@ -1814,7 +1869,8 @@ class BertFn(torch.autograd.Function):
                     split_done = False
                     dkv = dkv_own[li] if (shared and not has_neg) else _empty((b * E, 2 * D), dt, dev)
                     ops.attn_bwd(a["q"], kv, kv[:, D:], a["cc"], dcc, a["lse_c"], dq, dkv, dkv[:, D:], delta, B=b, H=H, Sq=S, Sk=E,
-                                 hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod, **stc)
+                                 hd=hd, scale=scale, mask=None, drop=at_drop(li * 8 + SITE_CROSS_P), kv_batch_mod=kv_mod,
+                                 dkv_accumulate=acc_own is not None, **stc)
                 linear_wgrad(dq, a["x16a"], G(ca + "query.weight"), inv_s)
                 ops.colsum(dq, G(ca + "query.bias"), scale=inv_s, accumulate=True)
                 if shared:   # dK/dV per batch entry -> per K/V set: the triplet's first and third thirds read the same (own) set
@@ -1859,6 +1915,14 @@ class BertFn(torch.autograd.Function):
         dc = dcond.view(b, E, D) if (dcond is not None and ctx.cond_needs_grad) else None
         if dkv2d is not None:      # contiguous row blocks [own | neg] of the one buffer
             dkv_own, dkv_neg = (dkv2d[:n_own * E], dkv2d[n_own * E:]) if has_neg else (dkv2d, None)
+        if acc_own is not None:    # the own set's gradient is in the buffer another pass handed to autograd
+            dkv_own, dkv_neg = None, dkv2d_neg
+            DkvSession.accumulated += 1
+        elif sess is not None:
+            if sess.own is None and not sess.closed and dkv2d is not None:
+                sess.own = dkv_own
+            else:
+                sess.closed = True      # a second buffer for the same set: the engine sums out of place from here on
         return (None, None, None, dc, None, dkv_own, dkv_neg) + grads.result()
 
 

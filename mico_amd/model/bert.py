@@ -112,7 +112,12 @@ class BertModel(nn.Module):
         for li in range(spec.L):
             ca = f"encoder.layer.{li}.crossattention.self."
             kvp += [params[spec.idx[ca + n]] for n in ("key.weight", "key.bias", "value.weight", "value.bias")]
-        return Fn.CrossKVFn.apply(spec, cond_own, cond_neg, *kvp)
+        session = Fn.DkvSession()
+        kv_own, kv_neg = Fn.CrossKVFn.apply(spec, session, cond_own, cond_neg, *kvp)
+        if kv_own.requires_grad:
+            # the passes that read this memory find the session on the tensor (BertFn.forward) and keep ONE gradient buffer for the own set
+            kv_own._mico_dkv = session
+        return kv_own, kv_neg
 
     def forward(self, input_ids=None, attention_mask=None, encoder_hidden_states=None, kv_cache=None, cross_kv=None, **_):
         """kv_cache (dict, inference only): holds the cross-attention K/V projections of `encoder_hidden_states` across calls -

@@ -48,6 +48,10 @@ class _Cfg:
     share_cross_kv = True
     # one gradient arena per backward pass for all the BERT passes of a step (functional.GradArena.session): no per-parameter sums by autograd
     share_grad_arena = True
+    # the BERT passes that read one shared cross-attention K/V memory (ITM triplet + captioning) accumulate its 16-bit gradient in ONE buffer
+    # (functional.DkvSession: the first backward writes it, later ones add in the attention kernel) instead of a buffer per pass summed out of
+    # place by autograd at the step's memory peak; MICO_DKV_PER_PASS=1: a buffer per pass (A/B runs)
+    dkv_inplace = os.environ.get("MICO_DKV_PER_PASS") is None
     # fp8 mode: the LayerNorm that feeds qkv / fc1 writes the GEMM's block-scaled fp8 operand itself (mico_layernorm_fwd_mx8) instead of a
     # quantisation pass over its 16-bit output; MICO_FP8_NO_FUSED_QUANT=1 for A/B runs
     fp8_fused_quant = os.environ.get("MICO_FP8_NO_FUSED_QUANT") is None

@@ -309,28 +309,35 @@ def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
     b = fx["meta"]["b"]
     batch0 = to_dev(synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234), cuda)
     from mico_amd import functional as Fn
-    res, concat = {}, {}
+    res, concat, accum = {}, {}, {}
     # per-pass projection; the shared memory interleaved over the layers (default: one projection GEMM, one K = L * 2 D product for the token
     # gradient); the shared memory layer-major (a launch per layer)
-    for share, interleaved in ((False, True), (True, True), (True, False)):
+    # (third field: functional.DkvSession - the captioning pass and the ITM triplet keep ONE gradient buffer for the own set they both read;
+    # off = a buffer per pass, summed by autograd)
+    for share, interleaved, inplace in ((False, True, True), (True, True, True), (True, True, False), (True, False, True)):
         batch = dict(batch0)
         batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
         batch["_injected"]["cap"] = r["inj"]["cap"]
-        old = runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved
-        runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved = share, interleaved
-        c0 = Fn.CrossKVFn.concat_backwards
+        old = runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved, runtime.CFG.dkv_inplace
+        runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved, runtime.CFG.dkv_inplace = share, interleaved, inplace
+        c0, a0 = Fn.CrossKVFn.concat_backwards, Fn.DkvSession.accumulated
         try:
             with runtime.precision(torch.float16):
                 m.zero_grad(set_to_none=True)
                 out = m(batch, fx["meta"]["task"], compute_loss=True)
                 sum(out.values()).backward()
         finally:
-            runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved = old
-        concat[(share, interleaved)] = Fn.CrossKVFn.concat_backwards - c0
-        res[(share, interleaved)] = ({k: v.item() for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-    assert concat[(True, True)] > 0 and concat[(True, False)] == 0 and concat[(False, True)] == 0, concat
-    ref_l, ref_g = res[(False, True)]
-    for key in ((True, True), (True, False)):
+            runtime.CFG.share_cross_kv, runtime.CFG.kv_interleaved, runtime.CFG.dkv_inplace = old
+        concat[(share, interleaved, inplace)] = Fn.CrossKVFn.concat_backwards - c0
+        accum[(share, interleaved, inplace)] = Fn.DkvSession.accumulated - a0
+        res[(share, interleaved, inplace)] = ({k: v.item() for k, v in out.items()},
+                                              {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert concat[(True, True, True)] > 0 and concat[(True, True, False)] > 0 and concat[(True, False, True)] == 0 and concat[(False, True, True)] == 0, concat
+    # the task's captioning pass shares the tva memory with the tva triplet: exactly one of the two adds to the other's buffer - and only in the
+    # interleaved layout with the session on
+    assert accum == {(False, True, True): 0, (True, True, True): 1, (True, True, False): 0, (True, False, True): 0}, accum
+    ref_l, ref_g = res[(False, True, True)]
+    for key in ((True, True, True), (True, True, False), (True, False, True)):
         for k in ref_l:
             assert abs(res[key][0][k] - ref_l[k]) <= 2e-4 * max(1.0, abs(ref_l[k])), (key, k)
         assert set(res[key][1]) == set(ref_g)
@@ -341,7 +348,8 @@ def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
             e = rel_err(res[key][1][n], g0) if g0.abs().max() > 0 else float(res[key][1][n].abs().max())
             if e > worst[1]:
                 worst = (n, e)
-        print(tag, "shared", "interleaved" if key[1] else "layer-major", "vs per-pass K/V: worst gradient difference", worst)
+        print(tag, "shared", "interleaved" if key[1] else "layer-major", "one dK/dV buffer" if (key[1] and key[2]) else "a buffer per pass",
+              "vs per-pass K/V: worst gradient difference", worst)
         assert worst[1] < 5e-3, (key, worst)
         assert any("crossattention.self.key.weight" in n for n in res[key][1])
 
