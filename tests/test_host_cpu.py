@@ -344,3 +344,76 @@ def test_grad_arena_private_fused_group_with_outside_producer():
         got = run(order, True)
         for a, b in zip(ref, got):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), order
+
+
+def test_dkv_session_contract_under_the_autograd_engine():
+    """functional.DkvSession's contract with the engine, restated with toy nodes on the CPU (the real readers are BertFn passes on the GPU:
+    tests/test_model_gpu.py::test_shared_cross_kv_equals_per_pass_projection): several readers of ONE producer output keep one gradient buffer - the
+    first backward writes and registers it and hands it to autograd, later ones add IN PLACE and return None, the producer's backward sees the
+    complete sum (the engine keeps a single incoming gradient by reference, it does not copy it) and ends the session.  A reader that cannot take
+    part returns its own buffer and closes the session: the readers after it fall back to buffers of their own, autograd sums, nothing is lost.
+    Every order of readers, against plain autograd."""
+    import torch
+    from mico_amd.functional import DkvSession
+
+    seen = {}
+
+    class Producer(torch.autograd.Function):                     # CrossKVFn: y = x w, session ended by the backward
+        @staticmethod
+        def forward(ctx, session, x, w):
+            ctx.session, ctx.x, ctx.w = session, x.detach(), w.detach()
+            return x.detach() @ w.detach()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["own_at_producer"] = ctx.session.own
+            ctx.session.reset()
+            return None, g @ ctx.w.t(), ctx.x.t() @ g
+
+    class Reader(torch.autograd.Function):                       # a BertFn pass reading kv_own
+        @staticmethod
+        def forward(ctx, kv, scale, can_add):
+            ctx.session, ctx.scale, ctx.can_add = getattr(kv, "_mico_dkv", None), scale, can_add
+            return kv.detach() * scale
+
+        @staticmethod
+        def backward(ctx, g):
+            sess = ctx.session if ctx.needs_input_grad[0] else None
+            mine = g * ctx.scale
+            if sess is not None and sess.own is not None and not sess.closed:
+                if ctx.can_add:
+                    sess.own.add_(mine)                          # (the attention kernel's dkv_accumulate)
+                    DkvSession.accumulated += 1
+                    return None, None, None
+                sess.closed = True
+            buf = mine.clone()
+            if sess is not None:
+                if sess.own is None and not sess.closed:
+                    sess.own = buf
+                else:
+                    sess.closed = True
+            return buf, None, None
+
+    torch.manual_seed(1)
+    x0, w0 = torch.randn(6, 3), torch.randn(3, 5)
+    for can in ((True, True, True), (True, False, True), (False, True, True), (True, True, False)):
+        ref = None
+        for plain in (True, False):
+            x, w = x0.clone().requires_grad_(), torch.nn.Parameter(w0.clone())
+            sess = DkvSession()
+            kv = x @ w if plain else Producer.apply(sess, x, w)
+            if not plain:
+                kv._mico_dkv = sess
+            a0 = DkvSession.accumulated
+            terms = [((kv * s if plain else Reader.apply(kv, s, c)) ** 2).sum() for s, c in zip((1.0, 2.0, 3.0), can)]
+            sum(terms).backward()
+            got = (x.grad.clone(), w.grad.clone())
+            if plain:
+                ref = got
+                continue
+            assert sess.own is None and not sess.closed                   # ended by the producer's backward
+            # readers run in reverse creation order: every reader that may add, and runs before a non-adding one closes the session, adds
+            expect = {(True, True, True): 2, (True, False, True): 0, (False, True, True): 1, (True, True, False): 2}[can]
+            assert DkvSession.accumulated - a0 == expect, (can, DkvSession.accumulated - a0)
+            for r, g in zip(ref, got):
+                assert torch.allclose(r, g, rtol=1e-5, atol=1e-5), can
