@@ -63,10 +63,33 @@ def main():
             print(f"live at end of forward: {tot / gib:.1f} GiB in {sum(cnt.values())} blocks")
             for k, v in by.most_common(40):
                 print(f"  {v / gib:8.2f} GiB  {cnt[k]:6d} blocks  {k}")
+        if it == 2:
+            # the backward, node by node: allocated at entry, peak inside, allocated at exit of every big autograd function (in execution order)
+            from mico_amd import functional as Fn
+            trace, saved = [], {}
+            for cls in (Fn.EvaTowerFn, Fn.CrossKVFn, Fn.BertFn, Fn.LMHeadLossFn, Fn._CondPack):
+                orig = saved[cls] = cls.backward
+
+                def wrapped(ctx, *g, _orig=orig, _name=cls.__name__):
+                    torch.cuda.synchronize()
+                    a0 = torch.cuda.memory_allocated()
+                    torch.cuda.reset_peak_memory_stats()
+                    out = _orig(ctx, *g)
+                    torch.cuda.synchronize()
+                    trace.append((_name, a0, torch.cuda.max_memory_allocated(), torch.cuda.memory_allocated(), torch.cuda.memory_reserved()))
+                    return out
+                cls.backward = staticmethod(wrapped)
+            peak_fwd = torch.cuda.max_memory_allocated()
         total.backward()
         torch.cuda.synchronize()
         if it == 2:
-            print(f"step peak {torch.cuda.max_memory_allocated() / gib:.1f} GiB (allocated), {torch.cuda.max_memory_reserved() / gib:.1f} GiB reserved")
+            for cls, orig in saved.items():
+                cls.backward = staticmethod(orig)
+            print("backward, node by node (GiB): allocated at entry / peak inside / allocated at exit / reserved at exit")
+            for name, a0, pk, a1, rs in trace:
+                print(f"  {name:14s} {a0 / gib:7.1f} {pk / gib:7.1f} {a1 / gib:7.1f} {rs / gib:7.1f}")
+            print(f"forward peak {peak_fwd / gib:.1f} GiB")
+            print(f"step peak {max([peak_fwd] + [t[2] for t in trace]) / gib:.1f} GiB (allocated; forward and the traced backward nodes), {torch.cuda.max_memory_reserved() / gib:.1f} GiB reserved")
             torch.cuda.memory._record_memory_history(enabled=None)
 
 
