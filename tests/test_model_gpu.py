@@ -354,6 +354,62 @@ def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
         assert any("crossattention.self.key.weight" in n for n in res[key][1])
 
 
+def test_dkv_session_both_reader_orders(setup, cuda):
+    """functional.DkvSession at the BertModel level, in BOTH orders of arrival: a triplet pass [own | neg | own] and an own-only pass read one shared
+    K/V memory (BertModel.project_cross_kv); whichever is created last is differentiated first and writes the own set's gradient buffer, the other adds to
+    it - the triplet in three short-query launches (own / negative / own), the own-only pass with dkv_accumulate in its one launch, into the own half of
+    the triplet's [own | neg] pair.  Against a buffer per pass summed by autograd (dkv_inplace off): same parameter and condition-token gradients."""
+    vtype, tag, m, sd = setup
+    if tag != "b16_d2":
+        pytest.skip("tower independent")
+    from mico_amd import functional as Fn
+    bert = m.multimodal_encoder.bert
+    g = torch.Generator().manual_seed(7)
+    n, S, E = 3, 16, 40
+    ids = torch.randint(1000, 30000, (3 * n, S), generator=g).to(cuda)
+    ids[:, 0] = 101
+    am = torch.ones_like(ids)
+    cond0, neg0 = torch.randn((n, E, 768), generator=g).to(cuda), torch.randn((n, E, 768), generator=g).to(cuda)
+    wt = torch.randn((3 * n, S, 768), generator=g).to(cuda)        # a fixed cotangent per output element
+    was_training = bert.training
+    bert.eval()                                                    # (no dropout: the two runs of an order must see the same function)
+    res = {}
+    try:
+        for order in ("triplet_first", "own_first"):
+            for inplace in (False, True):
+                old = runtime.CFG.dkv_inplace
+                runtime.CFG.dkv_inplace = inplace
+                a0 = Fn.DkvSession.accumulated
+                try:
+                    with runtime.precision(torch.float16):
+                        m.zero_grad(set_to_none=True)
+                        cond, neg = cond0.clone().requires_grad_(True), neg0.clone().requires_grad_(True)
+                        kv = bert.project_cross_kv(cond, neg)
+                        passes = {"triplet": lambda: (bert(input_ids=ids, attention_mask=am, cross_kv=kv).last_hidden_state * wt).sum(),
+                                  "own": lambda: (bert(input_ids=ids[:n], attention_mask=am[:n], cross_kv=(kv[0], None)).last_hidden_state * wt[:n]).sum() * 0.5}
+                        terms = [passes[k]() for k in (("triplet", "own") if order == "triplet_first" else ("own", "triplet"))]
+                        sum(terms).backward()
+                finally:
+                    runtime.CFG.dkv_inplace = old
+                assert Fn.DkvSession.accumulated - a0 == (1 if inplace else 0), (order, inplace)
+                grads = {k: p.grad.clone() for k, p in bert.named_parameters() if p.grad is not None}
+                grads["cond"], grads["neg"] = cond.grad.clone(), neg.grad.clone()
+                res[(order, inplace)] = grads
+            ref, got = res[(order, False)], res[(order, True)]
+            assert set(ref) == set(got) and any("crossattention.self.value.weight" in k for k in got)
+            worst = ("", 0.0)
+            for k, g0 in ref.items():
+                if k.endswith("self.key.bias"):       # analytically zero: rounding noise only
+                    continue
+                e = rel_err(got[k], g0) if g0.abs().max() > 0 else float(got[k].abs().max())
+                if e > worst[1]:
+                    worst = (k, e)
+            print("DkvSession", order, "vs a buffer per pass: worst gradient difference", worst)
+            assert worst[1] < 2e-3, (order, worst)
+    finally:
+        bert.train(was_training)
+
+
 def test_cap_subtask_without_retrieval_twin_keeps_cross_kv_gradients(setup, cuda):
     """task "cap%tv%tva_ret%tva" - cap%tv has no retrieval twin, so its BERT pass projects its own condition tokens and produces
     cross-attention key / value weight gradients itself, while ret%tva / cap%tva go through functional.CrossKVFn, a second producer of the same
