@@ -129,7 +129,7 @@ def test_alignment_step_full_gradients(setup, cuda):
     sdo = oracle_sd(sd)
     ref, _ = O.mico_forward(sdo, O.ARCHS[vtype], inp, fx["meta"]["task"], dict(itm_ratio=0.1), injected=injected)
     for k, v in r["losses"].items():   # the oracle against the reference-generated losses
-        assert abs(float(ref[k]) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-6), (k, float(ref[k]), float(v))
+        assert abs(float(ref[k].detach()) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-6), (k, float(ref[k].detach()), float(v))
     sum(ref.values()).backward()
     for n, d in r["grads"].items():
         assert grad_digest_check(d, sdo[n].grad, None) < 1e-3, ("oracle vs reference digest", n)
