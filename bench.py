@@ -63,6 +63,10 @@ PRECISIONS = {   # --dtype -> (torch dtype, split_fp16, split_mode, description)
 
 
 HEAD_SPLIT_BLOCKS = 4
+# Test switches for the N > 1 launch path on a 1-GPU box (tests/test_bench_launch_gpu.py): every rank on device 0, the process group on gloo (it
+# carries CUDA tensors; a 1-GPU box cannot host two RCCL ranks).  Never set by the driver: a line produced with them says so (`comm.backend`).
+ONE_DEVICE = os.environ.get("MICO_BENCH_ONE_DEVICE") == "1"
+BACKEND = os.environ.get("MICO_BENCH_BACKEND", "nccl")
 
 
 def release_memory():
@@ -104,6 +108,10 @@ def parse():
                     help="also run the AdamW step (mico_amd.optim, SURVEY section 8 row f4) inside the timed step: a full training step, "
                          "beyond the metric's fwd+bwd definition")
     ap.add_argument("--no-bert-dropout", action="store_true", help="A/B switch: BERT dropout probabilities set to 0 (invalidates the metric)")
+    ap.add_argument("--direct-backward", action="store_true",
+                    help="A/B switch: the direct form of the step (every BERT graph built, one backward over all of it) instead of MiCo.forward("
+                         "backward_scale=1.0), which differentiates the BERT passes one condition set at a time inside the forward (same values and "
+                         "gradients, ~25 GiB lower peak: room for every tower block's MLP pre-activation)")
     ap.add_argument("--dense-droppath", action="store_true",
                     help="evaluate dropped residual branches too and multiply them by 0 (the reference's schedule) instead of skipping them")
     return ap.parse_args()
@@ -311,7 +319,7 @@ def measure_parity(model, dev):
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: become the launcher - one process per GPU over RCCL, same arguments."""
     n = torch.cuda.device_count()
-    if n < args.gpus:
+    if n < args.gpus and not ONE_DEVICE:
         sys.exit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     port = 29500 + os.getpid() % 2000
@@ -365,6 +373,71 @@ def executed_tflop_per_sample(wname, task, kept, share_kv, eval_mode):
     return nominal, executed
 
 
+def compact_line(res):
+    """The stdout line: the contract's fields verbatim + the numbers of every other object (their prose and per-variant tables stay in the full
+    record on stderr)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: res[k] for k in keep}
+    c = res["config"]
+    out["config"] = {k: c[k] for k in ("workload", "per_gpu_batch", "global_batch", "frames_per_sample", "vision", "vit_layers", "parallelism",
+                                       "droppath_schedule", "kept_branch_fraction", "optimizer_step_in_timed_region")}
+    out["config"]["precision"] = c["precision"][:120]
+    out["config"]["backward"] = c.get("backward")
+    r = res.get("roofline")
+    if r is not None:
+        out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "launches", "avg_launch_ms",
+                                                 "step_frac", "step_tflops", "executed_tflop_per_sample", "kept_branch_fraction")}
+        out["roofline"]["all_gemm"] = r.get("all_gemm")
+        if r.get("traffic_provenance"):
+            out["roofline"]["traffic_provenance"] = r["traffic_provenance"][:60] + " ... (not measured in this run)"
+    else:
+        out["roofline"] = None
+    cb = res.get("cpu_baseline")
+    if cb is not None:
+        out["cpu_baseline"] = dict(value=cb["value"], unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], sample=cb["sample"][:230], cpu=cb.get("cpu"),
+                                   host_threads=cb.get("host_threads"),
+                                   anchors={k: round(v["samples_per_s"], 4) for k, v in (cb.get("anchors") or {}).items()})
+    for k in ("samples_per_sec_per_gpu", "frames_per_sec_per_gpu", "step_mfma_frac", "peak_mem_gb", "peak_reserved_gb", "hbm_gb", "losses", "allocator"):
+        out[k] = res.get(k)
+    tp = res.get("tower_plan") or {}
+    out["tower_plan"] = {k: tp.get(k) for k in ("frames", "frames_per_pass", "diet", "mlp_blocks_kept", "mlp_stash", "kept_fraction")}
+    p = res.get("parity")
+    if p is not None:
+        worst = max(((k, v) for k, v in p.items() if isinstance(v, float) and k not in ("worst", "gate")), key=lambda kv: kv[1])
+        out["parity"] = dict(worst=p["worst"], worst_tensor=worst[0], gate=p["gate"], tensors=sum(1 for v in p.values() if isinstance(v, float)) - 2,
+                             metric="max|out - ref| / max|ref| vs reference fp32 CPU goldens, timed precision")
+    sec = res.get("secondary")
+    if sec is not None:
+        out["secondary"] = {}
+        for k, v in sec.items():
+            if not isinstance(v, dict) or "error" in v:
+                out["secondary"][k] = v
+                continue
+            e = {kk: v.get(kk) for kk in ("value", "unit", "ms_per_step", "steps", "per_gpu_batch", "step_mfma_frac", "peak_mem_gb") if v.get(kk) is not None}
+            rr = v.get("roofline")
+            if rr:
+                e["all_gemm_tflops"] = (rr.get("all_gemm") or {}).get("tflops")
+            out["secondary"][k] = e
+    d = res.get("droppath_ab")
+    if d is not None:
+        out["droppath_ab"] = d if "error" in d else dict(speedup=d["speedup"], dense_value=d["dense_reference_schedule"]["value"], unit=d["unit"])
+    pc = res.get("parity_config")
+    if pc is not None:
+        out["parity_config"] = pc if "error" in pc else dict(precision=pc["precision"][:60], value=pc["value"], ms_per_step=pc["ms_per_step"],
+                                                             parity_worst=(pc.get("parity") or {}).get("worst"))
+    op = res.get("other_precisions")
+    if op is not None:
+        out["other_precisions"] = {k: (v if "error" in v else dict(value=v["value"], ms_per_step=v["ms_per_step"], parity_worst=(v.get("parity") or {}).get("worst")))
+                                   for k, v in op.items()}
+    cm = res.get("comm")
+    if cm is not None:
+        out["comm"] = {k: cm[k] for k in ("error", "backend", "rccl_ranks", "world_size", "packed_allgather_us", "grad_bytes", "grad_reduce_exposed_ms_per_step",
+                                          "per_rank_samples_per_s", "per_rank_exposed_reduce_ms", "forced_at_world_size_1", "ms_per_step_with_collectives",
+                                          "ms_per_step_headline") if k in cm}
+    out["full_record"] = "stderr line BENCH_FULL_JSON (per-variant GEMM table, parity per tensor, tower plans, notes)"
+    return out
+
+
 def main():
     args = parse()
     wl = WORKLOADS[args.workload]
@@ -388,13 +461,18 @@ def main():
     os.dup2(2, 1)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun)")
+    if ONE_DEVICE:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(BACKEND)
 
     from mico_amd import runtime, ops
     from mico_amd.model import MiCo, default_cfg
@@ -424,19 +502,22 @@ def main():
         optimizer = AdamW([dict(params=decay, weight_decay=0.01, lr=1e-6), dict(params=nodecay, weight_decay=0.0, lr=1e-6)],
                           lr=1e-6, betas=(0.9, 0.98))
     finish_ms = []
+    main_model = model
 
     def step(the_batch, task, model=model):
+        # (optimizer and reducer belong to the main model: a secondary model - configs[1]'s ViT-B/16 - steps without them)
+        mine = model is main_model
         model.zero_grad(set_to_none=True)
-        losses = model(dict(the_batch), task, compute_loss=True)
+        losses = model(dict(the_batch), task, compute_loss=True, backward_scale=None if args.direct_backward else 1.0)
         total = sum(losses.values())
         total.backward()
-        if state["reducer"] is not None:
+        if state["reducer"] is not None and mine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             state["reducer"].finish()
             e1.record()
             finish_ms.append((e0, e1))
-        if optimizer is not None:
+        if optimizer is not None and mine:
             optimizer.step()
         return losses
 
@@ -571,7 +652,8 @@ def main():
         torch.cuda.synchronize()
         ag_us = (time.perf_counter() - t0) / 20 * 1e6
         grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
-        comm = dict(backend="nccl (RCCL)", rccl_ranks=dist.get_world_size(), world_size=dist.get_world_size(), packed_allgather_us=ag_us,
+        comm = dict(backend="nccl (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend() + " (test switch MICO_BENCH_BACKEND: not an RCCL measurement)",
+                    rccl_ranks=dist.get_world_size() if dist.get_backend() == "nccl" else 0, world_size=dist.get_world_size(), packed_allgather_us=ag_us,
                     packed_allgather_bytes_per_rank=int(feat.numel() * 4 * 2 + ids.numel() * 8 * 2),
                     grad_bytes=grad_bytes, grad_reduce_exposed_ms_per_step=exposed,
                     grad_reduce_note="time the step spends in GradBucketReducer.finish() waiting for reductions that did not hide behind "
@@ -622,6 +704,13 @@ def main():
                                                       "this process, so this figure is NOT measured in this run")
                     break
 
+    if roofline is not None:
+        # the STEP next to the dominant kernel (the driver keeps this object): executed algorithmic TFLOP/s of the whole fwd+bwd
+        # step over the dense 16-bit MFMA peak, what was executed per sample, the kept stochastic-depth fraction, all GEMM launches together
+        roofline["step_frac"] = head["step_mfma_frac"]
+        roofline["step_tflops"] = head["step_executed_tflops_per_gpu"]
+        roofline["executed_tflop_per_sample"] = (head["tflop_per_sample"] or {}).get("executed")
+        roofline["kept_branch_fraction"] = head["kept_branch_fraction"]
     res = {
         "metric": "omni-modal samples/sec (ViT-g/14 fwd+bwd)", "value": head["value"], "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
@@ -632,6 +721,9 @@ def main():
                    "droppath": ("off (eval)" if args.eval_mode else "on, reference rates (0 -> 0.4 linear)"),
                    "droppath_schedule": ("dense: every branch evaluated then scaled by 0 | 1/keep" if args.dense_droppath
                                          else "dropped (block, branch, frame) triples are skipped - exact, zero contribution"),
+                   "backward": ("direct: one backward over every graph of the step" if args.direct_backward else
+                                "staged: BERT passes differentiated one condition set at a time inside the forward (MiCo.forward(backward_scale=1.0)), "
+                                "towers in the caller's backward - same values and gradients"),
                    "kept_branch_fraction": head["kept_branch_fraction"], "optimizer_step_in_timed_region": bool(args.optimizer),
                    "bert_dropout": (False if (args.eval_mode or args.no_bert_dropout) else
                                     "on: p=0.1 hidden + attention-probability (reference config.json)")},
@@ -672,6 +764,21 @@ def main():
             sec["workload"] = WORKLOAD_TEXT[other].format(b=b, task=WORKLOADS[other]["task"])
             res["secondary"] = {("configs2_img_aud_txt" if other == "img_aud_txt" else "omni_configs3_rank_share"): sec}
             del sbatch
+            if args.dtype != "bf16":
+                # BASELINE.json names configs[2] "bf16": the same step with bf16 MFMA operands, reported (not gated - bf16 keeps 8
+                # mantissa bits; the gated 16-bit configuration is the fp16 one above)
+                try:
+                    set_precision("bf16")
+                    release_memory()
+                    sbf, bbf = measure("img_aud_txt", WORKLOADS["img_aud_txt"]["task"], b, max(5, args.steps // 4), 2, seed=4321)
+                    del bbf
+                    res["secondary"]["configs2_img_aud_txt_bf16"] = dict(value=sbf["value"], unit="samples/s", ms_per_step=sbf["ms_per_step"], steps=sbf["steps"],
+                                                                         step_mfma_frac=sbf["step_mfma_frac"], peak_mem_gb=sbf["peak_mem_gb"],
+                                                                         precision=PRECISIONS["bf16"][3])
+                except Exception as e:
+                    res["secondary"]["configs2_img_aud_txt_bf16"] = {"error": repr(e)}
+                finally:
+                    set_precision(args.dtype)
         except Exception as e:   # the headline line must survive a failure of the secondary measurement
             res["secondary"] = {"error": repr(e)}
         # ---- BASELINE configs[1] (ViT-B/16 image + text contrastive step, b = 256): its own model, timed with its own GEMM roofline ----
@@ -749,7 +856,15 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(sd_cpu, args)
     sys.stdout.flush()
-    os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    # The complete record goes to stderr (and to MICO_BENCH_FULL, a path, when set: tools/profile_round.sh keeps it under profiles/); the ONE line on
+    # stdout is its compact form - every contract field, `roofline` with the step-level figures, `cpu_baseline`, and the headline numbers of the
+    # other objects - so that a tail of a few KB holds all of it (the round-5 line was > 8 KB and the driver's tail cut its head off).
+    full = json.dumps(res)
+    print("BENCH_FULL_JSON " + full, file=sys.stderr, flush=True)
+    if os.environ.get("MICO_BENCH_FULL"):
+        with open(os.environ["MICO_BENCH_FULL"], "w") as fh:
+            fh.write(full + "\n")
+    os.write(real_stdout, (json.dumps(compact_line(res)) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -61,16 +61,21 @@ int mico_struct_layout(int* out, int n);
  * ------------------------------------------------------------------------------------------------------------- */
 #define MICO_ACT_NONE 0
 #define MICO_ACT_GELU 1      /* v = gelu(v) */
-#define MICO_ACT_GELU_GRAD 2 /* v = v * gelu'(aux_in) */
+#define MICO_ACT_GELU_GRAD 2 /* v = v * gelu'(aux_in); with aux_out != NULL also aux_out = T(gelu(aux_in)) (ABI 115, see below) */
 /* The pair the MLPs use: the forward GEMM keeps gelu'(pre-activation) instead of the pre-activation itself (aux_out, same bytes), so
  * the backward epilogue is one multiply - the erf polynomial is ~10 % of a 256x256 tile's time and was paid in both directions.
  * Dedicated kernel instantiations: SAVE_DERIV needs ta = tb = 0, aux_out and a 16-bit C; MUL_AUX needs ta = 0, tb = 1 and aux_in. */
 #define MICO_ACT_GELU_SAVE_DERIV 3 /* aux_out = T(gelu'(v)); v = gelu(v) */
 #define MICO_ACT_MUL_AUX 4         /* v = v * aux_in */
+/* The pair that keeps ONE 16-bit tensor per MLP (round 6, ABI 115; the towers' saved activations: half the bytes of gelu + gelu'): the forward is
+ * MICO_ACT_GELU with aux_out = the pre-activation copy h, and fc2's input-gradient launch is MICO_ACT_GELU_GRAD with aux_in = h and
+ * aux_out = a second 16-bit [M, N] buffer (ldaux) that receives gelu(h) - the operand of fc2's weight gradient, re-created by the launch that
+ * reads h anyway (~0.3 ms per block against the 3.7 ms fc1 GEMM a block without kept intermediates re-runs).  Both take aux_tiled (h in the
+ * persistent kernel's accumulator layout; gelu(h) is always row-major). */
 
 typedef struct mico_gemm_epilogue {
     const float* bias;      /* [N] or NULL */
-    void* aux_out;          /* 16-bit [M,N] pre-activation copy or NULL */
+    void* aux_out;          /* 16-bit [M,N] pre-activation copy (GELU_SAVE_DERIV: gelu'; GELU_GRAD: gelu(aux_in)) or NULL */
     const void* aux_in;     /* 16-bit [M,N] (GELU_GRAD) or NULL */
     int64_t ldaux;
     int act;
@@ -113,7 +118,8 @@ typedef struct mico_gemm_epilogue {
      * `stream`; two launches that may run concurrently (different streams) must be given different scratch buffers. */
     void* splitk_ws;
     int64_t splitk_ws_bytes;
-    /* The MLP pair's private layout for gelu'(pre-activation) (round 5).  The tensor GELU_SAVE_DERIV writes (aux_out) is read by exactly one other
+    /* The MLP pair's private layout for gelu'(pre-activation) (round 5) - and for the pre-activation itself (round 6: GELU + aux_out writes it,
+     * GELU_GRAD + aux_in reads it; the same rules).  The tensor GELU_SAVE_DERIV writes (aux_out) is read by exactly one other
      * launch, MUL_AUX (aux_in), of the same [M, N] - so with aux_tiled != 0 both keep it the way the persistent 8-phase kernel's accumulators
      * hold it instead of row-major: tile (tm, tn) of 256 x 256 is the 128 KiB at ((tm * N / 256) + tn) * 128 KiB, wave w its 16 KiB at w * 16 KiB,
      * unit u (0..15) of a wave is one KiB with lane l's eight values at l * 16 bytes.  Written and read with whole-KiB accesses straight from /

@@ -133,7 +133,7 @@ class MicoHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 114   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
+ABI_VERSION = 115   # = mico_version() of the library this binding matches (bumped with every signature / struct change)
 
 
 def _check_struct_layout(l):

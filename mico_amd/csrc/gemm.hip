@@ -446,7 +446,7 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
         f32x4 v4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) v4[v] = *(LDS_AS const f32x4*)(wbuf + row * 256 + ((((col[v] >> 2)) ^ kr) << 4)) + bias4[v];
-        if ((ACT == 0 || ACT == MICO_ACT_GELU_SAVE_DERIV) && e.aux_out) {   // 16-bit copy of the pre-activation (ACT 3: of gelu'); present only with 16-bit outputs, i.e. the paired ownership
+        if ((ACT == 0 || ACT == MICO_ACT_GELU_SAVE_DERIV) && e.aux_out && !(ACT == 0 && e.act == MICO_ACT_GELU_GRAD)) {   // 16-bit copy of the pre-activation (ACT 3: of gelu'); present only with 16-bit outputs, i.e. the paired ownership
             T* ap = (T*)e.aux_out + m * e.ldaux + ncol0;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -478,12 +478,24 @@ __device__ __forceinline__ void gemm_epilogue_block(const GemmArgs& g, const f32
                 for (int v = 0; v < 4; ++v) v4[v] = gelu4(v4[v]);
             } else if (e.act == MICO_ACT_GELU_GRAD) {
                 const T* hp = (const T*)e.aux_in + m * e.ldaux + ncol0;
+                if (e.aux_out) {      // ... and gelu(aux_in) goes to aux_out (the pre-activation-keeping MLP pair: the operand of fc2's weight gradient);
+                    T* gp = (T*)e.aux_out + m * e.ldaux + ncol0;      // gelu_pair4: bit for bit the persistent kernel's ACT_GRAD_TILED epilogue
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (ok[v]) {
-                        const f32x4 h = unpack4<T>(*(const s16x4*)(hp + gcol[v]));
-                        v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
-                    }
+                    for (int v = 0; v < 4; ++v)
+                        if (ok[v]) {
+                            f32x4 d;
+                            const f32x4 gl = gelu_pair4(unpack4<T>(*(const s16x4*)(hp + gcol[v])), d);
+                            v4[v] *= d;
+                            *(s16x4*)(gp + gcol[v]) = pack4<T>(gl[0], gl[1], gl[2], gl[3]);
+                        }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (ok[v]) {
+                            const f32x4 h = unpack4<T>(*(const s16x4*)(hp + gcol[v]));
+                            v4[v][0] *= gelu_grad_f(h[0]); v4[v][1] *= gelu_grad_f(h[1]); v4[v][2] *= gelu_grad_f(h[2]); v4[v][3] *= gelu_grad_f(h[3]);
+                        }
+                }
             }
         }
         if (!LEAN && e.drop_p > 0.f) {
@@ -1741,20 +1753,26 @@ __device__ __forceinline__ void p8p_aux_load(i32x4 (&xa)[16], __amdgpu_buffer_rs
 }
 // ACT_PAIR_TILED / ACT_MUL_TILED: the GELU pair / the GELU' multiply with the tiled aux layout (rsx: p8p_aux_tile_desc).
 // `xa` / `more`: ACT_MUL_TILED only (the multipliers of p8p_aux_load, 16 loads older than the next tile's twelve requests when there is a next tile).
-constexpr int ACT_PAIR_TILED = 7, ACT_MUL_TILED = 8;
+// ACT_PRE_TILED / ACT_GRAD_TILED (round 6): the MLP pair that keeps the PRE-ACTIVATION h = x W1^T + b1 (one 16-bit tensor per block, in the same tiled
+// layout) instead of gelu(h) AND gelu'(h): the forward is GELU with h leaving from the registers (no GELU' arithmetic), and fc2's dX launch reads h
+// back, multiplies its result by gelu'(h) and writes gelu(h) - the operand of fc2's weight gradient, which therefore runs AFTER it - row-major through
+// `rso` next to its own output (MICO_ACT_GELU + aux_out / MICO_ACT_GELU_GRAD + aux_in + aux_out with aux_tiled; include/mico_hip.h).
+constexpr int ACT_PAIR_TILED = 7, ACT_MUL_TILED = 8, ACT_PRE_TILED = 9, ACT_GRAD_TILED = 10;
 template <typename T, int ACT>
 __device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], LDS_AS char* wbuf, __amdgpu_buffer_rsrc_t rsc, __amdgpu_buffer_rsrc_t rsx,
-                                             int64_t n0e, int wm, int wn, int lane, const i32x4* xa = nullptr, bool more = false) {
+                                             __amdgpu_buffer_rsrc_t rso, int64_t n0e, int wm, int wn, int lane, const i32x4* xa = nullptr, bool more = false) {
         int le = lane;
         asm volatile("" : "+v"(le));      // (lane arithmetic of the epilogue recomputed per tile: hoisted, it would live through every K loop)
         const int p = le & 15, gq = le >> 4, q = le & 3, rr = le >> 2;
                 const float alpha = g.e.alpha;
         const int64_t ncol0 = n0e + wn * 32;
-        f32x4 bias[4];
+        f32x4 bias[ACT == ACT_GRAD_TILED ? 1 : 4];      // (GRAD_TILED: an input-gradient launch, routed here without a bias only - 16 registers its epilogue needs)
+        if constexpr (ACT != ACT_GRAD_TILED) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t col = ncol0 + (j >> 1) * 128 + (j & 1) * 16 + gq * 4;
-            bias[j] = (g.e.bias && col < g.N) ? *(const f32x4*)(g.e.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                const int64_t col = ncol0 + (j >> 1) * 128 + (j & 1) * 16 + gq * 4;
+                bias[j] = (g.e.bias && col < g.N) ? *(const f32x4*)(g.e.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
         const int wkey = epi16_key(p), rkey = epi16_key(rr);
         const int woff = p * 128 + (gq & 1) * 8, wch = gq >> 1;
@@ -1764,6 +1782,7 @@ __device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&ac
         for (int u = 0; u < 2; ++u) coff[u] = (ncol0 + u * 128 + q * 8 < g.N) ? (unsigned)((wn * 32 + u * 128 + q * 8) * 2) : 0xFFFFFFF0u;
         auto value = [&](int i, int j) {
             f32x4 t = acc[i][j] * alpha;
+            if constexpr (ACT == ACT_GRAD_TILED) return t;
             asm volatile("" : "+v"(t));
             return t + bias[j];
         };
@@ -1771,7 +1790,37 @@ __device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&ac
             const unsigned off = coff[u] == 0xFFFFFFF0u ? 0xFFFFFFF0u : (unsigned)row_in_tile * ld2 + coff[u];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rs, (int)off, 0, 0);
         };
-        if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
+        if constexpr (ACT == ACT_GRAD_TILED) {
+            // eight rounds of 16 rows x two outputs (the SAVE_DERIV staging): round i reads the pre-activation units 2 i, 2 i + 1 of p8p_aux_load -
+            // 2 (7 - i) younger loads of it + the next tile's twelve requests may stay out (never a store counted on: see gemm_p8p_kernel)
+            auto round = [&](auto iv) {
+                constexpr int i = decltype(iv)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + 2 * (7 - i)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (7 - i)) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i32x4 x4 = xa[i * 2 + (j >> 1)];
+                    const f32x4 h = unpack4<T>(__builtin_bit_cast(s16x4, (j & 1) ? (i32x2){x4[2], x4[3]} : (i32x2){x4[0], x4[1]}));
+                    f32x4 d;
+                    const f32x4 gl = gelu_pair4(h, d);
+                    const f32x4 v = value(i, j) * d;
+                    const int off = woff + (((j * 2 + wch) ^ wkey) << 4);
+                    *(LDS_AS s16x4*)(wbuf + off) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    *(LDS_AS s16x4*)(wbuf + 2048 + off) = pack4<T>(gl[0], gl[1], gl[2], gl[3]);
+                }
+                const int row = (i >> 2) * 128 + wm * 64 + (i & 3) * 16 + rr;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int off = rr * 128 + (((u * 4 + q) ^ rkey) << 4);
+                    bstore(rsc, ldc2, row, u, *(LDS_AS const s16x8*)(wbuf + off));
+                    bstore(rso, ldx2, row, u, *(LDS_AS const s16x8*)(wbuf + 2048 + off));
+                }
+            };
+            round(std::integral_constant<int, 0>{}); round(std::integral_constant<int, 1>{}); round(std::integral_constant<int, 2>{}); round(std::integral_constant<int, 3>{});
+            round(std::integral_constant<int, 4>{}); round(std::integral_constant<int, 5>{}); round(std::integral_constant<int, 6>{}); round(std::integral_constant<int, 7>{});
+        } else if constexpr (ACT != MICO_ACT_GELU_SAVE_DERIV) {
             s16x4 dlo = {0, 0, 0, 0};
             const unsigned xbase = (unsigned)((wm * 4 + wn) * 16384 + le * 16);
             (void)dlo; (void)xbase;
@@ -1800,9 +1849,10 @@ __device__ __forceinline__ void p8p_epilogue(const GemmArgs& g, const f32x4 (&ac
                     for (int j = 0; j < 4; ++j) {
                         f32x4 v = value(r * 2 + ii, j);
                         if constexpr (ACT == MICO_ACT_GELU) v = gelu4(v);
-                        if constexpr (ACT == ACT_PAIR_TILED) {      // GELU' leaves from the registers: unit (i, j >> 1) of the wave's 16 KiB (p8p_aux_load)
+                        if constexpr (ACT == ACT_PAIR_TILED || ACT == ACT_PRE_TILED) {      // GELU' (PRE: the pre-activation) leaves from the registers: unit (i, j >> 1) of the wave's 16 KiB (p8p_aux_load)
                             f32x4 d;
-                            v = gelu_pair4(v, d);
+                            if constexpr (ACT == ACT_PAIR_TILED) v = gelu_pair4(v, d);
+                            else { d = v; v = gelu4(v); }
                             const s16x4 dp = pack4<T>(d[0], d[1], d[2], d[3]);
                             if ((j & 1) == 0) dlo = dp;
                             else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, (s16x8){dlo[0], dlo[1], dlo[2], dlo[3], dp[0], dp[1], dp[2], dp[3]}), rsx,
@@ -1851,9 +1901,11 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
     // epilogue in eight 16-row rounds of 4 KiB per wave: fc2 forward 1177 -> 1063, projection forward 830 -> 784, the GELU' multiply 1007 -> 880
     // TFLOP/s in situ - eight dependent load -> LDS -> store round trips cost more than the hidden prologue saves.  Those launches stay on the
     // one-tile kernel.)
-    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == ACT_PAIR_TILED || ACT == ACT_MUL_TILED, "the 16-bit staged epilogues");
+    static_assert(ACT == ACT_LEAN || ACT == MICO_ACT_GELU || ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == ACT_PAIR_TILED || ACT == ACT_MUL_TILED || ACT == ACT_PRE_TILED ||
+                  ACT == ACT_GRAD_TILED, "the 16-bit staged epilogues");
+    constexpr bool AUX_READ = ACT == ACT_MUL_TILED || ACT == ACT_GRAD_TILED;      // the tiled aux tensor is an INPUT of the epilogue (p8p_aux_load)
     constexpr int BM = P8C::BM, BN = P8C::BN, BK = P8C::BK, HALF = P8C::HALF, TILE = P8C::TILE;
-    constexpr int NS = (ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == ACT_PAIR_TILED) ? 32 : 16;      // buffer stores per wave and tile
+    constexpr int NS = (ACT == MICO_ACT_GELU_SAVE_DERIV || ACT == ACT_PAIR_TILED || ACT == ACT_PRE_TILED || ACT == ACT_GRAD_TILED) ? 32 : 16;      // buffer stores per wave and tile
     // Counted waits never count on a STORE being outstanding: loads return in order among themselves, stores among themselves, but a store can
     // retire before an older load (the first version waited vmcnt(NS + 6) while the wanted half-tile was older than the previous tile's NS stores -
     // and read half-tiles that had not landed: 41 of 48 outputs wrong in tools/probes/epi16_check.py).  vmcnt(6) = "at most the three youngest
@@ -1928,14 +1980,14 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
     const unsigned ld_dst = (unsigned)(wave * 1024);
     // CHECKED = false: K-tile t exists for sure (the prologue's K-tiles 0 and 1: the launcher requires >= 2) - no select on the offsets, i.e.
     // no per-tile-invariant copies of them for the register allocator to keep (it spilled twelve, reloaded behind vmcnt(0) in every tile)
-    auto issue = [&](int t, auto wv, auto checked) {
+    auto issue = [&](int t, auto wv, auto checked, unsigned ldd) {      // ldd: this wave's offset inside a half-tile image (ld_dst, or a per-tile copy of it)
         constexpr int W = decltype(wv)::value;
         constexpr bool isA = (W == 0 || W == 3);               // stream order of a tile: A-lo, B-hi, B-lo, A-hi (quadrant walk 1)
         constexpr int half = (W == 1 || W == 3) ? 1 : 0;
         const bool valid = (!decltype(checked)::value || t < T_) && (!TB || isA || half == 0 || bhi);
         const int ta_ = (!TB && g.a_wrap > 0 && t >= g.a_wrap) ? t - g.a_wrap : t;
         const unsigned soff = isA ? (unsigned)(ta_ * BK * 2) : (TB ? (unsigned)((int64_t)t * BK * ldb_b) : (unsigned)(t * BK * 2));
-        LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ld_dst;
+        LDS_AS char* dst = lds + (t & 1) * TILE + (isA ? 0 : 2 * HALF) + half * HALF + ldd;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             unsigned v = isA ? vra[half][it] : vrb[half][it];
@@ -1994,7 +2046,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
     using VMS = std::integral_constant<int, VMW>;
     auto issue_h = [&](int t, auto pv) {   // the half-tile issued in phase p of tile t: stream position 4 t + p + 6
         constexpr int IDX = decltype(pv)::value + 6;
-        issue(t + IDX / 4, std::integral_constant<int, IDX % 4>{}, std::true_type{});
+        issue(t + IDX / 4, std::integral_constant<int, IDX % 4>{}, std::true_type{}, ld_dst);
     };
     auto ktile = [&](int t, int cur, auto vm) {
         const int nxt = cur ^ TILE;
@@ -2006,7 +2058,15 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
 
     int vb = blockIdx.x;
     locate(vb);
-    issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
+    // the six requests of a tile's prologue: their twelve LDS destinations are constants of the kernel - as such hipcc keeps them in (vector) registers
+    // across the whole tile loop, and where the epilogue is register-hungry (ACT_GRAD_TILED) spills them: a scratch reload + vmcnt(0) in front of EVERY
+    // request, i.e. the next tile's requests issued one memory round trip apart.  Recomputed per tile from a laundered copy of the wave's offset instead.
+    auto first6 = [&]() {
+        unsigned ldd = ld_dst;
+        asm volatile("" : "+s"(ldd));
+        issue(0, W0{}, NC{}, ldd); issue(0, W1{}, NC{}, ldd); issue(0, W2{}, NC{}, ldd); issue(0, W3{}, NC{}, ldd); issue(1, W0{}, NC{}, ldd); issue(1, W1{}, NC{}, ldd);
+    };
+    first6();
     for (;;) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -2028,8 +2088,8 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
             ktile(t, cur, VMS{});
             cur ^= TILE;
         }
-        i32x4 xa[ACT == ACT_MUL_TILED ? 16 : 1];
-        if constexpr (ACT == ACT_MUL_TILED) {   // the multiplier tile, requested before the closing wait (which then leaves these 16 loads out)
+        i32x4 xa[AUX_READ ? 16 : 1];
+        if constexpr (AUX_READ) {   // the multiplier (GRAD: pre-activation) tile, requested before the closing wait (which then leaves these 16 loads out)
             fence();
             rsx = p8p_aux_tile_desc(g.e.aux_in, g, m0, n0);
             p8p_aux_load(xa, rsx, wave, lane);
@@ -2037,23 +2097,25 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8p_kernel(const GemmArg
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();
         // the zero-fill DMAs issued past the last tile must not land in what follows
-        if constexpr (ACT == ACT_MUL_TILED) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (AUX_READ) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---- the next tile's first six half-tiles, requested before this tile is stored ----
         rsc = out_desc(g.C, g.ldc * 2);
+        __amdgpu_buffer_rsrc_t rso = rsc;
         if constexpr (ACT == MICO_ACT_GELU_SAVE_DERIV) rsx = out_desc((char*)g.e.aux_out, g.e.ldaux * 2);
-        else if constexpr (ACT == ACT_PAIR_TILED) rsx = p8p_aux_tile_desc(g.e.aux_out, g, m0, n0);
-        else if constexpr (ACT != ACT_MUL_TILED) rsx = rsc;
+        else if constexpr (ACT == ACT_PAIR_TILED || ACT == ACT_PRE_TILED) rsx = p8p_aux_tile_desc(g.e.aux_out, g, m0, n0);
+        else if constexpr (ACT == ACT_GRAD_TILED) rso = out_desc((char*)g.e.aux_out, g.e.ldaux * 2);
+        else if constexpr (!AUX_READ) rsx = rsc;
         const int64_t n0e = n0;
         vb += gridDim.x;
         const bool more = vb < g.ntiles;
         if (more) {
             locate(vb);
-            issue(0, W0{}, NC{}); issue(0, W1{}, NC{}); issue(0, W2{}, NC{}); issue(0, W3{}, NC{}); issue(1, W0{}, NC{}); issue(1, W1{}, NC{});
+            first6();
         }
         // ---- epilogue: staging in the two ring slots the requests above do not use (second tile buffer: A-hi, B-lo), 4 KiB per wave ----
-        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, n0e, wm, wn, lane, xa, more);
+        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, rso, n0e, wm, wn, lane, xa, more);
         if (!more) return;
     }
 }
@@ -2572,7 +2634,7 @@ __global__ __launch_bounds__(P8C::THREADS, 2) void gemm_p8pmx_kernel(const Mx8Ar
             locate(vb);
             request_first();
         }
-        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, n0e, wm, wn, lane);
+        p8p_epilogue<T, ACT>(g, acc, lds + TILE + HALF + wave * 4096, rsc, rsx, rsc, n0e, wm, wn, lane);
         if (!more) return;
     }
 }
@@ -3347,6 +3409,9 @@ bool launch_p8p(int tb, const GemmArgs& g, hipStream_t st) {
         if (g.N % 256 != 0) return false;
         if (g.e.act == MICO_ACT_MUL_AUX && tb && g.e.aux_in && !g.e.aux_out) { MICO_LAUNCH((gemm_p8p_kernel<T, true, ACT_MUL_TILED>), grid, block, 0, st, g); return true; }
         if (g.e.act == MICO_ACT_GELU_SAVE_DERIV && !tb && g.e.aux_out) { MICO_LAUNCH((gemm_p8p_kernel<T, false, ACT_PAIR_TILED>), grid, block, 0, st, g); return true; }
+        // the pre-activation-keeping pair (round 6): GELU with the tiled pre-activation copy / GELU' multiply from it + gelu(pre-activation) row-major
+        if (g.e.act == MICO_ACT_GELU && !tb && g.e.aux_out && !g.e.aux_in) { MICO_LAUNCH((gemm_p8p_kernel<T, false, ACT_PRE_TILED>), grid, block, 0, st, g); return true; }
+        if (g.e.act == MICO_ACT_GELU_GRAD && tb && g.e.aux_in && g.e.aux_out && !g.e.bias) { MICO_LAUNCH((gemm_p8p_kernel<T, true, ACT_GRAD_TILED>), grid, block, 0, st, g); return true; }
         return false;
     }
     if (g.e.aux_in) return false;
@@ -3472,7 +3537,7 @@ static constexpr int g_mico_gemm_variant = 0;
 static constexpr int g_mico_mid_group = 0;
 #endif
 extern "C" int mico_gemm_last_kernel(void) { return g_mico_last_gemm_kernel; }
-extern "C" int mico_version(void) { return 114; }
+extern "C" int mico_version(void) { return 115; }
 extern "C" const char* mico_last_error_string(void) { return g_mico_err; }
 
 extern "C" int mico_struct_layout(int* out, int n) {
@@ -3750,6 +3815,7 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
                    "mico_gemm: split_k > 1 supports only the alpha-scaled accumulate epilogue");
     }
     if (g.e.act == MICO_ACT_GELU_GRAD || g.e.act == MICO_ACT_MUL_AUX) MICO_CHECK(g.e.aux_in != nullptr, "mico_gemm: GELU_GRAD / MUL_AUX need aux_in");
+    if (g.e.act == MICO_ACT_GELU_GRAD && g.e.aux_out) MICO_CHECK(c_dtype != MICO_F32 && g.e.aux_out != g.e.aux_in, "mico_gemm: GELU_GRAD with aux_out (= gelu(aux_in)) needs a 16-bit C and a buffer of its own");
     MICO_CHECK(g.e.act >= MICO_ACT_NONE && g.e.act <= MICO_ACT_MUL_AUX, "mico_gemm: unknown act %d", g.e.act);
     // the MLP pair exists as dedicated instantiations only: forward orientation / dX orientation, no split-K, 16-bit output
     if (g.e.act == MICO_ACT_GELU_SAVE_DERIV) MICO_CHECK(!ta && !tb && g.e.aux_out && c_dtype != MICO_F32, "mico_gemm: GELU_SAVE_DERIV is the forward epilogue (ta = tb = 0, aux_out, 16-bit C)");
@@ -3770,12 +3836,13 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
         }
     }
     g_mico_last_gemm_kernel = w4 ? 3 : pc ? 2 : (big ? 1 : 0);
+    // (checked in front of the routing chain: between the W4 build's dangling `else` and `if (pc)` it would become that else's body - ADVICE r5)
+    if (g.e.aux_tiled) MICO_CHECK(p8 && !pc && !w4, "mico_gemm: aux_tiled is the layout of the persistent 8-phase kernel's MLP pair (ask mico_gemm_aux_tiled_elems first)");
 #ifdef MICO_GEMM_W4
     if (w4 && deep) DISPATCH_T16(dtype, (launch_w4<T, 1>(ta, tb, g, st)));
     else if (w4) DISPATCH_T16(dtype, (launch_w4<T, 0>(ta, tb, g, st)));
     else
 #endif
-    if (g.e.aux_tiled) MICO_CHECK(p8 && !pc && !w4, "mico_gemm: aux_tiled is the layout of the persistent 8-phase kernel's MLP pair (ask mico_gemm_aux_tiled_elems first)");
     if (pc) DISPATCH_T16(dtype, (launch_pc<T>(ta, tb, g, st)));
     else if (p8) {
         g_mico_last_gemm_kernel = 8;
@@ -3785,13 +3852,14 @@ extern "C" int mico_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, const 
                    (g.e.aux_out || g.e.aux_in ? 256 * g.e.ldaux * 2 < 0x7FFFFFFFll : true) && g_mico_gemm_variant != 15;
         if (g.e.aux_tiled)      // exactly launch_p8p's conditions for the two tiled instantiations
             MICO_CHECK(MICO_P8_PERSIST && g_mico_gemm_variant != 16 && g.fast16 && N % 256 == 0 && g.ntiles > 256 && g.ktiles >= 2 &&
-                           ((g.e.act == MICO_ACT_GELU_SAVE_DERIV && !tb && g.e.aux_out) || (g.e.act == MICO_ACT_MUL_AUX && tb && g.e.aux_in && !g.e.aux_out)),
+                           ((g.e.act == MICO_ACT_GELU_SAVE_DERIV && !tb && g.e.aux_out) || (g.e.act == MICO_ACT_MUL_AUX && tb && g.e.aux_in && !g.e.aux_out) ||
+                            (g.e.act == MICO_ACT_GELU && !tb && g.e.aux_out && !g.e.aux_in) || (g.e.act == MICO_ACT_GELU_GRAD && tb && g.e.aux_in && g.e.aux_out && !g.e.bias)),
                        "mico_gemm: aux_tiled is the layout of the persistent 8-phase kernel's MLP pair (ask mico_gemm_aux_tiled_elems first)");
         // Round quantisation: T tiles on 256 CUs take ceil(T / 256) rounds and the towers' N = 1408 launches have only ~6 (M = kept frames x 257
         // rows: 257 row tiles x 6 = 6.02 rounds is SEVEN).  The row tiles beyond the last full round can go to the 256x128 two-workgroups-per-CU
         // kernel instead: the same rows as <= 512 half-size tiles in one pass (cost model below; MICO_P8_SPLIT in the build or variant 14).
         int ntm1 = g.ntm;
-        if ((MICO_P8_SPLIT && g_mico_gemm_variant != 13) || g_mico_gemm_variant == 14) {
+        if (((MICO_P8_SPLIT && g_mico_gemm_variant != 13) || g_mico_gemm_variant == 14) && !g.e.aux_tiled) {      // (a tiled aux tensor belongs to ONE persistent launch)
             const int ntn128 = (int)((N + 127) / 128);
             auto cost = [&](int rows_big) {
                 const long big_tiles = (long)rows_big * g.ntn, small_tiles = (long)(g.ntm - rows_big) * ntn128;

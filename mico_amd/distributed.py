@@ -178,6 +178,23 @@ def fetch_rows(local, global_idx):
     return _FetchRows.apply(local, global_idx)
 
 
+_STAGED = [0]
+
+
+class staged_backward:
+    """Context of a backward pass that runs INSIDE a forward (MiCo.forward(backward_scale=...): the BERT passes of one condition set): the
+    parameters it reaches may be reached again by later staged passes and by the step's final backward, so GradBucketReducer's
+    per-parameter hooks must not count these accumulations - the buckets of such parameters are reduced when the final backward completes them,
+    or by finish()."""
+
+    def __enter__(self):
+        _STAGED[0] += 1
+
+    def __exit__(self, *exc):
+        _STAGED[0] -= 1
+        return False
+
+
 class GradBucketReducer:
     """Bucketed data-parallel gradient averaging overlapped with backward (the role DDP plays at
     data/utils/build_model.py:57).  Parameters are grouped in reverse registration order into flat fp32 buckets; when the
@@ -250,6 +267,8 @@ class GradBucketReducer:
         self._early_slices = []
 
     def _hook(self, p):
+        if _STAGED[0]:      # a staged backward inside the forward: not the parameter's last accumulation of the step (see staged_backward)
+            return
         bi = self._where[p]
         self._pending[bi] -= 1
         if self._seen.get(id(p), 0) > 0:

@@ -321,8 +321,16 @@ def _gemm_dx(dy16, plist, tag, out, k_pad=None, n_pad=None, ln=True, **epi):
 def _aux_buf(M, N, K, dt, dev):
     """(buffer, tiled) for an MLP's gelu'(pre-activation) tensor between its forward GEMM and its backward (ops.aux_buffer).  Row-major where one
     of the two launches leaves the 16-bit persistent kernel: fp8 mode (the dX launch is an MX-fp8 one), the parity configuration (activation
-    [hi | lo]: three k-segments)."""
-    return ops.aux_buffer(M, N, K, dt, dev, tiled_ok=not (runtime.fp8_enabled() or runtime.split_precision()))
+    [hi | lo]: three k-segments; the weights-split head blocks of the timed precision - x W_hi + x W_lo on the wrapped A stream - stay tiled).
+    The same buffer carries the PRE-ACTIVATION where the block keeps that instead (_mlp_keeps_pre)."""
+    return ops.aux_buffer(M, N, K, dt, dev, tiled_ok=not (runtime.fp8_enabled() or runtime.split_activations()))
+
+
+def _mlp_keeps_pre():
+    """A plain-MLP tower block that keeps its MLP intermediates keeps ONE 16-bit tensor - the fc1 pre-activation h - instead of gelu(h) and gelu'(h)
+    (runtime.CFG.mlp_keep_pre, round 6): fc2's input-gradient launch multiplies by gelu'(h) computed from it and re-creates gelu(h) for fc2's weight
+    gradient in the same epilogue (MICO_ACT_GELU_GRAD with aux_in and aux_out).  Not in fp8 mode (its dX launch has the multiply epilogue only)."""
+    return runtime.CFG.mlp_keep_pre and not runtime.fp8_enabled()
 
 
 def _qkv_params(P, b, arch):
@@ -686,7 +694,13 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
                 a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
             else:
                 act = _empty((M2, Hd), dt, dev)
-                if (save and diet.keep_mlp[i]) or runtime.fp8_enabled() or not runtime.CFG.fc1_plain_gelu:   # (the 8-phase fp8 kernel has the pair epilogue only)
+                if save and diet.keep_mlp[i] and _mlp_keeps_pre():
+                    # the block keeps its pre-activation (2 hidden bytes per token): GELU with the pre-activation copy leaving from the registers
+                    h, h_tiled = _aux_buf(M2, Hd, D, dt, dev)
+                    _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU, aux_tiled=h_tiled)
+                    a.update(h=h, h_tiled=h_tiled, pre=True)
+                    del h
+                elif (save and diet.keep_mlp[i]) or runtime.fp8_enabled() or not runtime.CFG.fc1_plain_gelu:   # (the 8-phase fp8 kernel has the pair epilogue only)
                     h, h_tiled = _aux_buf(M2, Hd, D, dt, dev)
                     _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU_SAVE_DERIV, aux_tiled=h_tiled)
                     if diet.keep_mlp[i]:
@@ -825,7 +839,8 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
             else:
                 w1, w2 = P(b + "mlp.fc1.weight"), P(b + "mlp.fc2.weight")
                 fold2 = False
-                if "act" not in a:
+                kept_pre = bool(a.get("pre"))      # the block kept its fc1 pre-activation only (_mlp_keeps_pre)
+                if "act" not in a and not kept_pre:
                     # activation diet: the LayerNorm output (from the saved rows - fp32: compact kept rows or the whole stream, in either case
                     # exactly the M2 rows the forward normalised; or their fp16 normalised form), then fc1 + GELU / GELU' as the forward ran them
                     ln2b = a["ln2b"]
@@ -839,9 +854,17 @@ def _tower_backward(spec, params, saved, dout, grads, final=True):
                     fold2 = _ln_fold_ok(a, dt)   # ... and need not be: the gradient is taken against the normalised rows (below)
                     if not fold2:
                         _, a["ln2"], _, _ = _ln16(a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), spec.eps, M2, D, dt, dev, x_normalized=a["xn"])
-                linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
-                dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
-                _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX, aux_tiled=a["h_tiled"])   # a["h"] = gelu'(pre-activation)
+                if kept_pre:
+                    # dH = (g16 W2) . gelu'(h) with gelu(h) re-created by the same epilogue - then fc2's weight gradient against it
+                    dh, gact = _empty((M2, Hd), dt, dev), _empty((M2, Hd), dt, dev)
+                    _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], aux_out=gact, act=ops.ACT_GELU_GRAD, aux_tiled=a["h_tiled"])
+                    a["h"] = None
+                    linear_wgrad(g16, gact, G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
+                    del gact
+                else:
+                    linear_wgrad(g16, a["act"], G(b + "mlp.fc2.weight"), inv_s, dbias=G(b + "mlp.fc2.bias"))
+                    dh = a["act"]   # the GELU output is dead after the weight gradient: reuse its storage for dH
+                    _gemm_dx(g16, [w2], "w", dh, ln=False, aux_in=a["h"], act=ops.ACT_MUL_AUX, aux_tiled=a["h_tiled"])   # a["h"] = gelu'(pre-activation)
                 if fold2:
                     _wgrad_ln_folded(dh, a["x2"], P(b + "norm2.weight"), P(b + "norm2.bias"), G(b + "mlp.fc1.weight"), G(b + "mlp.fc1.bias"), inv_s)
                 else:
@@ -980,7 +1003,8 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     postnorm = bool(spec.arch.get("postnorm"))
     dietable = not spec.arch["swiglu"] and not postnorm
     # (the post-norm block saves fp32 br1 / br2 (8 D), x16a / x16b / ao (6 D), qkv (6 D), act + h (4 hidden): the same 20 D + 4 hidden per token)
-    per_frame = {0: depth * N * (20 * D + 4 * Hd)}
+    mlp_b = 2 if (dietable and _mlp_keeps_pre()) else 4      # bytes per hidden unit of a kept token: the pre-activation alone, or gelu + gelu'
+    per_frame = {0: depth * N * (20 * D + mlp_b * Hd)}
     if dietable:
         per_frame[1] = depth * N * 20 * D
         per_frame[2] = depth * N * 16 * D
@@ -997,7 +1021,10 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     # what the rest of the step needs next to the tower's saved activations - the backward's temporaries, BERT with its cross-attention K/V
     # over frames x N condition tokens, the gradient arena: measured 23 GiB at 320 frames (configs[2]: 162 GiB peak, 139 of it activations)
     # and 57 GiB at 896 (one rank of configs[3]: 231 GiB peak at level 2, 266 GiB at level 1)
-    headroom = (12 << 30) + n_frames * (52 << 20)
+    # A staged step (MiCo.forward(backward_scale=...), round 6) builds and differentiates the BERT passes one condition set at a time: one K/V memory,
+    # one set of graphs and gradient buffers on top of the tower stash instead of all of them - measured on one rank of configs[3]: 36.8 GiB between
+    # the end of encode_batch and the step's peak (inside the va set's backward) against 56 for the direct form.
+    headroom = (12 << 30) + n_frames * ((30 << 20) if runtime.step_staged else (52 << 20))
     # Two budgets for the saved activations.  HARD: what fits at all - 0.90 of the free memory beyond the headroom (0.95 put one rank of
     # configs[3] on level 1 at a 268 of 288 GiB peak).  SOFT: what keeps the step's projected peak (allocated now + headroom + activations)
     # under MICO_HBM_SOFT_FRAC of the device memory - the margin a data-parallel job needs for RCCL's buffers, a second reducer and allocator
@@ -1008,12 +1035,16 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     # that the hard budget avoids (> 0.05 of a tower forward dearer): memory margin is worth a LayerNorm recompute, not half a forward.
     total = torch.cuda.get_device_properties(device).total_memory
     hard = int(0.90 * max(free - headroom, free // 4))
-    soft = min(hard, int(_SOFT_FRAC * total) - torch.cuda.memory_allocated(device) - headroom)
-    kept = min(1.0, max(0.05, kept + 0.02))      # (a little slack: the draw differs from chunk to chunk)
-    if block_tokens is None or len(block_tokens) != depth:
+    soft_frac = _SOFT_FRAC
+    if "MICO_HBM_SOFT_FRAC" not in os.environ and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # a rank of an N > 1 job: RCCL's buffers, the reducer's fp32 buckets and the fragmentation they cause have only been measured on a one-rank
+        # group (no multi-GPU box this far): 0.03 of the device stay free for them until a scaling run confirms the one-rank figure
+        soft_frac -= 0.03
+    soft = min(hard, int(soft_frac * total) - torch.cuda.memory_allocated(device) - headroom)
+    exact = block_tokens is not None and len(block_tokens) == depth      # the step's own stochastic-depth draw, counted: no slack needed
+    if not exact:
+        kept = min(1.0, max(0.05, kept + 0.02))      # (a little slack: the draw differs from chunk to chunk)
         block_tokens = [kept * n_frames * N] * depth
-    else:
-        block_tokens = [t * (kept / max(kept - 0.02, 1e-6)) for t in block_tokens]      # (the same slack)
     # what re-running fc1 costs per kept token of block i, relative to a plain block: the head-split blocks of the timed precision
     # (runtime.CFG.head_split_blocks: x W_hi + x W_lo, K doubled) cost twice - their intermediates are the most valuable bytes to keep
     fc1_w = [runtime.fc1_recompute_weight(i, bool(spec.arch["swiglu"])) for i in range(depth)]
@@ -1037,11 +1068,15 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
                 # live until the END of the backward keep the allocator at the peak for the whole backward.)  A kept block saves its share of
                 # the fc1 recompute, weighted by what its recompute costs.
                 left = budget - pf * n_frames - _MLP_KEEP_MARGIN
-                order = list(reversed(range(depth)))
+                # (round 6, with ONE tensor per kept block nearly every block fits: the blocks whose recompute is dearest first - the head-split
+                # blocks' fc1 has twice the reduction length - then from the last block backwards; a block that does not fit is skipped, not the end)
+                order = sorted(range(depth), key=lambda i: (-fc1_w[i], -i)) if mlp_b == 2 else list(reversed(range(depth)))
                 keep, saved = [], 0.0
                 for i in order:
-                    need = block_tokens[i] * 4 * Hd
+                    need = block_tokens[i] * mlp_b * Hd
                     if need > left:
+                        if mlp_b == 2:
+                            continue
                         break
                     left -= need
                     saved += fc1_w[i] * block_tokens[i]
@@ -1090,7 +1125,8 @@ class EvaTowerFn(torch.autograd.Function):
             def record(**more):
                 runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet.level, mlp_blocks_kept=diet.mlp_blocks,
                                                mlp_blocks=_ranges([i for i, k in enumerate(diet.keep_mlp) if k]) if diet.level == 3 else None,
-                                               rows_fp16_normalised=diet.xh16, kept_fraction=kept, **more)
+                                               rows_fp16_normalised=diet.xh16, kept_fraction=kept,
+                                               mlp_stash=("pre-activation (2 B per hidden unit)" if _mlp_keeps_pre() else "gelu + gelu' (4 B per hidden unit)"), **more)
             record()
             if (Bf, min(chunk, Bf), diet.level, tuple(diet.keep_mlp)) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
                 EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet.level, tuple(diet.keep_mlp))
@@ -1545,7 +1581,17 @@ class CrossKVFn(torch.autograd.Function):
         dev = cond16.device
         inv_s = 1.0 / runtime.grad_scale()
         if ctx.session is not None:
-            ctx.session.reset()
+            sess = ctx.session
+            # The session's contract: the buffer the first reader registered IS the gradient the engine hands over here - later readers
+            # added to it in place and returned None.  Were it ever copied or cast on the way (a tensor hook, another producer stream's InputBuffer
+            # path, a future engine), those additions would sit in an orphan buffer and the K/V weight and condition-token gradients would be short -
+            # silently.  Checked by address; MICO_DKV_PER_PASS=1 is the way out.
+            if sess.own is not None and not sess.closed and (dkv_own is None or dkv_own.data_ptr() != sess.own.data_ptr()
+                                                             or tuple(dkv_own.shape) != tuple(sess.own.shape)):
+                sess.reset()
+                raise RuntimeError("CrossKVFn.backward: the gradient of the shared own K/V set is not the buffer its readers accumulated into "
+                                   "(functional.DkvSession) - set MICO_DKV_PER_PASS=1 (one buffer per pass, summed by autograd)")
+            sess.reset()
         parts = [(dkv_own, cond16[:n * E])]
         if ctx.sets == 2:
             parts.append((dkv_neg, cond16[n * E:]))
@@ -1767,7 +1813,8 @@ class BertFn(torch.autograd.Function):
         # DkvSession: the passes that read one own set share ONE gradient buffer for it.  acc_own = the buffer an earlier backward of this pass
         # wrote (this one adds to it in the attention kernel and returns None for kv_own).  Only when the engine wants kv_own's gradient in this
         # pass at all - then CrossKVFn.backward runs after every reader and ends the session.
-        sess = ctx.dkv_session if (kv_il and runtime.CFG.dkv_inplace and ctx.needs_input_grad[5]) else None
+        # (and only under an engine that can tell backward passes apart - the condition GradArena.session has: without it, a buffer per pass)
+        sess = ctx.dkv_session if (kv_il and runtime.CFG.dkv_inplace and ctx.needs_input_grad[5] and hasattr(torch._C, "_current_graph_task_id")) else None
         acc_own = None
         if sess is not None and sess.own is not None and not sess.closed:
             if (ops.attn_bwd_smallq_ok(n_own, H, S, E, hd, at_drop(SITE_CROSS_P), batch0=2 * n_own if has_neg else 0)

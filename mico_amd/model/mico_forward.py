@@ -95,9 +95,12 @@ def _condition_feats(self, enc, cond):
     return torch.cat([enc["condition_feats_" + m] for m in cond], dim=1)
 
 
-def _forward_ret(self, batch, enc, subtasks, itm=True):
+def _forward_ret(self, batch, enc, subtasks, itm=True, deferred=None):
     """ITC + ITM of vast.py:395-457.  itm=False: the contrastive objective alone (step-A of SURVEY.md section 8d, BASELINE configs[1]) - the
-    ITM hard-negative passes are not run and no "loss_itm" is returned (task prefix "itc%...", an addition of this repo)."""
+    ITM hard-negative passes are not run and no "loss_itm" is returned (task prefix "itc%...", an addition of this repo).
+    deferred (dict, staged differentiation - forward(backward_scale=...)): the ITM passes are not run here either; their inputs - the hard-negative
+    draws (same random numbers in the same order as the direct form), the triplet's token ids and masks - are left in deferred[subtask] for
+    _staged_groups, and only "loss_itc" is returned."""
     inj = batch.get("_injected", {})
     world = batch.get("_world")
     ids, am = _tokens(self, batch)
@@ -122,7 +125,7 @@ def _forward_ret(self, batch, enc, subtasks, itm=True):
         if not itm:
             continue
         # ---- ITM hard negatives (vast.py:421-457) ----
-        cond = _condition_feats(self, enc, st[1:])
+        cond = _condition_feats(self, enc, st[1:]) if deferred is None else None
         if st in inj:
             neg_c, neg_t = inj[st]["neg_cond_idx"].to(ids.device), inj[st]["neg_text_idx"].to(ids.device)
         else:
@@ -133,12 +136,15 @@ def _forward_ret(self, batch, enc, subtasks, itm=True):
                 torch.rand(bs, device=ids.device), torch.rand(bs, device=ids.device))
             neg_c = ops.itm_sample(sim_t2c.detach(), rank * bs, u_c.float())
             neg_t = ops.itm_sample(sim_c2t.detach(), rank * bs, u_t.float())
+        ids1 = torch.cat((ids, ids, ids_all[neg_t]), dim=0)
+        am1 = torch.cat((am, am, mask_all[neg_t]), dim=0)
+        if deferred is not None:
+            deferred[st] = dict(neg_c=neg_c, ids1=ids1, am1=am1, fetch=world[f"cond_{st[1:]}_fetch"] if world else D.fetch_rows)
+            continue
         if world:
             cond_neg = world[f"cond_{st[1:]}_fetch"](cond, neg_c)
         else:
             cond_neg = D.fetch_rows(cond, neg_c)
-        ids1 = torch.cat((ids, ids, ids_all[neg_t]), dim=0)
-        am1 = torch.cat((am, am, mask_all[neg_t]), dim=0)
         if _share_cross_kv(self):
             # the triplet [own | hard negative | own] holds the batch's own condition tokens twice and the captioning pass reads
             # them again: their K/V projections are computed once per step (functional.CrossKVFn) and kept for _forward_cap
@@ -152,9 +158,19 @@ def _forward_ret(self, batch, enc, subtasks, itm=True):
         gt = torch.zeros(bs * 3, dtype=torch.long, device=ids.device)
         gt[:bs] = 1
         loss_itm.append(self.itm_ratio * Fn.cross_entropy(logits, gt))
-    if not itm:
+    if not itm or deferred is not None:
         return {"loss_itc": sum(loss_itc) / len(loss_itc)}
     return {"loss_itc": sum(loss_itc) / len(loss_itc), "loss_itm": sum(loss_itm) / len(loss_itm)}
+
+
+def _itm_loss(self, kv, ids1, am1):
+    """The ITM pass over the triplet [own | hard negative | own] against a shared K/V memory, and its loss (vast.py:438-457)."""
+    bs = ids1.shape[0] // 3
+    out = self.multimodal_encoder.bert(input_ids=ids1, attention_mask=am1, cross_kv=kv).last_hidden_state
+    logits = self.itm_head(out[:, 0])
+    gt = torch.zeros(bs * 3, dtype=torch.long, device=ids1.device)
+    gt[:bs] = 1
+    return self.itm_ratio * Fn.cross_entropy(logits, gt)
 
 
 def _share_cross_kv(self):
@@ -162,7 +178,8 @@ def _share_cross_kv(self):
     return runtime.CFG.share_cross_kv and torch.is_grad_enabled()
 
 
-def _forward_cap(self, batch, enc, subtasks):
+def _cap_inputs(self, batch):
+    """masked token ids, labels (TokenMasker at 0.6 or the injected draw) and the causal 3-D mask of the captioning pass (vast.py:489-499)."""
     inj = batch.get("_injected", {})
     ids, am = _tokens(self, batch)
     if "cap" in inj:
@@ -171,6 +188,11 @@ def _forward_cap(self, batch, enc, subtasks):
         masked_ids, labels = self.text_masker(ids, 0.6)
     S = am.shape[1]
     m3 = torch.tril(am.unsqueeze(1).expand(-1, S, -1)).contiguous()                       # vast.py:497-499
+    return masked_ids, labels, m3
+
+
+def _forward_cap(self, batch, enc, subtasks):
+    masked_ids, labels, m3 = _cap_inputs(self, batch)
     losses = []
     for st in subtasks:
         kv = enc.get("_cross_kv", {}).get(st[1:]) if _share_cross_kv(self) else None
@@ -183,12 +205,114 @@ def _forward_cap(self, batch, enc, subtasks):
     return {"loss_cap": sum(losses) / len(losses)}
 
 
-def forward(self, batch, task, compute_loss=True):
-    """Returns {"loss_itc", "loss_itm", "loss_cap"} for task strings like "ret%tva%tv_cap%tva" (vast.py:317-348)."""
+class _StagedLoss(torch.autograd.Function):
+    """The hand-over of a staged step (forward(backward_scale=...)): `value` is a loss that has ALREADY been differentiated through BERT inside
+    forward, `grads[i]` = d(scale * sum of the staged losses) / d(tensors[i]) for the tower-side tensors the BERT passes read (the per-modality
+    condition tokens).  The caller's backward of scale * (sum of the returned losses) arrives here with grad_output = scale and hands those
+    gradients to the towers' graph (multiplied by grad_output / scale on the device - 1 when the caller keeps its side of the contract)."""
+
+    @staticmethod
+    def forward(ctx, value, scale, n, *tg):
+        ctx.scale, ctx.n, ctx.grads = scale, n, tg[n:]
+        return value.detach().clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        f = (go / ctx.scale).to(torch.float32)
+        grads, ctx.grads = ctx.grads, None
+        return (None, None, None) + tuple(g.mul_(f) for g in grads) + (None,) * ctx.n
+
+
+def _forward_staged(self, batch, task, enc, scale):
+    """forward(compute_loss=True) with the BERT passes differentiated ONE CONDITION SET AT A TIME inside the forward (round 6).
+    The direct form builds every ITM / captioning graph, their cross-attention K/V memories and, in the backward, their gradients on top of the
+    towers' complete activation stash (profiles/r05_mem_trace.txt: the step's peak is the second triplet's BertFn.backward).  Here the towers'
+    condition tokens are cut out of the graph (detached leaves, one per modality), and for each condition set (e.g. "va": the tva triplet + the
+    captioning pass that shares its K/V memory) the losses are built AND differentiated at once with the factor the caller will apply (`scale`:
+    GradScaler's loss scale, 1.0 without one) - BERT-side parameter gradients go to .grad right away, the token gradients accumulate on the
+    leaves, and the set's graph, K/V memory and gradient buffers are gone before the next set is built.  The returned losses carry one
+    _StagedLoss node that hands the accumulated token gradients to the towers when the caller differentiates the sum.  Same loss values and
+    gradients as the direct form (same kernels on the same numbers; only the order in which autograd sums the token gradients differs);
+    random draws (hard negatives, token masks) happen in the direct form's order, BERT's per-pass dropout seeds are drawn in pass order, which
+    differs.  Contract: the caller calls backward() ONCE on scale * (unit-weight sum of the returned losses), after zero_grad - parameter
+    gradients of the BERT side are already in .grad when forward returns."""
+    ret_sub, cap_sub, out = [], [], {}
+    deferred = {}
+    for t in task.split("_"):
+        subtasks = t.split("%")[1:]
+        for st in subtasks:
+            assert st in SUBTASKS, st
+        if t.startswith("ret"):
+            out.update(_forward_ret(self, batch, enc, subtasks, deferred=deferred))
+            ret_sub += subtasks
+        elif t.startswith("itc"):
+            out.update(_forward_ret(self, batch, enc, subtasks, itm=False))
+        elif t.startswith("cap"):
+            cap_sub += subtasks
+        else:
+            raise NotImplementedError(t)
+    cap_in = _cap_inputs(self, batch) if cap_sub else None
+    keys = []
+    for st in ret_sub + cap_sub:
+        if st[1:] not in keys:
+            keys.append(st[1:])
+    leaves = {}
+    sums = {"loss_itm": None, "loss_cap": None}
+    from ..distributed import staged_backward
+    for key in keys:
+        for m in key:
+            if m not in leaves:
+                leaves[m] = enc["condition_feats_" + m].detach().requires_grad_(True)
+        cond = torch.cat([leaves[m] for m in key], dim=1) if len(key) > 1 else leaves[key]
+        total, kv = None, None
+        itm_sts = [st for st in ret_sub if st[1:] == key]
+        for st in itm_sts:
+            d = deferred[st]
+            kv = self.multimodal_encoder.bert.project_cross_kv(cond, d["fetch"](cond, d["neg_c"]))
+            l = _itm_loss(self, kv, d["ids1"], d["am1"]) / len(ret_sub)
+            sums["loss_itm"] = l.detach() if sums["loss_itm"] is None else sums["loss_itm"] + l.detach()
+            total = l if total is None else total + l
+        for st in cap_sub:
+            if st[1:] != key:
+                continue
+            masked_ids, labels, m3 = cap_in
+            if kv is not None and len(itm_sts) == 1:     # the retrieval branch of this set projected these condition tokens
+                l = self.multimodal_encoder(input_ids=masked_ids, attention_mask=m3, cross_kv=(kv[0], None), labels=labels).loss
+            else:
+                l = self.multimodal_encoder(input_ids=masked_ids, attention_mask=m3, encoder_hidden_states=cond, labels=labels).loss
+            l = l / len(cap_sub)
+            sums["loss_cap"] = l.detach() if sums["loss_cap"] is None else sums["loss_cap"] + l.detach()
+            total = l if total is None else total + l
+        del kv
+        runtime.mem_trace("staged set " + key + ": graph built")
+        with staged_backward():
+            torch.autograd.backward(total * scale)
+        del total, l, cond
+        runtime.mem_trace("staged set " + key)
+    first = True
+    for k, v in sums.items():
+        if v is None:
+            continue
+        if first and leaves:      # ONE node carries every condition-token gradient
+            ms = list(leaves)
+            v = _StagedLoss.apply(v, float(scale), len(ms), *[enc["condition_feats_" + m] for m in ms], *[leaves[m].grad for m in ms])
+            first = False
+        out[k] = v
+    return out
+
+
+def forward(self, batch, task, compute_loss=True, backward_scale=None):
+    """Returns {"loss_itc", "loss_itm", "loss_cap"} for task strings like "ret%tva%tv_cap%tva" (vast.py:317-348).
+    backward_scale (float; None = the direct form): staged differentiation, see _forward_staged - the factor the caller multiplies the summed
+    losses with before its single backward() (1.0, or GradScaler.get_scale())."""
     batch = dict(batch) if not isinstance(batch, dict) else batch
     runtime.mem_trace("step start")
+    staged = backward_scale is not None and compute_loss and torch.is_grad_enabled() and _share_cross_kv(self)
+    runtime.step_staged = staged      # (functional.tower_plan: a staged step needs less memory next to the towers' saved activations)
     enc = encode_batch(self, batch)
     runtime.mem_trace("after encode_batch")
+    if staged:
+        return _forward_staged(self, batch, task, enc, float(backward_scale))
     out = {}
     for t in task.split("_"):
         subtasks = t.split("%")[1:]

@@ -104,9 +104,16 @@ def gemm(A, B, out, *, ta=False, tb=False, M=None, N=None, K=None, bias=None, au
     e.aux_in = _p(aux_in)
     aux = aux_out if aux_out is not None else aux_in
     e.ldaux = aux.stride(0) if aux is not None else 0
+    if aux_out is not None and aux_in is not None:
+        # GELU_GRAD with both (the pre-activation-keeping MLP pair): aux_in = the pre-activation (tiled with aux_tiled), aux_out = gelu(aux_in), always
+        # row-major; one leading dimension serves both
+        if act != ACT_GELU_GRAD or (not aux_tiled and aux_in.stride(0) != aux_out.stride(0)):
+            raise MicoHipError("mico_gemm: aux_in together with aux_out is the GELU_GRAD launch that also writes gelu(aux_in); both row-major tensors share ldaux")
     if aux_tiled:
-        _check_tiled(aux, M, N)
-        e.aux_tiled, e.ldaux = 1, N
+        _check_tiled(aux_in if aux_in is not None else aux, M, N)
+        e.aux_tiled = 1
+        if aux_out is None or aux_in is None:
+            e.ldaux = N
     e.act = act
     e.row_scale = _p(row_scale)
     e.rows_per_scale = rows_per_scale

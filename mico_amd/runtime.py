@@ -58,6 +58,10 @@ class _Cfg:
     # fc1 of a tower forward that keeps no GELU' (no backward, or the activation diet recomputes the pair) runs the GELU-only epilogue
     # (half the output bytes); MICO_FC1_PAIR_ALWAYS=1: the pair epilogue everywhere (A/B runs)
     fc1_plain_gelu = os.environ.get("MICO_FC1_PAIR_ALWAYS") is None
+    # a tower block that keeps its MLP intermediates keeps ONE 16-bit tensor, the fc1 pre-activation, instead of gelu and gelu' (functional.
+    # _mlp_keeps_pre: half the bytes per kept block, i.e. twice the blocks without an fc1 recompute in a given budget); MICO_MLP_STASH=pair: the
+    # round-5 form (A/B runs)
+    mlp_keep_pre = os.environ.get("MICO_MLP_STASH", "pre") != "pair"
 
 
 CFG = _Cfg()
@@ -347,6 +351,7 @@ def gemm_weight(plist, tag="w", k_pad=None, n_pad=None, channel_sum=False, ln_fe
 
 
 _tower_chunk = None
+step_staged = False      # the current step differentiates its BERT passes inside the forward (MiCo.forward(backward_scale=...)); read by functional.tower_plan
 
 
 def tower_chunk_override():

@@ -72,6 +72,25 @@ def _worker(rank, world, port, ret):
         res = {k: float(v) for k, v in out.items()}
         g = m.contra_head_va.weight.grad.detach().float().cpu().clone()
         g2 = m.vision_encoder.visual.blocks[0].mlp.w1.weight.grad.detach().float().cpu().clone()
+        # pass 3: the staged form (MiCo.forward(backward_scale=...): BERT differentiated inside the forward, round 6) under a reducer - the BERT-side
+        # parameters are accumulated more than once per step (staged passes + the final backward's text pass), which the bucket hooks must not count
+        # (distributed.staged_backward); the averaged gradients must be pass 2's
+        want = {k: p.grad.detach().float().clone() for k, p in probe.items()}
+        want["cross k"] = m.multimodal_encoder.bert.encoder.layer[2].crossattention.self.key.weight.grad.detach().float().clone()
+        probe3 = dict(probe, **{"cross k": m.multimodal_encoder.bert.encoder.layer[2].crossattention.self.key.weight})
+        red.close()      # (pass 2's reducer: its hooks would fire next to the new one's)
+        red = GradBucketReducer(m.parameters(), bucket_bytes=64 << 20)
+        m.zero_grad(set_to_none=True)
+        out3 = m(dict(batch), "ret%tva_cap%tva", backward_scale=4.0)
+        (sum(out3.values()) * 4.0).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        for k in out3:
+            assert abs(float(out3[k]) - res[k]) < 1e-4 * max(1.0, abs(res[k])), (k, float(out3[k]), res[k])
+        for k, p in probe3.items():
+            err = (p.grad.float() / 4.0 - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-20)
+            assert err < 2e-3, ("staged", k, float(err))
+        red.close()
         # ---- single-process reference of THIS rank's loss on the global batch (simulated world) ----
         if rank == 0:
             with torch.no_grad():

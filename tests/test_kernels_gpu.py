@@ -179,6 +179,64 @@ def test_mlp_pair_tiled_aux_matches_row_major(cuda, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(40000, 768, 256), (33001, 1536, 1408)])
+def test_mlp_pair_keeping_the_pre_activation(cuda, dtype, M, N, K):
+    """Round 6: the MLP pair that keeps ONE tensor.  Forward = MICO_ACT_GELU with aux_out = the pre-activation copy, fc2's dX = MICO_ACT_GELU_GRAD with
+    aux_in = that copy and aux_out = gelu(copy) (the operand of fc2's weight gradient).  The tiled instantiations of the persistent kernel
+    (ACT_PRE_TILED / ACT_GRAD_TILED) against the row-major launches of the shared epilogue bit for bit, the tiled image against the row-major
+    pre-activation, and everything against fp32 torch."""
+    from mico_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + 1)
+    x = (0.5 * torch.randn(M, K, generator=g)).to(cuda).to(dtype)
+    w1 = (0.05 * torch.randn(N, K, generator=g)).to(cuda).to(dtype)
+    bias = torch.randn(N, generator=g).to(cuda)
+    dy = torch.randn(M, 512, generator=g).to(cuda).to(dtype)
+    w2 = (0.05 * torch.randn(512, N, generator=g)).to(cuda).to(dtype)       # dH = dy @ w2 : [M, N] over K2 = 512
+    # row-major (shared epilogue)
+    act_r, h_r = torch.empty(M, N, device=cuda, dtype=dtype), torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(x, w1, act_r, bias=bias, aux_out=h_r, act=ops.ACT_GELU)
+    dh_r, ga_r = torch.empty(M, N, device=cuda, dtype=dtype), torch.full((M, N), float("nan"), device=cuda, dtype=dtype)
+    ops.gemm(dy, w2, dh_r, tb=True, M=M, N=N, K=512, aux_in=h_r, aux_out=ga_r, act=ops.ACT_GELU_GRAD, alpha=0.5)
+    pre = x.float() @ w1.float().t() + bias
+    assert rel_err(h_r, pre) < tol(dtype) and rel_err(act_r, F.gelu(pre)) < tol(dtype)
+    hf = h_r.float()
+    gp = 0.5 * (1 + torch.erf(hf / math.sqrt(2))) + hf * torch.exp(-0.5 * hf * hf) / math.sqrt(2 * math.pi)
+    assert rel_err(ga_r, F.gelu(hf)) < tol(dtype)
+    assert rel_err(dh_r, 0.5 * (dy.float() @ w2.float()) * gp) < tol(dtype)
+    # the GELU output does not depend on whether (or how) the pre-activation is kept
+    act_g = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(x, w1, act_g, bias=bias, act=ops.ACT_GELU)
+    assert torch.equal(act_g.view(torch.int16), act_r.view(torch.int16))
+    # tiled
+    h_t, tiled = ops.aux_buffer(M, N, K, dtype, cuda)
+    assert tiled
+    h_t.fill_(float("nan"))
+    act_t = torch.empty(M, N, device=cuda, dtype=dtype)
+    ops.gemm(x, w1, act_t, bias=bias, aux_out=h_t, act=ops.ACT_GELU, aux_tiled=True)
+    assert ops._lib.lib().mico_gemm_last_kernel() == 8
+    assert torch.equal(act_t.view(torch.int16), act_r.view(torch.int16))
+    t = h_t.view(-1)[:((M + 255) // 256) * (N // 256) * 65536].view((M + 255) // 256, N // 256, 2, 4, 8, 2, 4, 16, 2, 4)   # tm tn wm wn i jj gq p half c
+    rows = h_r.new_zeros(((M + 255) // 256) * 256, N)
+    rows[:M] = h_r
+    r5 = rows.view((M + 255) // 256, 2, 2, 4, 16, N // 256, 2, 4, 2, 4, 4)        # tm ihi wm ilo p | tn jj wn half gq c
+    want = r5.permute(0, 5, 2, 7, 1, 3, 6, 9, 4, 8, 10).reshape(t.shape)
+    live = torch.zeros_like(rows, dtype=torch.bool)
+    live[:M] = True
+    lv = live.view((M + 255) // 256, 2, 2, 4, 16, N // 256, 2, 4, 2, 4, 4).permute(0, 5, 2, 7, 1, 3, 6, 9, 4, 8, 10).reshape(t.shape)
+    assert torch.equal(t[lv].view(torch.int16), want[lv].view(torch.int16))
+    dh_t, ga_t = torch.empty(M, N, device=cuda, dtype=dtype), torch.full((M, N), float("nan"), device=cuda, dtype=dtype)
+    ops.gemm(dy, w2, dh_t, tb=True, M=M, N=N, K=512, aux_in=h_t, aux_out=ga_t, act=ops.ACT_GELU_GRAD, alpha=0.5, aux_tiled=True)
+    assert ops._lib.lib().mico_gemm_last_kernel() == 8
+    assert torch.equal(dh_t.view(torch.int16), dh_r.view(torch.int16))
+    assert torch.equal(ga_t.view(torch.int16), ga_r.view(torch.int16))
+    # refused: the tiled GELU_GRAD launch takes no bias (its epilogue has no registers for one); a buffer that is too small
+    with pytest.raises(ops.MicoHipError):
+        ops.gemm(dy, w2, dh_t, tb=True, M=M, N=N, K=512, bias=bias, aux_in=h_t, aux_out=ga_t, act=ops.ACT_GELU_GRAD, aux_tiled=True)
+    with pytest.raises(ops.MicoHipError):
+        ops.gemm(dy, w2, dh_t, tb=True, M=M, N=N, K=512, aux_in=h_r, aux_out=ga_t, act=ops.ACT_GELU_GRAD, aux_tiled=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cols", [768, 1408, 2048])
 @pytest.mark.parametrize("xdt", ["f32", "16"])
 def test_layernorm(cuda, dtype, cols, xdt):

@@ -354,6 +354,46 @@ def test_shared_cross_kv_equals_per_pass_projection(setup, cuda):
         assert any("crossattention.self.key.weight" in n for n in res[key][1])
 
 
+def test_staged_backward_equals_direct(setup, cuda):
+    """MiCo.forward(backward_scale=...) (round 6: the BERT passes differentiated one condition set at a time inside the forward, the condition-token
+    gradients handed to the towers by one _StagedLoss node) against the direct form: same losses, same gradients for every parameter - towers, BERT,
+    heads - also with a loss scale other than 1 (the caller's backward of scale * sum)."""
+    vtype, tag, m, sd = setup
+    fx = golden(f"loss_{tag}.pt")
+    r = fx["W1"]
+    b = fx["meta"]["b"]
+    batch0 = to_dev(synth_inputs(dict(b=b, vision=2, audio=1, S=12), seed=1234), cuda)
+    res = {}
+    for name, scale in (("direct", None), ("staged", 1.0), ("staged-x8", 8.0)):
+        batch = dict(batch0)
+        batch["_injected"] = {st: {k: r["inj"][st][k] for k in ("neg_cond_idx", "neg_text_idx")} for st in ("tva", "tv")}
+        batch["_injected"]["cap"] = r["inj"]["cap"]
+        with runtime.precision(torch.float16):
+            m.zero_grad(set_to_none=True)
+            out = m(batch, fx["meta"]["task"], compute_loss=True, backward_scale=scale)
+            if scale is not None:      # the BERT side is already differentiated: its cross-attention projections have their gradients now
+                assert any(p.grad is not None for n, p in m.named_parameters() if "crossattention.self.key.weight" in n)
+                assert all(p.grad is None for n, p in m.named_parameters() if n.startswith("vision_encoder."))
+            (sum(out.values()) * (scale or 1.0)).backward()
+        res[name] = ({k: v.item() for k, v in out.items()},
+                     {n: p.grad.clone() / (scale or 1.0) for n, p in m.named_parameters() if p.grad is not None})
+    ref_l, ref_g = res["direct"]
+    assert set(ref_l) == {"loss_itc", "loss_itm", "loss_cap"}
+    for key in ("staged", "staged-x8"):
+        for k in ref_l:
+            assert abs(res[key][0][k] - ref_l[k]) <= 2e-4 * max(1.0, abs(ref_l[k])), (key, k, res[key][0][k], ref_l[k])
+        assert set(res[key][1]) == set(ref_g)
+        worst = ("", 0.0)
+        for n, g0 in ref_g.items():
+            if n.endswith("self.key.bias"):   # analytically zero: rounding noise only
+                continue
+            e = rel_err(res[key][1][n], g0) if g0.abs().max() > 0 else float(res[key][1][n].abs().max())
+            if e > worst[1]:
+                worst = (n, e)
+        print(tag, key, "vs direct: worst gradient difference", worst)
+        assert worst[1] < 2e-3, (key, worst)
+
+
 def test_dkv_session_both_reader_orders(setup, cuda):
     """functional.DkvSession at the BertModel level, in BOTH orders of arrival: a triplet pass [own | neg | own] and an own-only pass read one shared
     K/V memory (BertModel.project_cross_kv); whichever is created last is differentiated first and writes the own set's gradient buffer, the other adds to
