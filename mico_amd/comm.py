@@ -3,6 +3,15 @@ would use, and an alternative one for mico_amd.distributed (MICO_COMM=1 or comm.
 pack kernel + ONE ncclAllGather on the compute stream, the index-then-fetch row exchange as a grouped send / receive, gradient averaging as an
 in-place all-reduce.  Stream-ordered with the kernels around them (no side stream, no event hand-over).
 
+Ordering against torch.distributed's own communicator: two communicators whose collectives can be in flight at the same time must be
+issued in the same relative order on every rank.  With MICO_COMM=1 the collectives of THIS communicator are the forward's packed all-gather and row
+exchange and the row exchange's mirrored return in the backward; GradBucketReducer's all-reduces (torch's communicator, its own stream) start inside the
+final backward and are waited for by finish() before the next forward.  In the staged form of the step (MiCo.forward(backward_scale=...)) the return
+exchange runs inside the forward, with the reducer's hooks off - the two communicators never overlap.  In the direct form the return exchange and the
+first bucket reductions can overlap in the backward: every rank issues them from the same autograd order (same task, same graph), which is what RCCL
+needs, but this has only run on a one-rank group (tests/test_distributed_gpu.py::test_mico_comm_c_abi_one_rank) - MICO_COMM stays opt-in until an
+N > 1 run has exercised it.
+
 The communicator's 128-byte id travels over whatever process group torch.distributed already has (any backend: it is a host-side broadcast);
 a program without torch.distributed distributes it by its own means and calls MicoComm(rank, nranks, id) directly."""
 import ctypes as C

@@ -159,21 +159,25 @@ extern "C" int mico_comm_alltoallv(void* comm, const void* send, const int64_t* 
     Comm* c = (Comm*)comm;
     hipStream_t st = (hipStream_t)stream;
     int64_t so = 0, ro = 0;
-    RCCL_OK(g_rccl.GroupStart(), "mico_comm_alltoallv");
+    // every argument is validated BEFORE the group opens, and an error inside it still closes it (a return between ncclGroupStart and
+    // ncclGroupEnd left the group open and wedged the thread's later RCCL calls)
     for (int p = 0; p < c->nranks; ++p) {
         MICO_CHECK(send_bytes[p] >= 0 && recv_bytes[p] >= 0, "mico_comm_alltoallv: negative count for peer %d", p);
-        if (send_bytes[p] > 0) {
-            MICO_CHECK(send != nullptr, "mico_comm_alltoallv: null send buffer");
-            RCCL_OK(g_rccl.Send((const char*)send + so, (size_t)send_bytes[p], NCCL_UINT8, p, c->c, st), "mico_comm_alltoallv (send)");
-        }
-        if (recv_bytes[p] > 0) {
-            MICO_CHECK(recv != nullptr, "mico_comm_alltoallv: null receive buffer");
-            RCCL_OK(g_rccl.Recv((char*)recv + ro, (size_t)recv_bytes[p], NCCL_UINT8, p, c->c, st), "mico_comm_alltoallv (recv)");
-        }
+        MICO_CHECK(send_bytes[p] == 0 || send != nullptr, "mico_comm_alltoallv: null send buffer");
+        MICO_CHECK(recv_bytes[p] == 0 || recv != nullptr, "mico_comm_alltoallv: null receive buffer");
+    }
+    RCCL_OK(g_rccl.GroupStart(), "mico_comm_alltoallv");
+    int rc = 0;
+    const char* where = "";
+    for (int p = 0; p < c->nranks && rc == 0; ++p) {
+        if (send_bytes[p] > 0) { rc = g_rccl.Send((const char*)send + so, (size_t)send_bytes[p], NCCL_UINT8, p, c->c, st); where = "send"; }
+        if (rc == 0 && recv_bytes[p] > 0) { rc = g_rccl.Recv((char*)recv + ro, (size_t)recv_bytes[p], NCCL_UINT8, p, c->c, st); where = "recv"; }
         so += send_bytes[p];
         ro += recv_bytes[p];
     }
-    RCCL_OK(g_rccl.GroupEnd(), "mico_comm_alltoallv");
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc != 0) return mico_set_err(MICO_ELAUNCH, "mico_comm_alltoallv (%s): RCCL error %d (%s)", where, rc, g_rccl.GetErrorString(rc));
+    RCCL_OK(rc_end, "mico_comm_alltoallv");
     return MICO_OK;
 }
 

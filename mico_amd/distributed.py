@@ -82,7 +82,9 @@ def packed_all_gather(tensors):
     if not is_dist():
         return [t.detach() for t in tensors]
     from . import comm
-    if comm.enabled() and tensors[0].is_cuda:      # MICO_COMM=1: pack kernel + one ncclAllGather on the compute stream (mico_comm_allgather_packed)
+    # MICO_COMM=1: pack kernel + one ncclAllGather on the compute stream (mico_comm_allgather_packed: at most 8 parts - a task with more than five
+    # retrieval sub-tasks takes the torch.distributed path below instead of failing)
+    if comm.enabled() and tensors[0].is_cuda and len(tensors) <= 8:
         return comm.get().allgather_packed(tensors)
     b = tensors[0].shape[0]
     flat = [t.detach().contiguous().view(b, -1).view(torch.uint8) for t in tensors]

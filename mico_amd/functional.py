@@ -350,9 +350,9 @@ class TowerDiet:
     bit-for-bit recompute of the fp32 copies, which is why a step that fits without it does not use it).
     level: the legacy uniform levels 0 (keep all) / 1 (no MLP intermediates) / 2 (nor LayerNorm outputs) with fp32 rows, 3 = xh16 rows with
     nothing else kept except the MLP intermediates of the LAST mlp_blocks blocks (the first ones the backward frees)."""
-    __slots__ = ("xh16", "keep_mlp", "keep_ln", "level", "mlp_blocks")
+    __slots__ = ("xh16", "keep_mlp", "keep_ln", "level", "mlp_blocks", "mlp_pre")
 
-    def __init__(self, depth, level=0, mlp_blocks=0, keep=None):
+    def __init__(self, depth, level=0, mlp_blocks=0, keep=None, mlp_pre=None):
         """mlp_blocks: at level 3, the LAST n blocks keep their MLP intermediates; keep (level 3): an explicit set of block indices instead
         (tower_plan picks them by what their recompute costs per byte)."""
         level = int(level)
@@ -367,6 +367,11 @@ class TowerDiet:
         self.keep_mlp = [i in kset for i in range(depth)]
         self.mlp_blocks = len(kset)
         self.keep_ln = [level <= 1] * depth
+        # what a kept block keeps of its MLP: the fc1 pre-activation alone (2 hidden bytes per token; fc2's dX launch re-creates gelu and gelu' from
+        # it: ~0.4 ms per block dearer than the stored pair's launches) or gelu + gelu' (4 hidden bytes).  tower_plan takes the pair when every block
+        # can keep it (configs[2], configs[4]: everything fits) and the pre-activation when memory is what limits the kept blocks (one rank of
+        # configs[3]); a forced level 3 follows runtime.CFG.mlp_keep_pre.
+        self.mlp_pre = (level == 3 and _mlp_keeps_pre()) if mlp_pre is None else (bool(mlp_pre) and _mlp_keeps_pre())
 
     @classmethod
     def of(cls, diet, depth):
@@ -376,7 +381,8 @@ class TowerDiet:
         if self.level < 3:
             return self.level
         kept = [i for i, k in enumerate(self.keep_mlp) if k]
-        return f"3 (fp16 normalised rows; MLP intermediates kept in {len(kept)} of {len(self.keep_mlp)} blocks: {_ranges(kept)})"
+        what = "fc1 pre-activation" if self.mlp_pre else "MLP intermediates"
+        return f"3 (fp16 normalised rows; {what} kept in {len(kept)} of {len(self.keep_mlp)} blocks: {_ranges(kept)})"
 
 
 def _ranges(idx):
@@ -389,6 +395,15 @@ def _ranges(idx):
         out.append(str(idx[i]) if i == j else f"{idx[i]}-{idx[j]}")
         i = j + 1
     return ", ".join(out) if out else "none"
+
+
+def _h2d(t, dev):
+    """Host tensor -> device without a stream synchronisation: torch's blocking copy from pageable memory ends in a hipStreamSynchronize - at the
+    top of a step that drains everything the host had queued (tools/probes/sync_probe.py found exactly two such calls per step, both DropPlan's).
+    The pinned staging buffer comes from torch's caching host allocator, which keeps it alive until the copy has run."""
+    if torch.device(dev).type != "cuda":
+        return t.to(dev)
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
 
 
 class DropPlan:
@@ -404,7 +419,7 @@ class DropPlan:
     def __init__(self, scale, n_frames, dev):
         cpu = scale.detach().to("cpu", torch.float32)
         assert cpu.shape[1] == 2 and cpu.shape[2] == n_frames, (tuple(cpu.shape), n_frames)
-        self.scale = scale.detach().to(dev, torch.float32).contiguous()
+        self.scale = _h2d(cpu, dev) if scale.device.type == "cpu" else scale.detach().to(dev, torch.float32).contiguous()
         keep = (cpu != 0).reshape(-1, n_frames)
         if not DropPlan.skip_dropped:
             keep = torch.ones_like(keep)
@@ -412,7 +427,7 @@ class DropPlan:
         DropPlan.stats[0] += sum(self.counts)
         DropPlan.stats[1] += keep.numel()
         frames = keep.nonzero()[:, 1].to(torch.int32)          # row-major: sorted by (block, branch), then frame
-        self.frames = frames.to(dev)
+        self.frames = _h2d(frames, dev)
         self.starts = [0]
         for c in self.counts:
             self.starts.append(self.starts[-1] + c)
@@ -437,11 +452,7 @@ class DropPlan:
         for a_, d_ in zip(n_dst, n_diff):
             self.tr_dst_starts.append(self.tr_dst_starts[-1] + a_)
             self.tr_diff_starts.append(self.tr_diff_starts[-1] + d_)
-        flat = torch.cat((dst, of, ppos[oj, of])).to(torch.int32)
-        if self._dev.type == "cuda":
-            flat = flat.pin_memory().to(self._dev, non_blocking=True)
-        else:
-            flat = flat.to(self._dev)
+        flat = _h2d(torch.cat((dst, of, ppos[oj, of])).to(torch.int32), self._dev)
         n1, n2 = dst.numel(), of.numel()
         self.tr_dst, self.tr_diff_frames, self.tr_diff_dst = flat[:n1], flat[n1:n1 + n2], flat[n1 + n2:]
         self._tr = nb
@@ -694,7 +705,7 @@ def _tower_forward(spec, groups, dp_scale, params, save, diet=0, plan=None):
                 a.update(g1=g1, g2=g2, hsw=hsw, hln=hln, mean_f=mean_f, rstd_f=rstd_f)
             else:
                 act = _empty((M2, Hd), dt, dev)
-                if save and diet.keep_mlp[i] and _mlp_keeps_pre():
+                if save and diet.keep_mlp[i] and diet.mlp_pre:
                     # the block keeps its pre-activation (2 hidden bytes per token): GELU with the pre-activation copy leaving from the registers
                     h, h_tiled = _aux_buf(M2, Hd, D, dt, dev)
                     _gemm_fwd(ln2b, D, [P(b + "mlp.fc1.weight")], "w", act, bias=P(b + "mlp.fc1.bias"), aux_out=h, act=ops.ACT_GELU, aux_tiled=h_tiled)
@@ -1003,8 +1014,8 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     postnorm = bool(spec.arch.get("postnorm"))
     dietable = not spec.arch["swiglu"] and not postnorm
     # (the post-norm block saves fp32 br1 / br2 (8 D), x16a / x16b / ao (6 D), qkv (6 D), act + h (4 hidden): the same 20 D + 4 hidden per token)
-    mlp_b = 2 if (dietable and _mlp_keeps_pre()) else 4      # bytes per hidden unit of a kept token: the pre-activation alone, or gelu + gelu'
-    per_frame = {0: depth * N * (20 * D + mlp_b * Hd)}
+    pre_ok = dietable and _mlp_keeps_pre()      # a kept block may keep its fc1 pre-activation alone (2 bytes per hidden unit) instead of gelu + gelu' (4)
+    per_frame = {0: depth * N * (20 * D + 4 * Hd)}
     if dietable:
         per_frame[1] = depth * N * 20 * D
         per_frame[2] = depth * N * 16 * D
@@ -1015,7 +1026,7 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     levels = [forced_level if forced_level in per_frame else 0] if forced_diet is not None else sorted(per_frame)
     if forced_chunk:
         lv = levels[0] if forced_diet is not None else 0
-        return forced_chunk, TowerDiet(depth, lv, forced_diet[1] if (forced_diet is not None and lv == 3) else 0)
+        return forced_chunk, TowerDiet(depth, lv, forced_diet[1] if (forced_diet is not None and lv == 3) else 0)      # (forced level 3: CFG.mlp_keep_pre decides the stash)
     free, _ = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)    # cached blocks are reusable
     # what the rest of the step needs next to the tower's saved activations - the backward's temporaries, BERT with its cross-attention K/V
@@ -1057,8 +1068,9 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
             most = max(1, int(max(budget, 0) // pf))
             n_chunks = -(-n_frames // most)
             cost = extra[lv] + (n_chunks - 1) / n_chunks
-            keep = None
+            keep, pre = None, False
             if lv == 3 and forced_diet is not None:
+                pre = pre_ok
                 keep = list(range(depth - min(depth, max(0, forced_diet[1])), depth))
             elif lv == 3 and n_chunks == 1:
                 # one pass at level 3: what is left of the budget keeps MLP intermediates, from the LAST block backwards - the backward starts
@@ -1067,23 +1079,36 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
                 # 34-39 against 28-39 at the same 230 GiB peak, 39.96 / 39.74 against 40.31 / 40.38 samples/s in alternating runs: buffers that
                 # live until the END of the backward keep the allocator at the peak for the whole backward.)  A kept block saves its share of
                 # the fc1 recompute, weighted by what its recompute costs.
-                left = budget - pf * n_frames - _MLP_KEEP_MARGIN
-                # (round 6, with ONE tensor per kept block nearly every block fits: the blocks whose recompute is dearest first - the head-split
-                # blocks' fc1 has twice the reduction length - then from the last block backwards; a block that does not fit is skipped, not the end)
-                order = sorted(range(depth), key=lambda i: (-fc1_w[i], -i)) if mlp_b == 2 else list(reversed(range(depth)))
-                keep, saved = [], 0.0
-                for i in order:
-                    need = block_tokens[i] * mlp_b * Hd
-                    if need > left:
-                        if mlp_b == 2:
-                            continue
-                        break
-                    left -= need
-                    saved += fc1_w[i] * block_tokens[i]
-                    keep.append(i)
-                cost = 0.02 + 0.33 * (1.0 - saved / mlp_work_total)
+                # (a staged step priced with the draw's own counts: the estimate was within 1 GiB of the measured peak at 39 and at 40 kept blocks - half
+                # the margin)
+                left0 = budget - pf * n_frames - (_MLP_KEEP_MARGIN // 2 if (runtime.step_staged and exact) else _MLP_KEEP_MARGIN)
+
+                def fill(mlp_b):
+                    # (round 6, with ONE tensor per kept block nearly every block fits: the blocks whose recompute is dearest first - the
+                    # head-split blocks' fc1 has twice the reduction length - then from the last block backwards; a block that does not fit is
+                    # skipped, not the end.  The pair keeps round 5's measured order: from the last block backwards, stop at the first misfit.)
+                    order = sorted(range(depth), key=lambda i: (-fc1_w[i], -i)) if mlp_b == 2 else list(reversed(range(depth)))
+                    left, kp, sv = left0, [], 0.0
+                    for i in order:
+                        need = block_tokens[i] * mlp_b * Hd
+                        if need > left:
+                            if mlp_b == 2:
+                                continue
+                            break
+                        left -= need
+                        sv += fc1_w[i] * block_tokens[i]
+                        kp.append(i)
+                    return kp, sv
+                keep, saved = fill(4)
+                # the pre-activation stash where memory limits the pair: its two launches per kept block (GELU + copy forward, GELU' + gelu(h) in
+                # fc2's dX) cost ~0.04 of a block's forward more than the pair's - far less than the fc1 launch every additional kept block saves
+                if pre_ok and len(keep) < depth:
+                    keep2, saved2 = fill(2)
+                    if saved2 > saved:
+                        keep, saved, pre = keep2, saved2, True
+                cost = 0.02 + 0.33 * (1.0 - saved / mlp_work_total) + (0.01 * len(keep) / depth if pre else 0.0)
             if best is None or cost < best[0] - 1e-9:
-                best = (cost, -(-n_frames // n_chunks), lv, keep)      # equal chunks: the one whose activations are kept is then as large as the others
+                best = (cost, -(-n_frames // n_chunks), lv, keep, pre)      # equal chunks: the one whose activations are kept is then as large as the others
         return best
 
     bs, bh = cheapest(soft), cheapest(hard)
@@ -1092,8 +1117,8 @@ def tower_plan(spec, n_frames, device, kept=1.0, block_tokens=None):
     else:
         # only chunked recomputation keeps the step under the soft budget and the hard one avoids it: take the hard budget's level and chunking,
         # but none of its optional extras (MLP intermediates kept at level 3)
-        best = (bh[0], bh[1], bh[2], bh[3] if (forced_diet is not None and bh[2] == 3) else None)
-    return best[1], TowerDiet(depth, best[2], keep=best[3] if best[2] == 3 else None)
+        best = (bh[0], bh[1], bh[2], bh[3] if (forced_diet is not None and bh[2] == 3) else None, bh[4])
+    return best[1], TowerDiet(depth, best[2], keep=best[3] if best[2] == 3 else None, mlp_pre=best[4] if best[2] == 3 else False)
 
 
 def tower_chunk_frames(spec, n_frames, device):
@@ -1126,7 +1151,7 @@ class EvaTowerFn(torch.autograd.Function):
                 runtime.last_tower_plan = dict(frames=Bf, frames_per_pass=min(chunk, Bf), diet=diet.level, mlp_blocks_kept=diet.mlp_blocks,
                                                mlp_blocks=_ranges([i for i, k in enumerate(diet.keep_mlp) if k]) if diet.level == 3 else None,
                                                rows_fp16_normalised=diet.xh16, kept_fraction=kept,
-                                               mlp_stash=("pre-activation (2 B per hidden unit)" if _mlp_keeps_pre() else "gelu + gelu' (4 B per hidden unit)"), **more)
+                                               mlp_stash=("pre-activation (2 B per hidden unit)" if diet.mlp_pre else "gelu + gelu' (4 B per hidden unit)"), **more)
             record()
             if (Bf, min(chunk, Bf), diet.level, tuple(diet.keep_mlp)) != EvaTowerFn._logged_plan:   # once per distinct plan and process (= rank)
                 EvaTowerFn._logged_plan = (Bf, min(chunk, Bf), diet.level, tuple(diet.keep_mlp))

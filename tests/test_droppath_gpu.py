@@ -224,7 +224,8 @@ def test_activation_diet_recompute(cuda):
     chunk, diet = Fn.tower_plan(big, 896, cuda, kept=0.8)
     assert diet.level > 0 or chunk < 896          # 896 x 0.82 x 542 MB = 398 GB of level-0 activations exceed the 288 GB of an MI355X
     per_tok = {0: 20 * 1408 + 4 * 6144, 1: 20 * 1408, 2: 16 * 1408, 3: 12 * 1408}[diet.level]
-    mlp_b = 2 if Fn._mlp_keeps_pre() else 4       # a kept block keeps its fc1 pre-activation (round 6) or gelu + gelu'
+    mlp_b = 2 if diet.mlp_pre else 4       # a kept block keeps its fc1 pre-activation (round 6: where memory limits the kept blocks) or gelu + gelu'
+    assert diet.mlp_pre == (Fn._mlp_keeps_pre() and diet.level == 3 and diet.mlp_blocks > 0)      # 896 frames never fit 40 pairs
     acts = chunk * 0.82 * 257 * (40 * per_tok + (diet.mlp_blocks * mlp_b * 6144 if diet.level == 3 else 0))
     assert acts < torch.cuda.mem_get_info(cuda)[1]
     print("configs[3] rank share on this box:", chunk, "frames per pass, diet", diet.describe())
@@ -233,15 +234,11 @@ def test_activation_diet_recompute(cuda):
     # of SOME blocks kept from what the smaller rows free (round 4: level 2, 231 GiB measured), leaving room for RCCL and a second reducer
     if torch.cuda.mem_get_info(cuda)[0] > 250 << 30:
         assert (chunk, diet.level) == (896, 3) and 4 <= diet.mlp_blocks <= (40 if mlp_b == 2 else 24), (chunk, diet.describe())
-        if mlp_b == 2 and diet.mlp_blocks < 40:      # what is dropped is never a head-split block (their fc1 recompute costs twice)
-            old_h = runtime.CFG.head_split_blocks
-            runtime.CFG.head_split_blocks = 4
-            try:
-                with runtime.precision(torch.float16):
-                    _, dh = Fn.tower_plan(big, 896, cuda, kept=0.8)
-                assert all(dh.keep_mlp[:4]) or dh.mlp_blocks < 4, dh.describe()
-            finally:
-                runtime.CFG.head_split_blocks = old_h
+        if mlp_b == 2 and diet.mlp_blocks < 40:      # what is dropped is never a head-split block of the timed precision (their fc1 recompute costs twice)
+            from common import precision_config
+            with precision_config("timed"):
+                _, dh = Fn.tower_plan(big, 896, cuda, kept=0.8)
+            assert all(dh.keep_mlp[:4]) and dh.mlp_blocks >= diet.mlp_blocks - 1, dh.describe()
         proj = torch.cuda.memory_allocated(cuda) + (12 << 30) + 896 * (52 << 20) + acts
         assert proj < Fn._SOFT_FRAC * torch.cuda.mem_get_info(cuda)[1]
         # with the per-block kept tokens of a real draw (later blocks keep fewer frames) the last blocks are cheaper than the average

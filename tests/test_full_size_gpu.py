@@ -81,7 +81,7 @@ def test_full_size_config(cuda, name, vtype, cfg, task, conds, nsub):
         b2["_injected"] = {st: dict(neg_cond_idx=torch.arange(ft.shape[0]).roll(1), neg_text_idx=torch.arange(ft.shape[0]).roll(1))}
         loss_e = m2(b2, "ret%" + st)["loss_itc"]
     assert abs(float(loss_e) - float(itc_host)) < 2e-3 * float(itc_host)
-    print(name, {k: float(v) for k, v in out.items()}, "itc(eval)", float(loss_e), float(itc_host))
+    print(name, {k: float(v.detach()) for k, v in out.items()}, "itc(eval)", float(loss_e.detach()), float(itc_host))
 
 
 def test_config5_video_caption_step(cuda):
