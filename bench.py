@@ -691,7 +691,7 @@ def main():
     roofline = head.pop("roofline")
     if roofline is not None:
         dom = roofline.pop("_dom")
-        for tname in ("r05_gemm_hbm_traffic.json", "r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json"):
+        for tname in ("r06_gemm_hbm_traffic.json", "r05_gemm_hbm_traffic.json", "r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and world == 1:
                 tj = json.load(open(tpath))
@@ -748,7 +748,10 @@ def main():
         # ---- the timed precision against the reference goldens, measured here and now ----
         del batch
         release_memory()
-        res["parity"] = dict(precision=PRECISIONS[args.dtype][3], **measure_parity(model, dev))
+        # (rank 0 alone from here on - the other ranks wait at the final barrier: its alignment steps must not enter collectives)
+        from mico_amd.distributed import local_only
+        with local_only():
+            res["parity"] = dict(precision=PRECISIONS[args.dtype][3], **measure_parity(model, dev))
     if extras and world == 1:
         # ---- the other ViT-g/14 configuration of BASELINE.json, timed as a first-class object next to the headline: configs[2] (image +
         # audio + text, 5 frames per sample: the headline of rounds 1-3) when the headline is the omni share, and vice versa

@@ -29,12 +29,27 @@ def force_dist(on=True):
     return old
 
 
+_LOCAL = [0]
+
+
+class local_only:
+    """Context in which an initialised process group is ignored (is_dist() is False): work ONE rank does on its own while the others wait - e.g.
+    bench.py's in-run parity measurement on rank 0 of an N > 1 job, whose alignment step would otherwise enter collectives nobody else joins."""
+
+    def __enter__(self):
+        _LOCAL[0] += 1
+
+    def __exit__(self, *exc):
+        _LOCAL[0] -= 1
+        return False
+
+
 def _nccl():
     return dist.get_backend() == "nccl"
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+    return not _LOCAL[0] and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():

@@ -18,7 +18,10 @@ python tools/pmc_sq.py $O/sq $O/${TAG}_sq_counters.txt > /dev/null 2>&1
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1)
 python tools/prof_summary.py $f 45 > $O/${TAG}_kernel_stats.txt; cp $f $O/${TAG}_kernel_stats.csv
 $B --steps 10 --warmup 3 --gemm-detail > $O/bench_detail.json 2> $O/${TAG}_gemm_detail.txt
-python bench.py > $O/${TAG}_bench_line.json 2> $O/bench_line.err
+MICO_BENCH_FULL=$O/${TAG}_bench_full.json python bench.py > $O/${TAG}_bench_line.json 2> $O/bench_line.err
+python tools/probes/sync_probe.py > $O/${TAG}_sync_probe.txt 2>&1
+# the round's A/B: round 5's step (pair stash, direct backward) against the default (pre-activation stash where memory limits, staged backward), alternating
+bash tools/probes/stash_ab.sh $O > $O/${TAG}_stash_staged_ab.txt 2>&1
 if [ "${PROFILE_VIDCAP:-0}" = 1 ]; then
   # BASELINE configs[4] shapes: the fp8 mode and the same step in bf16 on the same box (two alternating pairs), + the fp8 step's kernel table
   for i in 1 2; do
