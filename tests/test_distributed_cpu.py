@@ -93,6 +93,58 @@ def _reducer(rank, world):
             assert torch.allclose(p.grad, sum(gs) / world, atol=1e-6)
 
 
+def _staged_reducer(rank, world):
+    """The staged step's contract with the reducer (round 6, MiCo.forward(backward_scale=...)): a "head" that is differentiated INSIDE the forward,
+    twice (two condition sets), against a detached leaf of the "tower" output - its parameters accumulate gradients before the step's one real
+    backward, one of them (shared with the main graph, like BERT's text pass) a third time in it - and the tower gets the leaf's gradient through
+    mico_forward._StagedLoss.  The reducer's bucket hooks must ignore the staged accumulations (distributed.staged_backward) and the averaged
+    gradients must equal those of the direct form, also with a loss scale other than 1."""
+    from mico_amd.distributed import GradBucketReducer, staged_backward
+    from mico_amd.model.mico_forward import _StagedLoss
+    torch.manual_seed(0)
+    tower = torch.nn.Linear(6, 5)
+    shared = torch.nn.Linear(5, 4)        # used by the main graph AND by the staged heads
+    head = torch.nn.Linear(4, 1)          # staged only
+    params = list(tower.parameters()) + list(shared.parameters()) + list(head.parameters())
+    g = torch.Generator().manual_seed(7 + rank)
+    x = torch.randn(9, 6, generator=g)
+
+    def losses(feat, sets):
+        main = shared(feat).square().mean()
+        staged = [head(torch.tanh(shared(feat * (k + 1)))).square().mean() for k in range(sets)]
+        return main, staged
+
+    def direct(scale):
+        for p in params:
+            p.grad = None
+        main, staged = losses(tower(x), 2)
+        ((main + sum(staged)) * scale).backward()
+
+    red = GradBucketReducer(params, bucket_bytes=64)
+    direct(1.0)
+    red.finish()
+    want = [p.grad.clone() for p in params]
+    for scale in (1.0, 8.0):
+        for p in params:
+            p.grad = None
+        feat = tower(x)
+        leaf = feat.detach().requires_grad_(True)
+        total = None
+        for k in range(2):
+            lk = head(torch.tanh(shared(leaf * (k + 1)))).square().mean()
+            with staged_backward():
+                torch.autograd.backward(lk * scale)
+            total = lk.detach() if total is None else total + lk.detach()
+        assert head.weight.grad is not None and tower.weight.grad is None
+        out = _StagedLoss.apply(total, float(scale), 1, feat, leaf.grad)
+        main = shared(feat).square().mean()
+        ((main + out) * scale).backward()
+        red.finish()
+        for p, w in zip(params, want):
+            assert torch.allclose(p.grad / scale, w, atol=1e-6, rtol=1e-5), (scale, (p.grad / scale - w).abs().max())
+    red.close()
+
+
 class _ArenaFn(torch.autograd.Function):
     """Stand-in for the ViT tower's backward: parameter gradients live in one flat arena, the finished slice is announced to
     runtime.grad_slice_hook() from INSIDE the backward (functional._tower_backward does this per block)."""
@@ -197,7 +249,7 @@ def _targets(rank, world):
     assert (w[torch.arange(b), targets] == 0).all() and (w > 0).sum() == b * (world * b - 1)
 
 
-@pytest.mark.parametrize("fn", [_packed, _fetch, _reducer, _arena_reducer, _targets])
+@pytest.mark.parametrize("fn", [_packed, _fetch, _reducer, _staged_reducer, _arena_reducer, _targets])
 def test_world2_gloo(fn):
     run2(fn)
 
