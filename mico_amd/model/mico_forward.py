@@ -218,6 +218,9 @@ class _StagedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
+        if ctx.grads is None:
+            raise RuntimeError("_StagedLoss: a second backward through a staged step - its BERT side was differentiated inside the forward and the "
+                               "condition-token gradients were handed over (scaled in place) by the first one; run the forward again")
         f = (go / ctx.scale).to(torch.float32)
         grads, ctx.grads = ctx.grads, None
         return (None, None, None) + tuple(g.mul_(f) for g in grads) + (None,) * ctx.n
@@ -309,7 +312,10 @@ def forward(self, batch, task, compute_loss=True, backward_scale=None):
     runtime.mem_trace("step start")
     staged = backward_scale is not None and compute_loss and torch.is_grad_enabled() and _share_cross_kv(self)
     runtime.step_staged = staged      # (functional.tower_plan: a staged step needs less memory next to the towers' saved activations)
-    enc = encode_batch(self, batch)
+    try:
+        enc = encode_batch(self, batch)
+    finally:
+        runtime.step_staged = False   # (the plan is made inside the tower's forward: a tower pass outside MiCo.forward is priced as a direct step)
     runtime.mem_trace("after encode_batch")
     if staged:
         return _forward_staged(self, batch, task, enc, float(backward_scale))
