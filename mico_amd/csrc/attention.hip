@@ -161,16 +161,22 @@ __device__ __forceinline__ float mask_val(const float* mask, int mode, int b, in
 // RB = 16-row query blocks per wave.  With RB = 1 every K / V^T fragment read from LDS feeds one MFMA, and the kernel is bound by
 // LDS bandwidth at twice the MFMA time (24.5 KB of LDS reads per 24 MFMAs per wave and key tile); RB = 2 (long self-attention:
 // the ViT towers) reuses each fragment for two query blocks and stages every K/V tile for 128 instead of 64 queries.
-template <typename T, int HDP, bool DROP, int RB>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                          const T* __restrict__ v, T* __restrict__ o,
-                                                          float* __restrict__ lse, const mico_attn_params p) {
+// NW = waves per workgroup (round 6).  4: 64 RB query rows per workgroup.  5: 80 - BERT's 77 text rows in training (dropout: RB = 1) as ONE
+// workgroup per (b, h) instead of two of 64 + 13 rows: the second one staged every key tile again for one live wave, and since the two sit on
+// different XCDs (consecutive workgroup ids) the K / V rows of every head were fetched twice - the cross-attention forward ran at 2.1 TB/s of
+// algorithmic K / V bytes on an HBM-bound kernel.  The fifth wave takes no part in the staging (the tile map covers 256 threads); every wave's
+// arithmetic is unchanged, so the results are bit for bit the four-wave kernel's.
+template <typename T, int HDP, bool DROP, int RB, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                              const T* __restrict__ v, T* __restrict__ o,
+                                                              float* __restrict__ lse, const mico_attn_params p) {
     using C = Cfg<HDP>;
     __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE];
     LDS_AS char* kt = (LDS_AS char*)smem;
     LDS_AS char* vt = kt + C::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * RB);
+    const bool stager = NW == 4 || tid < 256;      // (wave-uniform)
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (NW * 16 * RB);
     const T* qb = q + (int64_t)b * p.q_bs + h * p.hd;
     const int kvb = p.kv_batch_mod > 0 ? b % p.kv_batch_mod : b;   // shared K/V memory (see mico_attn_params)
     const T* kb = k + (int64_t)kvb * p.k_bs + h * p.hd;
@@ -195,18 +201,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     const int nt = (p.Sk + 63) / 64;
     const TileMap<HDP> tm_a = tile_map<HDP>(p.k_rs, p.hd, tid), tm_b = tile_map<HDP>(p.v_rs, p.hd, tid);
     s16x8 kr[C::NCH], vr[C::NCH];
-    tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, tm_a);
-    tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, tm_b);
+    if (stager) {
+        tile_fetch<T, HDP>(kr, kb, p.k_rs, 0, p.Sk, tm_a);
+        tile_fetch<T, HDP>(vr, vb, p.v_rs, 0, p.Sk, tm_b);
+    }
     PH_DECL;
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
         PH(0);
-        tile_commit<HDP>(kr, kt, tm_a);
-        tile_commit<HDP>(vr, vt, tm_b);
+        if (stager) {
+            tile_commit<HDP>(kr, kt, tm_a);
+            tile_commit<HDP>(vr, vt, tm_b);
+        }
         PH(1);
         __syncthreads();
         PH(2);
-        if (t + 1 < nt) {
+        if (stager && t + 1 < nt) {
             tile_fetch<T, HDP>(kr, kb, p.k_rs, (t + 1) * 64, p.Sk, tm_a);
             tile_fetch<T, HDP>(vr, vb, p.v_rs, (t + 1) * 64, p.Sk, tm_b);
         }
@@ -2935,9 +2945,17 @@ extern "C" int mico_attn_fwd(const void* q, const void* k, const void* v, void* 
     // cross-attention forward 0.219 -> 0.164 ms.  With dropout the two-block variant needs 227 registers instead of 116 and is slower
     // in situ (134 vs 119 us), as is the same change in the dQ kernel (192 vs 124 registers: -10 %): occupancy wins there.)
     const bool two = p->Sq > 64 && p->drop_p <= 0.f;
-    const int qpw = two ? 128 : 64;
+    // (round 6) 65 .. 80 query rows with dropout - BERT's 77 text rows in training: five waves of 16 rows, one workgroup per (b, h) (see the kernel)
+    static const bool no_five = getenv("MICO_ATTN_NOFIVE") != nullptr;   // A/B switch
+    const bool five = !two && !no_five && p->drop_p > 0.f && p->Sq > 64 && p->Sq <= 80 && p->hd <= 64;
+    const int qpw = two ? 128 : (five ? 80 : 64);
     const dim3 grid((p->Sq + qpw - 1) / qpw, p->H, p->B);
 #define ATTN_FWD_LAUNCH(DROP, RB) MICO_LAUNCH((attn_fwd_kernel<T, HDP, DROP, RB>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p)
+    if (five) {
+        DISPATCH_T16(dtype, MICO_LAUNCH((attn_fwd_kernel<T, 64, true, 1, 5>), grid, dim3(320), 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, *p));
+        MICO_LAUNCH_CHECK();
+        return MICO_OK;
+    }
     DISPATCH_T16(dtype, ATTN_DISPATCH_HD(p->hd, {
         if (two) ATTN_FWD_LAUNCH(false, 2);
         else if (p->drop_p > 0.f) ATTN_FWD_LAUNCH(true, 1);

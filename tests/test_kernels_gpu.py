@@ -690,6 +690,47 @@ def test_attention_short_queries(cuda, dtype, Sq, Sk, mask_kind, drop):
         assert err.max().item() < tol(dtype, 4), (name, err.max().item(), err.argmax().item())
 
 
+_FIVE_CASE = """
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from mico_amd import ops
+dtype = torch.float16 if sys.argv[3] == "f16" else torch.bfloat16
+cuda = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(11)
+n, H, hd, Sq, Sk = 4, 12, 64, 77, 517
+B, D = 3 * n, H * hd
+q = torch.randn(B, Sq, D, generator=g).to(cuda).to(dtype)
+kv = torch.randn(2 * n, Sk, 2 * D, generator=g).to(cuda).to(dtype)      # [own | neg] sets, K | V per row: the ITM triplet reads them modulo 2 n
+o = torch.empty(B, Sq, D, device=cuda, dtype=dtype)
+lse = torch.empty(B, H, Sq, device=cuda)
+ops.attn_fwd(q, kv, kv[:, :, D:], o, lse, B=B, H=H, Sq=Sq, Sk=Sk, hd=hd, scale=hd ** -0.5, drop=(0.1, 1234, 20), kv_batch_mod=2 * n,
+             q_strides=(Sq * D, D), k_strides=(Sk * 2 * D, 2 * D), v_strides=(Sk * 2 * D, 2 * D), o_strides=(Sq * D, D))
+torch.cuda.synchronize()
+torch.save((o.cpu(), lse.cpu()), sys.argv[2])
+"""
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_five_wave_forward_is_the_four_wave_arithmetic(cuda, dtype, tmp_path):
+    """Round 6: BERT's 77 query rows in training run the tiled forward as ONE five-wave workgroup per (b, h) (attn_fwd_kernel<.., NW = 5>) instead of
+    two four-wave ones of 64 + 13 rows - every K / V tile staged once.  Same per-wave arithmetic: outputs and lse bit for bit those of the four-wave
+    launch (MICO_ATTN_NOFIVE=1, a process of its own: the switch is read once), on the ITM triplet's shared K/V memory with dropout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, env in (("five", {}), ("four", {"MICO_ATTN_NOFIVE": "1"})):
+        f = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, "-c", _FIVE_CASE, root, f, "f16" if dtype == torch.float16 else "bf16"], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(torch.load(f))
+    (o5, l5), (o4, l4) = outs
+    assert torch.isfinite(o5.float()).all() and o5.float().abs().max() > 0
+    assert torch.equal(o5.view(torch.int16), o4.view(torch.int16)) and torch.equal(l5, l4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_elementwise(cuda, dtype):
     from mico_amd import ops
