@@ -417,3 +417,26 @@ def test_dkv_session_contract_under_the_autograd_engine():
             assert DkvSession.accumulated - a0 == expect, (can, DkvSession.accumulated - a0)
             for r, g in zip(ref, got):
                 assert torch.allclose(r, g, rtol=1e-5, atol=1e-5), can
+
+
+def test_bench_compact_line_keeps_the_contract():
+    """bench.py's stdout line is the compact form of the full record (round 6: the round-5 line was > 8 KB and a driver's tail cut its head off):
+    every contract field verbatim, `roofline` with the step-level figures, `cpu_baseline`, and it fits a tail.  Input: the committed full record of
+    the round's collection (profiles/r06_bench_full.json)."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r06_bench_full.json")))
+    line = bench.compact_line(full)
+    txt = json.dumps(line)
+    assert len(txt) < 8192
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert line["config"]["workload"] == full["config"]["workload"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["step_frac"] == full["step_mfma_frac"] and r["executed_tflop_per_sample"] == full["tflop_per_sample"]["executed"]
+    assert abs(r["step_frac"] - r["executed_tflop_per_sample"] * full["value"] / 2500.0) < 1e-6      # the step figure is recomputable from the line
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["kind"] == "port"
+    assert line["parity"]["worst"] == full["parity"]["worst"] < line["parity"]["gate"]
+    assert "configs2_img_aud_txt_bf16" in line["secondary"]
