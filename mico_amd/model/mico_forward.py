@@ -227,7 +227,7 @@ class _StagedLoss(torch.autograd.Function):
 
 
 def _forward_staged(self, batch, task, enc, scale):
-    """forward(compute_loss=True) with the BERT passes differentiated ONE CONDITION SET AT A TIME inside the forward (round 6; DESIGN.md section 2a).
+    """forward(compute_loss=True) with the BERT passes differentiated ONE CONDITION SET AT A TIME inside the forward (round 6; DESIGN.md section 2).
     The direct form builds every ITM / captioning graph, their cross-attention K/V memories and, in the backward, their gradients on top of the
     towers' complete activation stash (profiles/r05_mem_trace.txt: the step's peak is the second triplet's BertFn.backward).  Here the towers'
     condition tokens are cut out of the graph (detached leaves, one per modality), and for each condition set (e.g. "va": the tva triplet + the
