@@ -2195,6 +2195,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __rest
                 const int j = k0 + kbk * 16 + (lane & 15);      // this lane's key
                 const bool jv = j < p.Sk;
                 const int jc = jv ? j : p.Sk - 1;
+                // (round 6) an accumulating launch (the shared own set's second / third reader) adds to what the rows hold: their old values are
+                // requested HERE, a key block's worth of MFMA / softmax work ahead of the store that needs them - loaded next to the store, every key
+                // block waited a memory round trip for them.  MASK == 0 only (cross-attention: the one place that accumulates; the masked
+                // instantiations have no registers to spare)
+                T* const dkb = dk + (int64_t)b * p.k_bs + (int64_t)jc * p.k_rs + h * HD;
+                T* const dvb = dv + (int64_t)b * p.v_bs + (int64_t)jc * p.v_rs + h * HD;
+                s16x4 okd[4], ovd[4];
+                if (MASK == 0 && p.dkv_accumulate == 1) {      // (2: the A/B form of the launcher's MICO_SMALLQ_NOPF - loaded next to the store)
+#pragma unroll
+                    for (int td = 0; td < 4; ++td) {
+                        okd[td] = *(const s16x4*)(dkb + td * 16 + g * 4);
+                        ovd[td] = *(const s16x4*)(dvb + td * 16 + g * 4);
+                    }
+                }
                 float mk1 = 0.f;
                 if (MASK == 1) mk1 = p.mask[(int64_t)b * p.Sk + jc] * LOG2E;
                 f32x4 s[5], dp[5];
@@ -2254,14 +2268,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_smallq_kernel(const T* __rest
                     }
                 }
                 if (jv) {
-                    T* dkb = dk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * HD;
-                    T* dvb = dv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * HD;
 #pragma unroll
                     for (int td = 0; td < 4; ++td) {
                         const int d = td * 16 + g * 4;
                         if (p.dkv_accumulate) {   // (launch-uniform) the rows already hold another batch entry's gradient for the same K/V set
-                            dka[td] += unpack4<T>(*(const s16x4*)(dkb + d));
-                            dva[td] += unpack4<T>(*(const s16x4*)(dvb + d));
+                            if (MASK == 0 && p.dkv_accumulate == 1) {
+                                dka[td] += unpack4<T>(okd[td]);
+                                dva[td] += unpack4<T>(ovd[td]);
+                            } else {
+                                dka[td] += unpack4<T>(*(const s16x4*)(dkb + d));
+                                dva[td] += unpack4<T>(*(const s16x4*)(dvb + d));
+                            }
                         }
                         *(s16x4*)(dkb + d) = pack4<T>(dka[td][0], dka[td][1], dka[td][2], dka[td][3]);
                         *(s16x4*)(dvb + d) = pack4<T>(dva[td][0], dva[td][1], dva[td][2], dva[td][3]);
@@ -2978,7 +2995,10 @@ extern "C" int mico_attn_bwd(const void* q, const void* k, const void* v, const 
     static const bool no_smallq = getenv("MICO_ATTN_NOSMALLQ") != nullptr;   // A/B switch (tools/probes/drop_cost.py)
     if (!no_smallq && p->hd == 64 && p->Sq <= SqCfg::QMAX && (p->drop_p <= 0.f || (unsigned long long)(p->B + p->batch0) * p->H * p->Sq * p->Sk <= 0xFFFFFFFFull)) {
         const dim3 grid(p->H, p->B);
-#define SQ_LAUNCH(DROP, MASK) MICO_LAUNCH((attn_bwd_smallq_kernel<T, DROP, MASK>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, *p)
+        static const bool no_pf = getenv("MICO_SMALLQ_NOPF") != nullptr;      // A/B switch: the accumulated rows' old values loaded next to their store (round 5's form)
+        mico_attn_params pp = *p;
+        pp.dkv_accumulate = p->dkv_accumulate ? (no_pf ? 2 : 1) : 0;
+#define SQ_LAUNCH(DROP, MASK) MICO_LAUNCH((attn_bwd_smallq_kernel<T, DROP, MASK>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, (T*)dq, (T*)dk, (T*)dv, pp)
         DISPATCH_T16(dtype, {
             if (p->drop_p > 0.f) { if (p->mask_mode == 0) SQ_LAUNCH(true, 0); else if (p->mask_mode == 1) SQ_LAUNCH(true, 1); else SQ_LAUNCH(true, 2); }
             else { if (p->mask_mode == 0) SQ_LAUNCH(false, 0); else if (p->mask_mode == 1) SQ_LAUNCH(false, 1); else SQ_LAUNCH(false, 2); }

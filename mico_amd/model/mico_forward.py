@@ -310,7 +310,9 @@ def forward(self, batch, task, compute_loss=True, backward_scale=None):
     losses with before its single backward() (1.0, or GradScaler.get_scale())."""
     batch = dict(batch) if not isinstance(batch, dict) else batch
     runtime.mem_trace("step start")
-    staged = backward_scale is not None and compute_loss and torch.is_grad_enabled() and _share_cross_kv(self)
+    kinds = [t.split("%")[0] for t in task.split("_")]
+    # (a task string that names a branch twice keeps the direct form, whose later branch overwrites the earlier one's losses - vast.py:317-348)
+    staged = backward_scale is not None and compute_loss and torch.is_grad_enabled() and _share_cross_kv(self) and len(set(kinds)) == len(kinds)
     runtime.step_staged = staged      # (functional.tower_plan: a staged step needs less memory next to the towers' saved activations)
     try:
         enc = encode_batch(self, batch)
