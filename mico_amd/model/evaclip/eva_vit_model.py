@@ -110,7 +110,7 @@ class EVAVisionTransformer(nn.Module):
         self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, embed_dim))
         self.rope = _Rope(embed_dim // num_heads, img_size // patch_size) if rope else None
         hidden = int(embed_dim * mlp_ratio)
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]   # eva_vit_model.py:533
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]   # eva_vit_model.py:533
         self.blocks = nn.ModuleList([_Block(embed_dim, hidden, subln, naiveswiglu, dpr[i]) for i in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.head = nn.Linear(embed_dim, num_classes)

@@ -115,7 +115,7 @@ class SwinTransformer(nn.Module):
         self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, patch_norm)
         res = self.patch_embed.patches_resolution[0]
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]     # swin.py:541
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths), device="cpu")]     # swin.py:541
         self.layers = nn.ModuleList([
             BasicLayer(int(embed_dim * 2 ** i), (res // 2 ** i, res // 2 ** i), depths[i], num_heads[i], window_size, mlp_ratio, qkv_bias,
                        dpr[sum(depths[:i]):sum(depths[:i + 1])], i < self.num_layers - 1) for i in range(self.num_layers)])
